@@ -1,0 +1,241 @@
+/*
+ * dsk.h -- C ABI of the MI355X (gfx950) single-batch DeepSeek decode engine.
+ *
+ * This is the drop-in boundary for ONE hot path of andrewkchan/deepseek.cpp:
+ *   Model::forward -> Model::_forward_cpu -> Block::_block_cpu
+ *   (reference src/model.cpp:874-883, src/infer.cpp:1265-1317, src/infer.cpp:810-932)
+ * The reference dispatches that path on `enum class Device` (src/model.h:36-38,
+ * src/model.cpp:290-322,874-883).  A maintainer adds one enumerator (Device::HIP)
+ * and routes Model::forward to dsk_forward(); main/sampler/tokenizer/codec stay
+ * unchanged (see INTEGRATION.md for the binding a maintainer would write).
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes, no C++/torch types in any signature
+ *   - every function returns 0 on success, a negative dsk_status on failure and never
+ *     aborts across the boundary (the reference prints "FATAL:" and assert(false)s,
+ *     src/model.cpp:131-132); the message is available from dsk_last_error()
+ *   - host pointers passed to dsk_model_bind() need to stay valid only for the call:
+ *     the engine copies (and re-lays-out) the bytes into HBM and owns device memory
+ *   - one host thread drives one context; one HIP stream per context
+ */
+#ifndef DSK_H
+#define DSK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSK_ABI_VERSION 1
+
+typedef enum dsk_status {
+  DSK_OK = 0,
+  DSK_ERR_INVALID = -1,      /* bad argument / shape / role */
+  DSK_ERR_UNSUPPORTED = -2,  /* valid in the reference but not built here */
+  DSK_ERR_HIP = -3,          /* a HIP runtime call failed */
+  DSK_ERR_STATE = -4,        /* call out of order (e.g. forward before finalize) */
+  DSK_ERR_NOMEM = -5,
+  DSK_ERR_COMM = -6          /* RCCL failure */
+} dsk_status;
+
+/* Quant of in-memory tensors; same order as reference `enum class Quant` (src/codec.h:79-85). */
+typedef enum dsk_quant {
+  DSK_QUANT_F32 = 0,
+  DSK_QUANT_F16 = 1,
+  DSK_QUANT_F8E5M2 = 2,
+  DSK_QUANT_Q2_K = 3,
+  DSK_QUANT_Q3_K = 4
+} dsk_quant;
+
+/* reference `enum class InferenceMode` (src/model.h:40-43) */
+typedef enum dsk_mode {
+  DSK_MODE_HYDRATE_KV_CACHE = 0, /* update KV caches only, skip final norm + lm_head (src/infer.cpp:1284-1287) */
+  DSK_MODE_OUTPUT_LOGITS = 1
+} dsk_mode;
+
+enum { DSK_ACT_GELU = 0, DSK_ACT_SILU = 1 };                 /* src/model.h:16-19 */
+enum { DSK_TOPK_GREEDY = 0, DSK_TOPK_GROUP_LIMITED_GREEDY = 1 }; /* src/model.h:25-29 (NOAUX_TC asserts in the reference) */
+enum { DSK_SCORE_SOFTMAX = 0, DSK_SCORE_SIGMOID = 1 };       /* src/model.h:31-34 */
+
+/* POD mirror of reference `struct Config` (src/model.h:47-96); same field meaning. */
+typedef struct dsk_config {
+  int32_t dim;
+  int32_t hidden_dim;
+  int32_t n_layers;
+  int32_t n_heads;
+  int32_t vocab_size;
+  int32_t max_seq_len;
+  float rope_theta;
+  float norm_eps;
+  int32_t act;                    /* DSK_ACT_* */
+  int32_t first_k_dense_replace;
+  int32_t n_shared_experts;
+  int32_t n_routed_experts;
+  int32_t n_active_routed;
+  int32_t moe_intermediate_size;
+  float routed_scaling_factor;
+  int32_t n_group;
+  int32_t norm_topk_prob;         /* bool */
+  int32_t scoring_func;           /* DSK_SCORE_* */
+  int32_t topk_group;
+  int32_t topk_method;            /* DSK_TOPK_* */
+  int32_t has_moegate_bias;       /* bool; also selects rope_v3 (src/infer.cpp:958,1073) */
+  int32_t use_mla;                /* bool; BlockMLA vs BlockMHA */
+  int32_t kv_lora_rank;
+  int32_t q_lora_rank;
+  int32_t qk_nope_head_dim;
+  int32_t qk_rope_head_dim;
+  int32_t v_head_dim;
+  int32_t weight_quant;           /* dsk_quant */
+  int32_t block_size[2];          /* F8E5M2 block scales (src/model.h:85); {0,0} otherwise */
+  int32_t rs_original_max_position_embeddings; /* KV ring modulus (src/infer.cpp:1274-1277) */
+} dsk_config;
+
+/*
+ * Tensor roles = the tensors the reference Block/Model constructors bind by name
+ * (src/model.cpp:184-285, 393-457, 557-616, 766-871).  `layer` is the block index,
+ * or -1 for model-level tensors.  Scales (F8E5M2 only) use role + DSK_ROLE_SCALE.
+ */
+typedef enum dsk_role {
+  /* model level (layer = -1) */
+  DSK_ROLE_EMBED = 0,        /* model.embed.weight   (vocab, dim)            */
+  DSK_ROLE_FINAL_NORM = 1,   /* model.norm.weight    (dim) F32               */
+  DSK_ROLE_OUTPUT = 2,       /* model.output.weight  (vocab, dim); absent => tied to EMBED (src/model.cpp:852-856) */
+  /* per layer */
+  DSK_ROLE_ATTN_NORM = 10,   /* attn.norm.weight      (dim) F32              */
+  DSK_ROLE_Q_A_NORM = 11,    /* attn.q_a_norm.weight  (q_lora_rank) F32      */
+  DSK_ROLE_KV_A_NORM = 12,   /* attn.kv_a_norm.weight (kv_lora_rank) F32     */
+  DSK_ROLE_FFN_NORM = 13,    /* mlp.norm.weight       (dim) F32              */
+  DSK_ROLE_WQ = 14,          /* attn.wq   (n_heads*head_dim, dim)  [q_lora_rank == 0] */
+  DSK_ROLE_WQ_A = 15,        /* attn.wq_a (q_lora_rank, dim)                 */
+  DSK_ROLE_WQ_B = 16,        /* attn.wq_b (n_heads*head_dim, q_lora_rank) [MHA] */
+  DSK_ROLE_WKV_A = 17,       /* attn.wkv_a (kv_lora_rank+rope, dim)          */
+  DSK_ROLE_WKV_B = 18,       /* attn.wkv_b (n_heads*(nope+v), kv_lora_rank) [MHA] */
+  DSK_ROLE_WO = 19,          /* attn.wo   (dim, n_heads*v_head_dim)          */
+  DSK_ROLE_WC = 20,          /* attn.wc   (n_heads*kv_lora_rank, q_lora_rank) [MLA] */
+  DSK_ROLE_WQ_ROPE_B = 21,   /* attn.wq_rope_b (n_heads*rope, q_lora_rank)  [MLA] */
+  DSK_ROLE_WV_B = 22,        /* attn.wv_b (n_heads*v_head_dim, kv_lora_rank) [MLA] */
+  DSK_ROLE_W1 = 23,          /* mlp.w1 (hidden,dim) or (E, moe_inter, dim)   */
+  DSK_ROLE_W2 = 24,          /* mlp.w2 (dim,hidden) or (E, dim, moe_inter)   */
+  DSK_ROLE_W3 = 25,          /* mlp.w3 like w1                               */
+  DSK_ROLE_SHARED_W1 = 26,   /* shared_mlp.w1 (n_shared*moe_inter, dim)      */
+  DSK_ROLE_SHARED_W2 = 27,   /* shared_mlp.w2 (dim, n_shared*moe_inter)      */
+  DSK_ROLE_SHARED_W3 = 28,   /* shared_mlp.w3                                */
+  DSK_ROLE_MOEGATE = 29,     /* moegate.weight (E, dim) always F32 (src/model.cpp:196-198) */
+  DSK_ROLE_MOEGATE_BIAS = 30,/* moegate.bias (E) F32, V3 only                */
+  DSK_ROLE_SCALE = 64        /* add to a weight role for its ".scale" tensor (F32 block scales) */
+} dsk_role;
+
+typedef struct dsk_ctx dsk_ctx;
+typedef struct dsk_model dsk_model;
+
+/* ---- context -------------------------------------------------------------- */
+/* device_ordinal = HIP device index this context (process) drives. */
+int dsk_ctx_create(int device_ordinal, dsk_ctx** out);
+int dsk_ctx_destroy(dsk_ctx* ctx);
+const char* dsk_last_error(void);
+int dsk_abi_version(void);
+
+/* ---- expert-sharded multi-GPU (one process per GPU, RCCL over xGMI) --------
+ * No reference counterpart: routed experts e with
+ * e / ceil(E/world) == rank live on this rank; everything else is replicated.
+ * Per MoE layer the per-slot expert outputs are all-gathered and summed in k order,
+ * so results are bit-identical to the 1-GPU run.  uid = 128-byte ncclUniqueId made
+ * by rank 0 with dsk_comm_unique_id() and broadcast by the launcher. */
+int dsk_comm_unique_id(void* uid128);
+int dsk_comm_init(dsk_ctx* ctx, const void* uid128, int rank, int world);
+
+/* ---- model life-cycle (replaces Model::Model binding, src/model.cpp:756-872) */
+int dsk_model_create(dsk_ctx* ctx, const dsk_config* cfg, dsk_model** out);
+/* Upload one tensor.  `shape` is the logical shape as in QTensor::shape (src/codec.h:107-120;
+ * 0 = unused dim); `bytes` must equal the reference byte count (src/codec.cpp:166-234).
+ * For routed-expert tensors on a sharded context only this rank's experts are kept. */
+int dsk_model_bind(dsk_model* m, int role, int layer, int quant,
+                   const int32_t shape[4], const void* host_ptr, size_t bytes);
+/* Fill EVERY tensor the config requires with valid random blocks directly in HBM
+ * (220 GB of V3 Q2_K does not fit host disk/RAM).  Deterministic in seed. */
+int dsk_model_synthesize(dsk_model* m, uint64_t seed);
+/* Check all required tensors are bound, allocate KV caches (src/model.cpp:459-460,618-619)
+ * and activation scratch (src/model.cpp:677-726). */
+int dsk_model_finalize(dsk_model* m);
+int dsk_model_destroy(dsk_model* m);
+
+/* ---- the hot path (replaces Model::forward, src/model.cpp:874-883) -------- */
+/* One token.  mode == OUTPUT_LOGITS: host_logits receives vocab_size floats
+ * (what InferenceState::logits() holds, src/model.h:137).  HYDRATE: host_logits may be NULL. */
+int dsk_forward(dsk_model* m, int token, int pos, int mode, float* host_logits);
+/* Enable/disable replaying the token step from a captured hipGraph (default on). */
+int dsk_model_set_graph(dsk_model* m, int enable);
+
+/* Algorithmic HBM bytes one forward at `pos` must touch, with true block sizes
+ * (the corrected analogue of Model::active_bytes, src/model.cpp:885-901). */
+double dsk_model_active_bytes(const dsk_model* m, int pos);
+/* Bytes of device memory held by the model (weights + caches + scratch). */
+double dsk_model_device_bytes(const dsk_model* m);
+
+/* ---- observation taps for the parity harness (the reference's dead DEBUG_MODEL
+ * hooks, src/infer.cpp:10-119, show the intended mechanism) ------------------- */
+/* Record the router decision of every MoE layer of the LAST forward.
+ * experts: n_layers*n_active_routed ints (-1 for dense layers); weights likewise. */
+int dsk_model_get_routing(dsk_model* m, int32_t* experts, float* weights);
+/* Copy the residual stream x (dim floats) as it was after `layer` in the last forward;
+ * requires dsk_model_set_trace(m, 1) before the forward (disables the graph). */
+int dsk_model_set_trace(dsk_model* m, int enable);
+int dsk_model_get_trace_x(dsk_model* m, int layer, float* x_out);
+
+/* Per-kernel-class device time of ONE eager forward bracketed by HIP events on the
+ * engine stream.  names: up to max_classes pointers to static strings. */
+typedef struct dsk_kernel_time {
+  const char* name;
+  int32_t launches;
+  float total_ms;
+  double algo_bytes;   /* algorithmic HBM bytes those launches move */
+} dsk_kernel_time;
+int dsk_profile_forward(dsk_model* m, int token, int pos, dsk_kernel_time* out, int max_classes, int* n_classes);
+
+/* ---- op-level entry points (host buffers in/out; mirror the reference's
+ * "exposed for tests" set, src/model.h:503-535, plus the static helpers) ------ */
+/* quantize_row_q8_K_ref (src/quant.cpp:616-653): n % 256 == 0.
+ * qs: n int8; d: n/256 floats; bsums: n/16 int16. */
+int dsk_q8k_quantize(dsk_ctx* ctx, const float* x, int n, int8_t* qs, float* d, int16_t* bsums);
+/* matmul (src/infer.cpp:381-417): out[d] = W(d,n) . x(n).  w: reference byte layout.
+ * scale/block_size: F8E5M2 block scales or NULL. */
+int dsk_gemv(dsk_ctx* ctx, int quant, const void* w, size_t w_bytes, const float* scale,
+             const int32_t block_size[2], int d, int n, const float* x, float* out);
+/* matmul_expert (src/infer.cpp:423-469): slice `expert` of a stacked (E,d,n) tensor. */
+int dsk_gemv_expert(dsk_ctx* ctx, int quant, const void* w, size_t w_bytes, const float* scale,
+                    const int32_t block_size[2], int n_experts, int expert, int d, int n,
+                    const float* x, float* out);
+/* dequantize one row of an embedding table (Model::_copy_embedding, src/infer.cpp:1217-1263). */
+int dsk_embed_row(dsk_ctx* ctx, int quant, const void* w, size_t w_bytes, const float* scale,
+                  const int32_t block_size[2], int vocab, int dim, int token, float* out);
+/* rmsnorm (src/infer.cpp:601-611) */
+int dsk_rmsnorm(dsk_ctx* ctx, const float* x, const float* weight, int size, float eps, float* out);
+/* moe_gate (src/infer.cpp:493-599): scores are the raw router logits (modified in place in the
+ * reference; here read-only).  bias may be NULL. */
+int dsk_moe_gate(dsk_ctx* ctx, const float* scores, const float* bias, int n_routed, int n_active,
+                 int norm_topk_prob, float routed_scaling_factor, int scoring_func, int topk_method,
+                 int n_group, int topk_group, int32_t* active_experts, float* active_weights);
+/* rope / rope_v3 (src/infer.cpp:648-685) on `n_heads` vectors of length d (= rotary dim), in place. */
+int dsk_rope(dsk_ctx* ctx, float* vec, int n_heads, int d, int pos, float theta, int is_v3);
+/* attn over all heads (mha_cpu, src/infer.cpp:1143-1164): kb (kv_len, n_heads*head_dim) f16,
+ * vb (kv_len, n_heads*v_head_dim) f16, q (n_heads*head_dim) -> out (n_heads*v_head_dim). */
+int dsk_attn_mha(dsk_ctx* ctx, const float* q, const uint16_t* kb, const uint16_t* vb, int n_heads,
+                 int head_dim, int v_head_dim, int kv_len, float* out);
+/* attn_mla over all heads (src/infer.cpp:766-804): ckv (kv_len, kv_lora_rank) f16,
+ * krope (kv_len, rope) f16, q_c (n_heads*kv_lora_rank), q_rope (n_heads*rope)
+ * -> out (n_heads*kv_lora_rank); softmax scale 1/sqrt(head_dim). */
+int dsk_attn_mla(dsk_ctx* ctx, const float* q_c, const float* q_rope, const uint16_t* ckv,
+                 const uint16_t* krope, int n_heads, int head_dim, int kv_lora_rank, int rope_dim,
+                 int kv_len, float* out);
+
+/* Measured streaming-read bandwidth of this GPU (GB/s): grid-stride dwordx4 sum over `bytes`
+ * (SURVEY 8d "measured roofline" denominator).  Best of `iters`. */
+int dsk_measure_read_bw(dsk_ctx* ctx, size_t bytes, int iters, double* gbps_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSK_H */
