@@ -1,0 +1,298 @@
+#!/usr/bin/env python
+"""bench.py -- DeepSeek-V3 Q2_K batch-1 decode on MI355X: tok/s + achieved HBM GB/s vs roofline.
+
+    python bench.py --gpus 1 --steps 64 --warmup 8
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one decoded token (one dsk_forward: embed -> 61 blocks -> final norm -> lm_head ->
+logits on the host), BASELINE.json configs[3]: DeepSeek-V3 shapes, Q2_K, 256 routed experts,
+batch = 1.  No real weights exist on the machine (and 220 GB does not fit host storage), so the
+weights are valid random Q2_K blocks generated directly in HBM; token ids are
+U[0, vocab) with seed 0.  Inputs (weights, KV) are resident in HBM when the timed region starts.
+
+N > 1: one process per GPU; routed experts are sharded across ranks (expert e lives on rank
+e // ceil(E/N)), everything else is replicated, one RCCL all-reduce of the per-slot expert outputs
+per MoE layer (include/dsk.h dsk_comm_init).  All ranks decode the SAME token stream, so the total
+work is fixed as N grows: "scaling": "strong".
+
+Prints ONE JSON line on rank 0 (contract in the task statement) extended with
+  "roofline":     dominant kernel class, algorithmic bytes / launch / its HIP-event duration
+  "cpu_baseline": the unmodified reference (oracle/_ref) timed on this box's host cores
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "deepseek.cpp_amd"))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 achievable
+README_TOK_S = 4.02     # reference README.md:26 (V3 Q2_K, MHA path, EPYC 7R13 16 threads) -- BASELINE.md section 1
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--model", default="v3", choices=["v3", "v2lite", "tiny_v3"])
+    ap.add_argument("--quant", default="q2_k")
+    ap.add_argument("--attn", default="mha", choices=["mha", "mla"], help="reference attention path (BlockMHA is the README's)")
+    ap.add_argument("--layers", type=int, default=0, help="override n_layers (0 = the model's own depth)")
+    ap.add_argument("--ctx", type=int, default=1024, help="KV-cache allocation (max_seq_len)")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--profile-steps", type=int, default=4)
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg_full, seconds: float):
+    """Time the reference's own OpenMP CPU path on this box.
+
+    A full-depth V3 checkpoint needs 220 GB of host RAM, so the sample is a reduced-depth,
+    full-width checkpoint (1 dense + 1 MoE block, 32 of the 256 routed experts resident, 8 active,
+    full vocab) whose per-block times are extrapolated to the model's depth -- labelled as such.
+    """
+    from oracle import orc
+    from tools import synth
+    try:
+        R = orc.Ref()
+        kind = "reference"
+    except Exception as e:  # not built / not loadable on this host
+        return dict(value=None, unit="tok/s", cores=0, kind="unavailable", sample=str(e)[:120])
+    ncpu = os.cpu_count() or 1
+    threads = max(1, ncpu // 2)  # README.md:79-84: best ~ half the cores
+    R.set_threads(threads)
+    c = synth.preset(cfg_full.model_name, cfg_full.quant, cfg_full.use_mla)
+    n_dense = min(c.first_k_dense_replace, c.n_layers)
+    n_moe = c.n_layers - n_dense
+    c.n_layers = (1 if n_dense else 0) + (1 if n_moe else 0)
+    c.first_k_dense_replace = 1 if n_dense else 0
+    if c.n_routed_experts > 32:
+        c.n_routed_experts = 32
+        c.n_group = min(c.n_group, 8)
+    c.max_seq_len = 256
+    rng = np.random.default_rng(0)
+
+    def rand_tensor(shape):  # valid random blocks, like dsk_model_synthesize
+        rows = int(np.prod(shape[:-1]))
+        n = shape[-1]
+        if c.quant == "q2_k":
+            b = rng.integers(0, 256, (rows * (n // 256), 84), dtype=np.uint8)
+            d = (rng.uniform(0.5, 1.5, rows * (n // 256)) / np.sqrt(n) / 13.9).astype(np.float16)
+            b[:, 80:82] = d.view(np.uint8).reshape(-1, 2)
+            b[:, 82:84] = (1.5 * d.astype(np.float32)).astype(np.float16).view(np.uint8).reshape(-1, 2)
+            return synth.Tens(b.reshape(*shape[:-1], -1), tuple(shape), synth.QUANT_IDS["q2_k"])
+        w = (rng.standard_normal(shape, dtype=np.float32) / np.sqrt(n)).astype(np.float32)
+        return synth._encode(w, c.quant, c.block_size)
+
+    T = {}
+    F32 = synth.QUANT_IDS["fp32"]
+    H, hd = c.n_heads, c.head_dim
+    T["model.embed.weight"] = rand_tensor((c.vocab_size, c.dim))
+    T["model.output.weight"] = rand_tensor((c.vocab_size, c.dim))
+    T["model.norm.weight"] = synth.Tens(np.ones(c.dim, np.float32), (c.dim,), F32)
+    for l in range(c.n_layers):
+        p = f"model.layers.{l}."
+        for nm, n in (("attn.norm", c.dim), ("mlp.norm", c.dim), ("attn.kv_a_norm", c.kv_lora_rank)):
+            T[p + nm + ".weight"] = synth.Tens(np.ones(n, np.float32), (n,), F32)
+        if c.q_lora_rank > 0:
+            T[p + "attn.q_a_norm.weight"] = synth.Tens(np.ones(c.q_lora_rank, np.float32), (c.q_lora_rank,), F32)
+            T[p + "attn.wq_a.weight"] = rand_tensor((c.q_lora_rank, c.dim))
+        T[p + "attn.wkv_a.weight"] = rand_tensor((c.kv_lora_rank + c.qk_rope_head_dim, c.dim))
+        T[p + "attn.wo.weight"] = rand_tensor((c.dim, H * c.v_head_dim))
+        if c.use_mla:
+            T[p + "attn.wc.weight"] = rand_tensor((H * c.kv_lora_rank, c.q_lora_rank))
+            T[p + "attn.wq_rope_b.weight"] = rand_tensor((H * c.qk_rope_head_dim, c.q_lora_rank))
+            T[p + "attn.wv_b.weight"] = rand_tensor((H * c.v_head_dim, c.kv_lora_rank))
+        else:
+            if c.q_lora_rank > 0:
+                T[p + "attn.wq_b.weight"] = rand_tensor((H * hd, c.q_lora_rank))
+            else:
+                T[p + "attn.wq.weight"] = rand_tensor((H * hd, c.dim))
+            T[p + "attn.wkv_b.weight"] = rand_tensor((H * (c.qk_nope_head_dim + c.v_head_dim), c.kv_lora_rank))
+        if l >= c.first_k_dense_replace:
+            E, mi = c.n_routed_experts, c.moe_intermediate_size
+            T[p + "mlp.w1.weight"] = rand_tensor((E, mi, c.dim))
+            T[p + "mlp.w2.weight"] = rand_tensor((E, c.dim, mi))
+            T[p + "mlp.w3.weight"] = rand_tensor((E, mi, c.dim))
+            if c.n_shared_experts:
+                T[p + "shared_mlp.w1.weight"] = rand_tensor((c.n_shared_experts * mi, c.dim))
+                T[p + "shared_mlp.w2.weight"] = rand_tensor((c.dim, c.n_shared_experts * mi))
+                T[p + "shared_mlp.w3.weight"] = rand_tensor((c.n_shared_experts * mi, c.dim))
+            g = (rng.standard_normal((E, c.dim), dtype=np.float32) / np.sqrt(c.dim)).astype(np.float32)
+            T[p + "moegate.weight"] = synth.Tens(g, g.shape, F32)
+            if c.has_moegate_bias:
+                T[p + "moegate.bias"] = synth.Tens(np.zeros(E, np.float32), (E,), F32)
+        else:
+            T[p + "mlp.w1.weight"] = rand_tensor((c.hidden_dim, c.dim))
+            T[p + "mlp.w2.weight"] = rand_tensor((c.dim, c.hidden_dim))
+            T[p + "mlp.w3.weight"] = rand_tensor((c.hidden_dim, c.dim))
+    d = tempfile.mkdtemp(prefix="dsk_cpu_baseline_")
+    try:
+        synth.write_dseek(d, c, T)
+        del T
+        S = R.session(d, c, context=256)
+        import ctypes as C
+        R.lib.ref_forward_timed.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        per = (C.c_double * (c.n_layers + 1))()
+        tok = np.random.default_rng(0).integers(0, c.vocab_size, 4096)
+        R.lib.ref_forward_timed(S.h, int(tok[0]), 0, per)  # warm-up: faults in the mmap'd pages
+        acc = np.zeros(c.n_layers + 1)
+        n, t0 = 0, time.time()
+        while time.time() - t0 < seconds and n < 200:
+            R.lib.ref_forward_timed(S.h, int(tok[n + 1]), n + 1, per)
+            acc += np.array(list(per))
+            n += 1
+        acc /= max(n, 1)
+        t_dense = acc[0] if n_dense else 0.0
+        t_moe = acc[c.n_layers - 1] if n_moe else 0.0
+        t_tok = n_dense * t_dense + n_moe * t_moe + acc[c.n_layers]
+        S.close()
+    finally:
+        for f in os.listdir(d):
+            os.unlink(os.path.join(d, f))
+        os.rmdir(d)
+    return dict(value=round(1.0 / t_tok, 4), unit="tok/s", cores=threads, kind=kind,
+                sample=(f"unmodified reference (oracle/_ref, OpenMP {threads} threads of {ncpu} cpus): {n} tokens on a "
+                        f"{cfg_full.model_name}-shaped {c.quant} checkpoint with {c.n_layers} blocks "
+                        f"({c.n_routed_experts} experts resident), per-block times "
+                        f"[dense {t_dense*1e3:.2f} ms, moe {t_moe*1e3:.2f} ms, head {acc[c.n_layers]*1e3:.2f} ms] "
+                        f"extrapolated to {n_dense}+{n_moe} blocks"))
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    import torch  # plumbing only: rendezvous, barrier, max-reduce; loaded first so one HIP runtime is shared
+    import torch.distributed as dist
+    import dsk
+    from tools import synth
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    ctx = dsk.Ctx(local_rank)
+    if world > 1:
+        uid = [ctx.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(uid[0], rank, world)
+
+    c = synth.preset(a.model, a.quant, a.attn == "mla")
+    c.model_name = a.model
+    if a.layers > 0:
+        c.n_layers = a.layers
+        c.first_k_dense_replace = min(c.first_k_dense_replace, a.layers)
+    c.max_seq_len = max(a.ctx, a.steps + a.warmup + a.profile_steps + 2)
+    t_build = time.time()
+    M = dsk.Model(ctx, c, None, synth_seed=0)
+    t_build = time.time() - t_build
+    if a.no_graph:
+        M.set_graph(False)
+    tokens = np.random.default_rng(0).integers(0, c.vocab_size, a.steps + a.warmup + a.profile_steps + 1)
+
+    pos = 0
+    for _ in range(a.warmup):
+        M.forward_nocopy(int(tokens[pos]), pos)
+        pos += 1
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        M.forward_nocopy(int(tokens[pos]), pos)  # includes the logits D2H copy
+        pos += 1
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / a.steps * 1e3
+    tok_s = a.steps / dt
+    mid_pos = a.warmup + a.steps // 2
+    algo_bytes = M.active_bytes(mid_pos)
+
+    # ---- roofline of the dominant kernel: eager forwards bracketed by HIP events on the engine stream
+    agg = {}
+    for _ in range(a.profile_steps):
+        for k in M.profile_forward(int(tokens[pos]), pos):
+            g = agg.setdefault(k["name"], dict(launches=0, total_ms=0.0, algo_bytes=0.0))
+            g["launches"] += k["launches"]
+            g["total_ms"] += k["total_ms"]
+            g["algo_bytes"] += k["algo_bytes"]
+        pos += 1
+    roof, kernels = None, {}
+    if agg:
+        for name, g in agg.items():
+            kernels[name] = dict(launches_per_step=g["launches"] // a.profile_steps,
+                                 ms_per_step=round(g["total_ms"] / a.profile_steps, 4),
+                                 gbps=round(g["algo_bytes"] / max(g["total_ms"], 1e-9) / 1e6, 1))
+        dom = max(agg, key=lambda n: agg[n]["total_ms"])
+        g = agg[dom]
+        ach = g["algo_bytes"] / g["total_ms"] / 1e6  # GB/s
+        roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
+                    frac=round(ach / HBM_PEAK_GBPS, 4), traffic=None,
+                    bytes_per_launch=round(g["algo_bytes"] / g["launches"]),
+                    avg_launch_us=round(g["total_ms"] / g["launches"] * 1e3, 2),
+                    token_gbps=round(algo_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                    token_frac=round(algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4))
+    measured_bw = None
+    if rank == 0:
+        try:
+            M.close()
+            measured_bw = round(ctx.measure_read_bw(4 << 30, 5), 1)
+        except Exception:
+            measured_bw = None
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(c, a.cpu_seconds)
+        except Exception as e:
+            cpu = dict(value=None, unit="tok/s", cores=0, kind="failed", sample=repr(e)[:200])
+    if rank == 0:
+        full = a.model == "v3" and a.layers in (0, 61) and a.quant == "q2_k"
+        out = {
+            "metric": "decode tok/s (batch=1) + achieved HBM GB/s vs roofline, DeepSeek-V3 Q2_K",
+            "value": round(tok_s, 3), "unit": "tok/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": round(tok_s / README_TOK_S, 2) if (full and a.attn == "mha") else None,
+            "dtype": "u2xs8->s32 (W2A8 integer dots, f32 scales/activations)" if a.quant in ("q2_k", "q3_k") else "f32",
+            "data": "synthetic (valid random Q2_K blocks generated in HBM, random token ids seed 0)",
+            "config": {"workload": f"DeepSeek-{a.model} {a.quant} batch=1 decode, {c.n_layers} blocks, "
+                                   f"{c.n_routed_experts} routed experts top-{c.n_active_routed}, {a.attn.upper()} path, "
+                                   f"pos {a.warmup}..{a.warmup + a.steps - 1}, logits D2H included",
+                       "parallelism": "1 GPU" if world == 1 else f"experts sharded over {world} GPUs (RCCL all-reduce per MoE layer)",
+                       "hip_graph": not a.no_graph, "model_build_s": round(t_build, 1),
+                       "device_gb": None, "algo_bytes_per_token": round(algo_bytes)},
+            "roofline": roof, "kernels": kernels, "measured_read_gbps": measured_bw, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    barrier()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,164 @@
+// dsk_internal.h -- shared declarations of the gfx950 decode engine (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include "../../include/dsk.h"
+
+#define QK_K 256
+
+// ---- error plumbing (never abort across the boundary; include/dsk.h conventions) ----
+void dsk_set_error(int code, const char* fmt, ...);
+#define DSK_FAIL(code, ...)            \
+  do {                                 \
+    dsk_set_error((code), __VA_ARGS__); \
+    return (code);                     \
+  } while (0)
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) DSK_FAIL(DSK_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+#define DSK_TRY(expr)      \
+  do {                     \
+    int _r = (expr);       \
+    if (_r != DSK_OK) return _r; \
+  } while (0)
+
+// ---- device-side tensor views -------------------------------------------------
+// K-quant matrices are re-laid-out at upload into byte planes (same total bytes as the
+// reference's AoS blocks, src/quant.h:41-52,70-76), so that a wave reads each plane with
+// fully coalesced 16-byte-per-lane loads:
+//   Q2_K: qs  [row][blk][64]   the 2-bit quants, unchanged byte order
+//         sc  [row][blk][16]   scale/min nibbles permuted to "quarter order":
+//                              sc'[4*q + s] = scales[8*h + 2*s + lh], q = 2*h + lh
+//         dm  [row][blk] u32   d (f16) | dmin (f16) << 16
+//   Q3_K: qs  [row][blk][64], hm [row][blk][32], sc [row][blk][12] (packed 6-bit, unchanged),
+//         dm  [row][blk] u16   d (f16)
+// F8E5M2 / F16 / F32 matrices stay row-major as stored; F8 block scales stay (ceil(d/b0), ceil(n/b1)).
+struct DTensor {
+  int quant = DSK_QUANT_F32;
+  int n_experts = 0;  // 0 = plain 2-D (rows, n); >0 = stacked (E, rows, n)
+  int local_experts = 0, expert_base = 0;  // expert-sharded storage: experts [base, base+local)
+  int rows = 0, n = 0;
+  uint8_t* base = nullptr;  // one allocation
+  size_t bytes = 0;         // device bytes of this tensor (weights + scales)
+  // plane pointers (device)
+  uint8_t* qs = nullptr;
+  uint8_t* sc = nullptr;
+  uint8_t* hm = nullptr;
+  uint8_t* dm = nullptr;
+  float* scale = nullptr;   // F8 block scales
+  size_t e_qs = 0, e_sc = 0, e_hm = 0, e_dm = 0, e_scale = 0;  // per-expert strides in bytes (scale: floats)
+  bool bound() const { return base != nullptr; }
+};
+
+// One GEMV "segment": rows of one matrix (or one expert slot of a stacked tensor).
+struct GemvSeg {
+  const uint8_t* qs;  // K-quant: qs plane; F8/F16/F32: the row-major matrix
+  const uint8_t* sc;
+  const uint8_t* hm;
+  const uint8_t* dm;
+  const float* scale;  // F8 block scales (row-major (ceil(d/b0), ncols)) or null
+  // second matrix for the fused GLU pair (w3); same shape as the first
+  const uint8_t* qs2;
+  const uint8_t* sc2;
+  const uint8_t* hm2;
+  const uint8_t* dm2;
+  const float* scale2;
+  size_t e_qs, e_sc, e_hm, e_dm, e_scale;  // expert strides (bytes; scale in floats)
+  const int* expert_ids;    // device: slot -> expert id (null: slot s uses expert `s`, or none)
+  int expert_base, local_experts;  // sharding: skip slots whose expert is not local
+  int n_slots;              // grid.y
+  int rows, n;
+  // activation: q8 (K-quants) or f32
+  const int8_t* a_qs;
+  const float* a_d;
+  const int16_t* a_bsums;
+  const float* a_f32;
+  size_t a_slot_stride;     // elements between consecutive slots' activations (0 = shared)
+  float* out;               // out[slot * out_slot_stride + row]
+  size_t out_slot_stride;
+  int epilogue;             // EPI_*
+  int act;                  // DSK_ACT_* for EPI_GLU
+  int sc_cols, b0, b1;      // F8 scale geometry
+};
+enum { EPI_STORE = 0, EPI_ADD = 1, EPI_GLU = 2 };
+
+// per-token parameters living in device memory so that a captured graph can be replayed
+struct StepParams {
+  int token, pos, kv_sink, kv_pos, kv_len, pad[3];
+  float rope_cs[2 * 64];   // cos,sin for pair j at `pos` (host libm: powf/cosf/sinf, src/infer.cpp:655-658)
+  float rope_cs1[2 * 64];  // same for pos = 1 (attention-sink rotation, src/infer.cpp:1015)
+};
+
+struct NormJob {         // one workgroup of norm_q8_kernel
+  const float* x;        // input vector
+  float* x_store;        // if non-null: write the (combined) input back here
+  const float* weight;   // rmsnorm weight (null: no norm, y = x)
+  int n;                 // length (multiple of 256 if q8 requested)
+  float eps;
+  float* y_f32;          // optional f32 output
+  int8_t* q_qs;          // optional q8 output
+  float* q_d;
+  int16_t* q_bsums;
+  // optional MoE combine folded in front (src/infer.cpp:874-877,900-903):
+  //   x += sum_k w_k * eout[k]  (k order)  then  x += eout[n_add-1] if add_shared
+  const float* eout;     // [n_slots][n]
+  const float* eweights; // [k]
+  int n_routed_slots;
+  int add_shared;        // slot index n_routed_slots holds the shared expert output
+  // optional rope on a tail vector (k_rope), V2 or V3 style
+  float* rope_vec;
+  int rope_d;
+  int rope_v3;
+};
+
+// ---- launchers (kernels_*.hip) --------------------------------------------------
+int launch_gemv(hipStream_t st, int quant, const GemvSeg& seg);
+int launch_quantize_q8k(hipStream_t st, const float* x, int n, int8_t* qs, float* d, int16_t* bsums);
+int launch_norm_jobs(hipStream_t st, const NormJob* jobs, int n_jobs, const StepParams* sp);
+int launch_repack_q2k(hipStream_t st, const uint8_t* aos, size_t n_blocks, uint8_t* qs, uint8_t* sc, uint8_t* dm);
+int launch_repack_q3k(hipStream_t st, const uint8_t* aos, size_t n_blocks, uint8_t* qs, uint8_t* hm, uint8_t* sc, uint8_t* dm);
+int launch_embed(hipStream_t st, const DTensor& t, const StepParams* sp, int token_override, int b0, int b1, float* x);
+int launch_router(hipStream_t st, const float* w, const float* x, int n_routed, int dim, float* partial, int ksplit);
+int launch_gate(hipStream_t st, const float* partial, int ksplit, const float* bias, int n_routed, int n_active,
+                int norm_topk_prob, float scaling, int scoring, int topk_method, int n_group, int topk_group,
+                int* active_experts, float* active_weights, float* scores_out);
+struct AttnMhaArgs {
+  float* q;             // (H, head_dim) f32, rope applied in place by rope_kv
+  const float* kv_b;    // (H, nope + v)
+  const float* kv_a;    // (lora + rope): k_rope = kv_a + lora (un-rotated)
+  uint16_t* key_cache;  // (seq, H*head_dim) f16
+  uint16_t* value_cache;
+  float* out;           // (H, v)
+  int n_heads, head_dim, nope, rope, v_dim, lora, is_v3;
+};
+int launch_rope_kv_mha(hipStream_t st, const AttnMhaArgs& a, const StepParams* sp);
+int launch_attn_mha(hipStream_t st, const AttnMhaArgs& a, const StepParams* sp, int kv_len_override, int max_kv);
+struct AttnMlaArgs {
+  float* q_rope;         // (H, rope)
+  const float* q_c;      // (H, lora)
+  const float* kv_a;     // (lora + rope), latent part already normed
+  uint16_t* nope_cache;  // (seq, lora)
+  uint16_t* rope_cache;  // (seq, rope)
+  float* out;            // (H, lora)
+  int n_heads, head_dim, rope, lora, is_v3;
+};
+int launch_rope_kv_mla(hipStream_t st, const AttnMlaArgs& a, const StepParams* sp);
+int launch_attn_mla(hipStream_t st, const AttnMlaArgs& a, const StepParams* sp, int kv_len_override, int max_kv);
+int launch_rope_only(hipStream_t st, float* vec, int n_heads, int d, const float* cs, int is_v3);
+int launch_fill_tensor(hipStream_t st, const DTensor& t, uint64_t seed, float wscale);
+int launch_fill_f32(hipStream_t st, float* p, size_t n, uint64_t seed, float mean, float std);
+int launch_read_bw(hipStream_t st, const void* p, size_t bytes, float* sink);
+
+// ---- engine.cpp helpers shared with ops_api.cpp ----------------------------------
+struct dsk_ctx;
+int ctx_scratch(dsk_ctx* c, int slot, size_t bytes, void** out);
+hipStream_t ctx_stream(dsk_ctx* c);
+int ctx_device(dsk_ctx* c);
+bool is_kq(int q);
+size_t mat_bytes(int quant, size_t rows, size_t n);
+int alloc_tensor(int b0, int b1, DTensor& t, int quant, int e, int rows, int n, int local, int base);
+int upload_tensor(dsk_ctx* ctx, DTensor& t, const void* host_ptr);

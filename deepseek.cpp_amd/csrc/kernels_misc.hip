@@ -1,0 +1,769 @@
+// kernels_misc.hip -- everything on the decode path that is not a weight-streaming GEMV:
+// Q8_K activation quantisation, RMSNorm (+ residual / MoE combine), RoPE + KV-cache writes,
+// decode attention (MHA and latent MLA), the MoE router + top-k gate, embedding-row dequant,
+// upload-time re-layout of K-quant blocks, synthetic-weight fills and the bandwidth probe.
+#include "dsk_internal.h"
+#include <math.h>
+
+typedef unsigned int u32;
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+#define DEV __device__ __forceinline__
+
+DEV float h2f(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
+DEV unsigned short f2h(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }  // RNE like _cvtss_sh(x,0), src/codec.h:26-27
+
+DEV float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+DEV float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+  return v;
+}
+// block-wide reductions through a small LDS scratch (deterministic order); all threads get the result
+DEV float block_sum(float v, float* scratch, int tid, int nthreads) {
+  v = wave_sum(v);
+  const int nw = nthreads >> 6;
+  __syncthreads();
+  if ((tid & 63) == 0) scratch[tid >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += scratch[i];
+  return t;
+}
+DEV float block_max(float v, float* scratch, int tid, int nthreads) {
+  v = wave_max(v);
+  const int nw = nthreads >> 6;
+  __syncthreads();
+  if ((tid & 63) == 0) scratch[tid >> 6] = v;
+  __syncthreads();
+  float t = scratch[0];
+  for (int i = 1; i < nw; ++i) t = fmaxf(t, scratch[i]);
+  return t;
+}
+
+// ------------------------------------------------------------------------------------
+// Q8_K quantisation of one 256-block by one wave (lane holds elements 4*lane..4*lane+3).
+// quantize_row_q8_K_ref, src/quant.cpp:616-653: max = signed value of the FIRST element
+// with the largest |x|; iscale = -127/max (IEEE divide); q = min(127, rne(iscale*x));
+// bsums over 16; d = 1/iscale, which the reference's -ffast-math build evaluates as
+// max * (1/-127) (see oracle/dsk_oracle.c).
+// ------------------------------------------------------------------------------------
+DEV void q8k_block(const float (&v)[4], int lane, int8_t* qs_blk, float* d_out, int16_t* bsums_blk) {
+  float amax = 0.f, vmax = 0.f;
+  int imax = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float ax = fabsf(v[i]);
+    if (ax > amax) { amax = ax; vmax = v[i]; imax = lane * 4 + i; }
+  }
+  if (amax == 0.f) imax = lane * 4;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float oa = __shfl_xor(amax, off), ov = __shfl_xor(vmax, off);
+    const int oi = __shfl_xor(imax, off);
+    if (oa > amax || (oa == amax && oi < imax)) { amax = oa; vmax = ov; imax = oi; }
+  }
+  int q[4] = {0, 0, 0, 0};
+  float d = 0.f;
+  if (amax != 0.f) {
+    const float iscale = __fdiv_rn(-127.f, vmax);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = (int)rintf(__fmul_rn(iscale, v[i]));
+      q[i] = r < 127 ? r : 127;
+    }
+    d = __fmul_rn(vmax, 1.0f / -127.f);
+  }
+  const u32 packed = (u32)(q[0] & 0xff) | ((u32)(q[1] & 0xff) << 8) | ((u32)(q[2] & 0xff) << 16) | ((u32)(q[3] & 0xff) << 24);
+  reinterpret_cast<u32*>(qs_blk)[lane] = packed;
+  int s = q[0] + q[1] + q[2] + q[3];
+  s += __shfl_xor(s, 1);
+  s += __shfl_xor(s, 2);
+  if ((lane & 3) == 0) bsums_blk[lane >> 2] = (int16_t)s;
+  if (lane == 0) *d_out = d;
+}
+
+__global__ __launch_bounds__(256) void quantize_q8k_kernel(const float* __restrict__ x, int nb, int8_t* qs, float* d, int16_t* bsums) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (b >= nb) return;
+  const f32x4 t = *reinterpret_cast<const f32x4*>(x + (size_t)b * 256 + lane * 4);
+  const float v[4] = {t.x, t.y, t.z, t.w};
+  q8k_block(v, lane, qs + (size_t)b * 256, d + b, bsums + (size_t)b * 16);
+}
+
+int launch_quantize_q8k(hipStream_t st, const float* x, int n, int8_t* qs, float* d, int16_t* bsums) {
+  if (n <= 0 || n % 256) DSK_FAIL(DSK_ERR_INVALID, "q8k: n=%d must be a positive multiple of 256", n);
+  const int nb = n / 256;
+  hipLaunchKernelGGL(quantize_q8k_kernel, dim3((nb + 3) / 4), dim3(256), 0, st, x, nb, qs, d, bsums);
+  return DSK_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// norm jobs: [MoE combine ->] rmsnorm -> [f32 out] -> [Q8_K out] -> [rope on a tail vector]
+// rmsnorm: src/infer.cpp:601-611; combine: src/infer.cpp:874-877, 900-903.
+// One workgroup (1024 threads) per job.
+// ------------------------------------------------------------------------------------
+struct NormJobs2 {
+  NormJob j[2];
+};
+
+DEV void rope_pairs(float* vec, int d, const float* cs, int is_v3, int tid, int nthreads) {
+  // rope (V2: de-interleaving) src/infer.cpp:648-668; rope_v3 (in place) src/infer.cpp:670-685.
+  // cs[2*j], cs[2*j+1] = cos, sin of pos * theta^(-2j/d), computed on the host with libm.
+  float re = 0.f, im = 0.f;
+  const int p = tid;
+  if (p < d / 2) {
+    const float v0 = vec[2 * p], v1 = vec[2 * p + 1];
+    const float c = cs[2 * p], s = cs[2 * p + 1];
+    re = v0 * c - v1 * s;
+    im = v0 * s + v1 * c;
+  }
+  __syncthreads();
+  if (p < d / 2) {
+    if (is_v3) {
+      vec[2 * p] = re;
+      vec[2 * p + 1] = im;
+    } else {
+      vec[p] = re;
+      vec[p + d / 2] = im;
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void norm_jobs_kernel(NormJobs2 jobs, const StepParams* __restrict__ sp) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ float scratch[16];
+  const NormJob& J = jobs.j[blockIdx.x];
+  float* l_y = reinterpret_cast<float*>(smem);
+  const int tid = threadIdx.x, n = J.n;
+
+  float ss = 0.f;
+  for (int i = tid; i < n; i += 1024) {
+    float xv = J.x[i];
+    if (J.eout) {
+      for (int k = 0; k < J.n_routed_slots; ++k) xv = fmaf(J.eout[(size_t)k * n + i], J.eweights[k], xv);
+      if (J.add_shared) xv += J.eout[(size_t)J.n_routed_slots * n + i];
+      if (J.x_store) J.x_store[i] = xv;
+    }
+    l_y[i] = xv;
+    ss = fmaf(xv, xv, ss);
+  }
+  if (J.weight) {
+    const float total = block_sum(ss, scratch, tid, 1024);
+    const float scale = 1.0f / sqrtf(total / (float)n + J.eps);
+    for (int i = tid; i < n; i += 1024) {
+      const float y = l_y[i] * scale * J.weight[i];
+      l_y[i] = y;
+      if (J.y_f32) J.y_f32[i] = y;
+    }
+  } else if (J.y_f32) {
+    for (int i = tid; i < n; i += 1024) J.y_f32[i] = l_y[i];
+  }
+  __syncthreads();
+  if (J.q_qs) {
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int b = wave; b < (n >> 8); b += 16) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(l_y + b * 256 + lane * 4);
+      const float v[4] = {t.x, t.y, t.z, t.w};
+      q8k_block(v, lane, J.q_qs + (size_t)b * 256, J.q_d + b, J.q_bsums + (size_t)b * 16);
+    }
+  }
+  if (J.rope_vec) rope_pairs(J.rope_vec, J.rope_d, sp->rope_cs, J.rope_v3, tid, 1024);
+}
+
+int launch_norm_jobs(hipStream_t st, const NormJob* jobs, int n_jobs, const StepParams* sp) {
+  if (n_jobs < 1 || n_jobs > 2) DSK_FAIL(DSK_ERR_INVALID, "norm jobs: 1..2 jobs");
+  NormJobs2 a;
+  int nmax = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    a.j[i] = jobs[i];
+    if (jobs[i].q_qs && jobs[i].n % 256) DSK_FAIL(DSK_ERR_INVALID, "norm job: q8 output needs n %% 256 == 0 (n=%d)", jobs[i].n);
+    if (jobs[i].n > nmax) nmax = jobs[i].n;
+  }
+  if (n_jobs == 1) a.j[1] = jobs[0];
+  const size_t lds = (size_t)nmax * 4;
+  if (lds > 150 * 1024) DSK_FAIL(DSK_ERR_UNSUPPORTED, "norm job: n=%d too large", nmax);
+  if (lds > 64 * 1024) hipFuncSetAttribute((const void*)norm_jobs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(norm_jobs_kernel, dim3(n_jobs), dim3(1024), lds, st, a, sp);
+  return DSK_OK;
+}
+
+// rope only (op-level API): n_heads vectors of length d, one workgroup each
+__global__ void rope_only_kernel(float* vec, int d, const float* cs, int is_v3) {
+  rope_pairs(vec + (size_t)blockIdx.x * d, d, cs, is_v3, threadIdx.x, blockDim.x);
+}
+int launch_rope_only(hipStream_t st, float* vec, int n_heads, int d, const float* cs, int is_v3) {
+  hipLaunchKernelGGL(rope_only_kernel, dim3(n_heads), dim3(64 * ((d / 2 + 63) / 64)), 0, st, vec, d, cs, is_v3);
+  return DSK_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// upload-time re-layout of K-quant blocks into planes (see dsk_internal.h)
+// ------------------------------------------------------------------------------------
+__global__ void repack_q2k_kernel(const u32* __restrict__ aos, size_t n_blocks, uint8_t* qs, uint8_t* sc, uint8_t* dm) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t b = gid / 21;
+  const int j = (int)(gid % 21);
+  if (b >= n_blocks) return;
+  const u32 w = aos[b * 21 + j];  // 84-byte blocks: scales[16] | qs[64] | d | dmin (src/quant.h:41-52)
+  if (j < 4) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int jj = 4 * j + t;  // sub-block index 8h + 2s + lh
+      const int h = jj >> 3, s = (jj >> 1) & 3, lh = jj & 1;
+      sc[b * 16 + (2 * h + lh) * 4 + s] = (uint8_t)(w >> (8 * t));
+    }
+  } else if (j < 20) {
+    reinterpret_cast<u32*>(qs)[b * 16 + (j - 4)] = w;
+  } else {
+    reinterpret_cast<u32*>(dm)[b] = w;
+  }
+}
+int launch_repack_q2k(hipStream_t st, const uint8_t* aos, size_t n_blocks, uint8_t* qs, uint8_t* sc, uint8_t* dm) {
+  const size_t total = n_blocks * 21;
+  hipLaunchKernelGGL(repack_q2k_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                     reinterpret_cast<const u32*>(aos), n_blocks, qs, sc, dm);
+  return DSK_OK;
+}
+
+__global__ void repack_q3k_kernel(const unsigned short* __restrict__ aos, size_t n_blocks, unsigned short* qs,
+                                  unsigned short* hm, unsigned short* sc, unsigned short* dm) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t b = gid / 55;
+  const int j = (int)(gid % 55);
+  if (b >= n_blocks) return;
+  const unsigned short w = aos[b * 55 + j];  // 110-byte blocks: hmask[32] | qs[64] | scales[12] | d (src/quant.h:70-76)
+  if (j < 16) hm[b * 16 + j] = w;
+  else if (j < 48) qs[b * 32 + (j - 16)] = w;
+  else if (j < 54) sc[b * 6 + (j - 48)] = w;
+  else dm[b] = w;
+}
+int launch_repack_q3k(hipStream_t st, const uint8_t* aos, size_t n_blocks, uint8_t* qs, uint8_t* hm, uint8_t* sc, uint8_t* dm) {
+  const size_t total = n_blocks * 55;
+  hipLaunchKernelGGL(repack_q3k_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                     reinterpret_cast<const unsigned short*>(aos), n_blocks, reinterpret_cast<unsigned short*>(qs),
+                     reinterpret_cast<unsigned short*>(hm), reinterpret_cast<unsigned short*>(sc),
+                     reinterpret_cast<unsigned short*>(dm));
+  return DSK_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// embedding row: Model::_copy_embedding, src/infer.cpp:1217-1263 (one thread per element)
+// ------------------------------------------------------------------------------------
+DEV int q3k_scale_b(const uint8_t* S, int j) {  // src/quant.cpp:402-407
+  const int low4 = j < 8 ? (S[j] & 0xF) : (S[j - 8] >> 4);
+  const int hi2 = (S[8 + (j & 3)] >> (2 * (j >> 2))) & 3;
+  return (low4 | (hi2 << 4)) - 32;
+}
+
+__global__ void embed_kernel(DTensor t, const StepParams* __restrict__ sp, int token_override, int b0, int b1, float* __restrict__ x) {
+  const int token = token_override >= 0 ? token_override : sp->token;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int dim = t.n;
+  if (i >= dim) return;
+  const size_t nb = dim >> 8;
+  float y;
+  switch (t.quant) {
+    case DSK_QUANT_F32: y = reinterpret_cast<const float*>(t.qs)[(size_t)token * dim + i]; break;
+    case DSK_QUANT_F16: y = h2f(reinterpret_cast<const unsigned short*>(t.qs)[(size_t)token * dim + i]); break;
+    case DSK_QUANT_F8E5M2: {
+      const int ncols = (dim + b1 - 1) / b1;
+      const float s = t.scale[(size_t)(token / b0) * ncols + i / b1];
+      y = h2f((unsigned short)((unsigned short)t.qs[(size_t)token * dim + i] << 8)) * s;
+      break;
+    }
+    case DSK_QUANT_Q2_K: {  // dequantize_row_q2_K, src/quant.cpp:217-247
+      const size_t b = (size_t)token * nb + (i >> 8);
+      const int e = i & 255, h = e >> 7, s = (e >> 5) & 3, l = e & 31, lh = l >> 4;
+      const int q = (t.qs[b * 64 + 32 * h + l] >> (2 * s)) & 3;
+      const int scb = t.sc[b * 16 + (2 * h + lh) * 4 + s];
+      const u32 dmw = reinterpret_cast<const u32*>(t.dm)[b];
+      const float dl = h2f(dmw & 0xffff) * (scb & 0xF), ml = h2f(dmw >> 16) * (scb >> 4);
+      y = dl * q - ml;
+      break;
+    }
+    default: {  // dequantize_row_q3_K, src/quant.cpp:384-432
+      const size_t b = (size_t)token * nb + (i >> 8);
+      const int e = i & 255, h = e >> 7, s = (e >> 5) & 3, l = e & 31, lh = l >> 4;
+      const int ql = (t.qs[b * 64 + 32 * h + l] >> (2 * s)) & 3;
+      const int hb = (t.hm[b * 32 + l] >> (4 * h + s)) & 1;
+      const int sc = q3k_scale_b(t.sc + b * 12, 8 * h + 2 * s + lh);
+      const float dl = h2f(reinterpret_cast<const unsigned short*>(t.dm)[b]) * sc;
+      y = dl * (ql - (hb ? 0 : 4));
+      break;
+    }
+  }
+  x[i] = y;
+}
+int launch_embed(hipStream_t st, const DTensor& t, const StepParams* sp, int token_override, int b0, int b1, float* x) {
+  hipLaunchKernelGGL(embed_kernel, dim3((t.n + 255) / 256), dim3(256), 0, st, t, sp, token_override, b0, b1, x);
+  return DSK_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// MoE router: F32 GEMV (src/infer.cpp:847, 121-157), split over K so that E = 256 rows still
+// fill the chip; partial[c][e] are summed in c order by the gate kernel (deterministic).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void router_kernel(const float* __restrict__ w, const float* __restrict__ x, int n_routed,
+                                                     int dim, float* __restrict__ partial, int ksplit) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n_routed) return;
+  const int c = blockIdx.y;
+  const int chunk = ((dim / 4 + ksplit - 1) / ksplit + 63) / 64 * 64 * 4;  // floats per K slice, multiple of 256
+  const int k0 = c * chunk, k1 = min(dim, k0 + chunk);
+  float acc = 0.f;
+  const float* wr = w + (size_t)row * dim;
+  for (int i = k0 + lane * 4; i < k1; i += 256) {
+    const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wr + i));
+    const f32x4 b = *reinterpret_cast<const f32x4*>(x + i);
+    acc = fmaf(a.x, b.x, acc);
+    acc = fmaf(a.y, b.y, acc);
+    acc = fmaf(a.z, b.z, acc);
+    acc = fmaf(a.w, b.w, acc);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) partial[(size_t)c * n_routed + row] = acc;
+}
+int launch_router(hipStream_t st, const float* w, const float* x, int n_routed, int dim, float* partial, int ksplit) {
+  if (dim % 4) DSK_FAIL(DSK_ERR_INVALID, "router: dim %% 4 != 0");
+  hipLaunchKernelGGL(router_kernel, dim3((n_routed + 3) / 4, ksplit), dim3(256), 0, st, w, x, n_routed, dim, partial, ksplit);
+  return DSK_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// moe_gate: src/infer.cpp:493-599.  The reference's k rounds of "argmax over unmasked with
+// strict >" select experts in descending score order, lowest index first among equals; that
+// is the rank of e under the order (score desc, index asc), computed here by all E threads
+// in parallel: rank(e) = #{ j : s[j] > s[e] or (s[j] == s[e] and j < e) }.
+// Group-limited (:545-588): first keep the topk_group best of every group, then rank the
+// survivors globally.  Weights: x[e_k] / wsum * scaling with wsum accumulated in k order.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ partial, int ksplit, const float* __restrict__ bias,
+                                                   int E, int K, int norm_topk_prob, float scaling, int scoring, int topk_method,
+                                                   int n_group, int topk_group, int* __restrict__ active_experts,
+                                                   float* __restrict__ active_weights, float* __restrict__ scores_out) {
+  __shared__ float s[256];
+  __shared__ int surv[256];
+  __shared__ float scratch[4];
+  __shared__ int sel[256];
+  const int e = threadIdx.x;
+  float v = -INFINITY;
+  if (e < E) {
+    v = 0.f;
+    for (int c = 0; c < ksplit; ++c) v += partial[(size_t)c * E + e];
+  }
+  if (scoring == DSK_SCORE_SOFTMAX) {  // softmax, src/infer.cpp:472-487
+    const float mx = block_max(v, scratch, e, 256);
+    const float ex = e < E ? expf(v - mx) : 0.f;
+    const float sum = block_sum(ex, scratch, e, 256);
+    v = ex / sum;
+  } else {
+    v = 1.0f / (1.0f + expf(-v));  // sigmoid, src/infer.cpp:489-491
+  }
+  if (bias && e < E) v += bias[e];
+  if (e < E) {
+    s[e] = v;
+    if (scores_out) scores_out[e] = v;
+  }
+  surv[e] = e < E ? 1 : 0;
+  __syncthreads();
+  if (topk_method == DSK_TOPK_GROUP_LIMITED_GREEDY && e < E) {
+    const int gs = E / n_group, g0 = (e / gs) * gs;
+    int rank = 0;
+    for (int j = g0; j < g0 + gs; ++j) rank += (s[j] > v || (s[j] == v && j < e)) ? 1 : 0;
+    surv[e] = rank < topk_group ? 1 : 0;
+  }
+  __syncthreads();
+  if (e < E && surv[e]) {
+    int rank = 0;
+    for (int j = 0; j < E; ++j) rank += (surv[j] && (s[j] > v || (s[j] == v && j < e))) ? 1 : 0;
+    if (rank < K) sel[rank] = e;
+  }
+  __syncthreads();
+  if (e == 0) {
+    float wsum = 0.f;
+    for (int k = 0; k < K; ++k) wsum += s[sel[k]];
+    if (!norm_topk_prob) wsum = 1.0f;
+    for (int k = 0; k < K; ++k) {
+      active_experts[k] = sel[k];
+      active_weights[k] = s[sel[k]] / wsum * scaling;
+    }
+  }
+}
+int launch_gate(hipStream_t st, const float* partial, int ksplit, const float* bias, int n_routed, int n_active,
+                int norm_topk_prob, float scaling, int scoring, int topk_method, int n_group, int topk_group,
+                int* active_experts, float* active_weights, float* scores_out) {
+  if (n_routed > 256) DSK_FAIL(DSK_ERR_UNSUPPORTED, "moe_gate: more than 256 routed experts (src/infer.cpp:527)");
+  if (n_active > n_routed) DSK_FAIL(DSK_ERR_INVALID, "moe_gate: n_active > n_routed");
+  if (topk_method == DSK_TOPK_GROUP_LIMITED_GREEDY && (n_group <= 0 || n_routed % n_group || topk_group * n_group < n_active))
+    DSK_FAIL(DSK_ERR_INVALID, "moe_gate: bad group config (E=%d, n_group=%d, topk_group=%d, k=%d)", n_routed, n_group, topk_group, n_active);
+  hipLaunchKernelGGL(gate_kernel, dim3(1), dim3(256), 0, st, partial, ksplit, bias, n_routed, n_active, norm_topk_prob, scaling,
+                     scoring, topk_method, n_group, topk_group, active_experts, active_weights, scores_out);
+  return DSK_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// MHA path: RoPE on q, assemble k/v, f16 cache write, attention-sink rotation.
+// BlockMHA::_attention_impl, src/infer.cpp:956-1020.  One workgroup per head.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rope_kv_mha_kernel(AttnMhaArgs a, const StepParams* __restrict__ sp) {
+  const int h = blockIdx.x, tid = threadIdx.x;
+  const int hd = a.head_dim, nope = a.nope, rope = a.rope, vd = a.v_dim;
+  const int kv_pos = sp->kv_pos, kv_sink = sp->kv_sink;
+  // q rope, in place
+  rope_pairs(a.q + (size_t)h * hd + nope, rope, sp->rope_cs, a.is_v3, tid, 256);
+  // key = [k_nope | rope(k_rope)], value  -> f16 caches at kv_pos
+  uint16_t* kc = a.key_cache + ((size_t)kv_pos * a.n_heads + h) * hd;
+  uint16_t* vc = a.value_cache + ((size_t)kv_pos * a.n_heads + h) * vd;
+  const float* kvb = a.kv_b + (size_t)h * (nope + vd);
+  for (int i = tid; i < nope; i += 256) kc[i] = f2h(kvb[i]);
+  for (int i = tid; i < vd; i += 256) vc[i] = f2h(kvb[nope + i]);
+  if (tid < rope / 2) {
+    const float* kr = a.kv_a + a.lora;
+    const float v0 = kr[2 * tid], v1 = kr[2 * tid + 1];
+    const float c = sp->rope_cs[2 * tid], s = sp->rope_cs[2 * tid + 1];
+    const float re = v0 * c - v1 * s, im = v0 * s + v1 * c;
+    if (a.is_v3) {
+      kc[nope + 2 * tid] = f2h(re);
+      kc[nope + 2 * tid + 1] = f2h(im);
+    } else {
+      kc[nope + tid] = f2h(re);
+      kc[nope + tid + rope / 2] = f2h(im);
+    }
+  }
+  // sinks: rotate the rope part of cached keys 0..kv_sink-1 by one position, in f16
+  // (src/infer.cpp:1008-1020, rope f16 variants :687-724)
+  for (int r = 0; r < kv_sink; ++r) {
+    uint16_t* kh = a.key_cache + ((size_t)r * a.n_heads + h) * hd + nope;
+    float re = 0.f, im = 0.f;
+    if (tid < rope / 2) {
+      const float v0 = h2f(kh[2 * tid]), v1 = h2f(kh[2 * tid + 1]);
+      const float c = sp->rope_cs1[2 * tid], s = sp->rope_cs1[2 * tid + 1];
+      re = v0 * c - v1 * s;
+      im = v0 * s + v1 * c;
+    }
+    __syncthreads();
+    if (tid < rope / 2) {
+      if (a.is_v3) {
+        kh[2 * tid] = f2h(re);
+        kh[2 * tid + 1] = f2h(im);
+      } else {
+        kh[tid] = f2h(re);
+        kh[tid + rope / 2] = f2h(im);
+      }
+    }
+    __syncthreads();
+  }
+}
+int launch_rope_kv_mha(hipStream_t st, const AttnMhaArgs& a, const StepParams* sp) {
+  if (a.rope > 128 || (a.rope & 1)) DSK_FAIL(DSK_ERR_UNSUPPORTED, "rope dim %d (max 128, even)", a.rope);
+  hipLaunchKernelGGL(rope_kv_mha_kernel, dim3(a.n_heads), dim3(256), 0, st, a, sp);
+  return DSK_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// attn (per head), src/infer.cpp:728-762: scores = q.k / sqrt(head_dim), softmax, sum att*v.
+// One workgroup per head; scores live in LDS (kv_len floats).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_mha_kernel(AttnMhaArgs a, const StepParams* __restrict__ sp, int kv_len_override) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ float scratch[4];
+  __shared__ float part[256];
+  float* att = reinterpret_cast<float*>(smem);
+  const int h = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int hd = a.head_dim, vd = a.v_dim, H = a.n_heads;
+  const int kv_len = kv_len_override > 0 ? kv_len_override : sp->kv_len;
+  const float* q = a.q + (size_t)h * hd;
+  float qv[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool act = lane * 4 < hd;
+  if (act) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qv[i] = q[lane * 4 + i];
+  }
+  const float inv = sqrtf((float)hd);
+  for (int t = wave; t < kv_len; t += 4) {
+    float p = 0.f;
+    if (act) {
+      const f16x4 k = *reinterpret_cast<const f16x4*>(a.key_cache + ((size_t)t * H + h) * hd + lane * 4);
+      p = fmaf(qv[0], (float)k.x, p);
+      p = fmaf(qv[1], (float)k.y, p);
+      p = fmaf(qv[2], (float)k.z, p);
+      p = fmaf(qv[3], (float)k.w, p);
+    }
+    p = wave_sum(p);
+    if (lane == 0) att[t] = p / inv;
+  }
+  __syncthreads();
+  // softmax, src/infer.cpp:472-487
+  float mx = -INFINITY;
+  for (int t = tid; t < kv_len; t += 256) mx = fmaxf(mx, att[t]);
+  mx = block_max(mx, scratch, tid, 256);
+  float sum = 0.f;
+  for (int t = tid; t < kv_len; t += 256) {
+    const float e = expf(att[t] - mx);
+    att[t] = e;
+    sum += e;
+  }
+  sum = block_sum(sum, scratch, tid, 256);
+  for (int t = tid; t < kv_len; t += 256) att[t] = att[t] / sum;
+  __syncthreads();
+  // mix values: thread (g, i) sums t = g, g+G, ... for output i; groups are added in order
+  const int G = 256 / vd > 0 ? 256 / vd : 1;
+  const int g = tid / vd, i = tid % vd;
+  float acc = 0.f;
+  if (g < G) {
+    for (int t = g; t < kv_len; t += G) acc = fmaf(att[t], h2f(a.value_cache[((size_t)t * H + h) * vd + i]), acc);
+  }
+  part[tid] = acc;
+  __syncthreads();
+  if (tid < vd) {
+    float o = 0.f;
+    for (int gg = 0; gg < G; ++gg) o += part[gg * vd + tid];
+    a.out[(size_t)h * vd + tid] = o;
+  }
+}
+int launch_attn_mha(hipStream_t st, const AttnMhaArgs& a, const StepParams* sp, int kv_len_override, int max_kv) {
+  if (a.head_dim > 256 || a.head_dim % 4 || a.v_dim > 256) DSK_FAIL(DSK_ERR_UNSUPPORTED, "attn: head_dim %d / v_head_dim %d", a.head_dim, a.v_dim);
+  const size_t lds = (size_t)max_kv * 4;
+  if (lds > 150 * 1024) DSK_FAIL(DSK_ERR_UNSUPPORTED, "attn: kv_len %d does not fit LDS", max_kv);
+  if (lds > 64 * 1024) hipFuncSetAttribute((const void*)attn_mha_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(attn_mha_kernel, dim3(a.n_heads), dim3(256), lds, st, a, sp, kv_len_override);
+  return DSK_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// MLA path: BlockMLA::_attention_impl, src/infer.cpp:1072-1130.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rope_kv_mla_kernel(AttnMlaArgs a, const StepParams* __restrict__ sp) {
+  const int h = blockIdx.x, tid = threadIdx.x;
+  const int rope = a.rope, lora = a.lora;
+  rope_pairs(a.q_rope + (size_t)h * rope, rope, sp->rope_cs, a.is_v3, tid, 256);
+  if (h != 0) return;
+  const int kv_pos = sp->kv_pos, kv_sink = sp->kv_sink;
+  uint16_t* nc = a.nope_cache + (size_t)kv_pos * lora;
+  uint16_t* rc = a.rope_cache + (size_t)kv_pos * rope;
+  for (int i = tid; i < lora; i += 256) nc[i] = f2h(a.kv_a[i]);
+  if (tid < rope / 2) {
+    const float* kr = a.kv_a + lora;
+    const float v0 = kr[2 * tid], v1 = kr[2 * tid + 1];
+    const float c = sp->rope_cs[2 * tid], s = sp->rope_cs[2 * tid + 1];
+    const float re = v0 * c - v1 * s, im = v0 * s + v1 * c;
+    if (a.is_v3) {
+      rc[2 * tid] = f2h(re);
+      rc[2 * tid + 1] = f2h(im);
+    } else {
+      rc[tid] = f2h(re);
+      rc[tid + rope / 2] = f2h(im);
+    }
+  }
+  for (int r = 0; r < kv_sink; ++r) {  // src/infer.cpp:1103-1110
+    uint16_t* kh = a.rope_cache + (size_t)r * rope;
+    float re = 0.f, im = 0.f;
+    if (tid < rope / 2) {
+      const float v0 = h2f(kh[2 * tid]), v1 = h2f(kh[2 * tid + 1]);
+      const float c = sp->rope_cs1[2 * tid], s = sp->rope_cs1[2 * tid + 1];
+      re = v0 * c - v1 * s;
+      im = v0 * s + v1 * c;
+    }
+    __syncthreads();
+    if (tid < rope / 2) {
+      if (a.is_v3) {
+        kh[2 * tid] = f2h(re);
+        kh[2 * tid + 1] = f2h(im);
+      } else {
+        kh[tid] = f2h(re);
+        kh[tid + rope / 2] = f2h(im);
+      }
+    }
+    __syncthreads();
+  }
+}
+int launch_rope_kv_mla(hipStream_t st, const AttnMlaArgs& a, const StepParams* sp) {
+  if (a.rope > 128 || (a.rope & 1)) DSK_FAIL(DSK_ERR_UNSUPPORTED, "rope dim %d (max 128, even)", a.rope);
+  hipLaunchKernelGGL(rope_kv_mla_kernel, dim3(a.n_heads), dim3(256), 0, st, a, sp);
+  return DSK_OK;
+}
+
+// attn_mla (per head), src/infer.cpp:766-804.  All heads read the same latent cache (L2-resident).
+__global__ __launch_bounds__(256) void attn_mla_kernel(AttnMlaArgs a, const StepParams* __restrict__ sp, int kv_len_override) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ float scratch[4];
+  float* att = reinterpret_cast<float*>(smem);
+  const int h = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int lora = a.lora, rope = a.rope;
+  const int kv_len = kv_len_override > 0 ? kv_len_override : sp->kv_len;
+  const float* qc = a.q_c + (size_t)h * lora;
+  const float* qr = a.q_rope + (size_t)h * rope;
+  const float inv = sqrtf((float)a.head_dim);
+  for (int t = wave; t < kv_len; t += 4) {
+    float p = 0.f;
+    const uint16_t* c = a.nope_cache + (size_t)t * lora;
+    for (int i = lane * 4; i < lora; i += 256) {
+      const f16x4 k = *reinterpret_cast<const f16x4*>(c + i);
+      const f32x4 qq = *reinterpret_cast<const f32x4*>(qc + i);
+      p = fmaf(qq.x, (float)k.x, p);
+      p = fmaf(qq.y, (float)k.y, p);
+      p = fmaf(qq.z, (float)k.z, p);
+      p = fmaf(qq.w, (float)k.w, p);
+    }
+    const uint16_t* r = a.rope_cache + (size_t)t * rope;
+    for (int i = lane; i < rope; i += 64) p = fmaf(qr[i], h2f(r[i]), p);
+    p = wave_sum(p);
+    if (lane == 0) att[t] = p / inv;
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int t = tid; t < kv_len; t += 256) mx = fmaxf(mx, att[t]);
+  mx = block_max(mx, scratch, tid, 256);
+  float sum = 0.f;
+  for (int t = tid; t < kv_len; t += 256) {
+    const float e = expf(att[t] - mx);
+    att[t] = e;
+    sum += e;
+  }
+  sum = block_sum(sum, scratch, tid, 256);
+  for (int t = tid; t < kv_len; t += 256) att[t] = att[t] / sum;
+  __syncthreads();
+  for (int i = tid; i < lora; i += 256) {
+    float acc = 0.f;
+    for (int t = 0; t < kv_len; ++t) acc = fmaf(att[t], h2f(a.nope_cache[(size_t)t * lora + i]), acc);
+    a.out[(size_t)h * lora + i] = acc;
+  }
+}
+int launch_attn_mla(hipStream_t st, const AttnMlaArgs& a, const StepParams* sp, int kv_len_override, int max_kv) {
+  if (a.lora % 4) DSK_FAIL(DSK_ERR_UNSUPPORTED, "attn_mla: kv_lora_rank %d", a.lora);
+  const size_t lds = (size_t)max_kv * 4;
+  if (lds > 150 * 1024) DSK_FAIL(DSK_ERR_UNSUPPORTED, "attn_mla: kv_len %d does not fit LDS", max_kv);
+  if (lds > 64 * 1024) hipFuncSetAttribute((const void*)attn_mla_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(attn_mla_kernel, dim3(a.n_heads), dim3(256), lds, st, a, sp, kv_len_override);
+  return DSK_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// synthetic weights generated directly in HBM (220 GB does not fit host storage).
+// Counter-based hash RNG => deterministic in (seed, index), independent of launch geometry.
+// ------------------------------------------------------------------------------------
+DEV uint64_t mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+DEV float u01(uint64_t r) { return (float)((r >> 40) + 1) * (1.0f / 16777217.0f); }
+DEV float gauss(uint64_t seed, uint64_t i) {
+  const uint64_t r = mix64(seed ^ (i * 0xD1342543DE82EF95ull));
+  const float u1 = u01(r), u2 = u01(mix64(r));
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530718f * u2);
+}
+
+__global__ void fill_u32_kernel(u32* p, size_t n, uint64_t seed) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    p[i] = (u32)mix64(seed ^ (i * 0x9E3779B97F4A7C15ull));
+}
+// Q2_K d/dmin: w = d*sc*q - dmin*m with uniform nibbles has std ~13.9 d and zero mean for dmin = 1.5 d
+__global__ void fill_dm_q2k_kernel(u32* dm, size_t n_blocks, uint64_t seed, float wscale) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_blocks; i += (size_t)gridDim.x * blockDim.x) {
+    const uint64_t r = mix64(seed ^ (i * 0xA24BAED4963EE407ull));
+    const float d = (0.5f + u01(r)) * wscale / 13.9f;
+    dm[i] = (u32)f2h(d) | ((u32)f2h(1.5f * d) << 16);
+  }
+}
+// Q3_K: (sc-32)*q has std ~43 for uniform fields
+__global__ void fill_d_q3k_kernel(unsigned short* dm, size_t n_blocks, uint64_t seed, float wscale) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_blocks; i += (size_t)gridDim.x * blockDim.x) {
+    const uint64_t r = mix64(seed ^ (i * 0xA24BAED4963EE407ull));
+    dm[i] = f2h((0.5f + u01(r)) * wscale / 43.3f);
+  }
+}
+__global__ void fill_f32_kernel(float* p, size_t n, uint64_t seed, float mean, float std) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    p[i] = mean + std * gauss(seed, i);
+}
+__global__ void fill_f16_kernel(unsigned short* p, size_t n, uint64_t seed, float std) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    p[i] = f2h(std * gauss(seed, i));
+}
+__global__ void fill_f8_kernel(uint8_t* p, size_t n, uint64_t seed) {  // N(0,1) truncated to e5m2 (src/codec.h:49-57)
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    p[i] = (uint8_t)(f2h(gauss(seed, i)) >> 8);
+}
+__global__ void fill_uniform_f32_kernel(float* p, size_t n, uint64_t seed, float lo, float hi) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    p[i] = lo + (hi - lo) * u01(mix64(seed ^ (i * 0x9E3779B97F4A7C15ull)));
+}
+
+static unsigned fill_grid(size_t n) {
+  size_t g = (n + 255) / 256;
+  return (unsigned)(g > 8192 ? 8192 : (g ? g : 1));
+}
+
+int launch_fill_f32(hipStream_t st, float* p, size_t n, uint64_t seed, float mean, float std) {
+  hipLaunchKernelGGL(fill_f32_kernel, dim3(fill_grid(n)), dim3(256), 0, st, p, n, seed, mean, std);
+  return DSK_OK;
+}
+
+// Fill every plane of a (possibly expert-stacked) weight tensor.  wscale = target std of a weight.
+int launch_fill_tensor(hipStream_t st, const DTensor& t, uint64_t seed, float wscale) {
+  const size_t mats = t.n_experts > 0 ? (size_t)t.local_experts : 1;
+  const size_t numel = mats * (size_t)t.rows * t.n;
+  switch (t.quant) {
+    case DSK_QUANT_F32:
+      hipLaunchKernelGGL(fill_f32_kernel, dim3(fill_grid(numel)), dim3(256), 0, st, reinterpret_cast<float*>(t.qs), numel, seed, 0.f, wscale);
+      break;
+    case DSK_QUANT_F16:
+      hipLaunchKernelGGL(fill_f16_kernel, dim3(fill_grid(numel)), dim3(256), 0, st, reinterpret_cast<unsigned short*>(t.qs), numel, seed, wscale);
+      break;
+    case DSK_QUANT_F8E5M2: {
+      hipLaunchKernelGGL(fill_f8_kernel, dim3(fill_grid(numel)), dim3(256), 0, st, t.qs, numel, seed);
+      const size_t ns = mats * t.e_scale;
+      hipLaunchKernelGGL(fill_uniform_f32_kernel, dim3(fill_grid(ns)), dim3(256), 0, st, t.scale, ns, seed ^ 0x5ca1e, 0.5f * wscale, 1.5f * wscale);
+      break;
+    }
+    case DSK_QUANT_Q2_K: {
+      const size_t nblk = numel / 256;
+      hipLaunchKernelGGL(fill_u32_kernel, dim3(fill_grid(nblk * 16)), dim3(256), 0, st, reinterpret_cast<u32*>(t.qs), nblk * 16, seed);
+      hipLaunchKernelGGL(fill_u32_kernel, dim3(fill_grid(nblk * 4)), dim3(256), 0, st, reinterpret_cast<u32*>(t.sc), nblk * 4, seed ^ 0x51);
+      hipLaunchKernelGGL(fill_dm_q2k_kernel, dim3(fill_grid(nblk)), dim3(256), 0, st, reinterpret_cast<u32*>(t.dm), nblk, seed ^ 0xd3, wscale);
+      break;
+    }
+    case DSK_QUANT_Q3_K: {
+      const size_t nblk = numel / 256;
+      hipLaunchKernelGGL(fill_u32_kernel, dim3(fill_grid(nblk * 16)), dim3(256), 0, st, reinterpret_cast<u32*>(t.qs), nblk * 16, seed);
+      hipLaunchKernelGGL(fill_u32_kernel, dim3(fill_grid(nblk * 8)), dim3(256), 0, st, reinterpret_cast<u32*>(t.hm), nblk * 8, seed ^ 0x77);
+      hipLaunchKernelGGL(fill_u32_kernel, dim3(fill_grid(nblk * 3)), dim3(256), 0, st, reinterpret_cast<u32*>(t.sc), nblk * 3, seed ^ 0x51);
+      hipLaunchKernelGGL(fill_d_q3k_kernel, dim3(fill_grid(nblk)), dim3(256), 0, st, reinterpret_cast<unsigned short*>(t.dm), nblk, seed ^ 0xd3, wscale);
+      break;
+    }
+    default: DSK_FAIL(DSK_ERR_INVALID, "fill: bad quant");
+  }
+  return DSK_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// streaming-read probe: the "measured roofline" denominator
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void read_bw_kernel(const u32x4* __restrict__ p, size_t n16, float* sink) {
+  u32x4 acc = {0, 0, 0, 0};
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const u32x4 a = __builtin_nontemporal_load(p + i), b = __builtin_nontemporal_load(p + i + stride);
+    const u32x4 c = __builtin_nontemporal_load(p + i + 2 * stride), d = __builtin_nontemporal_load(p + i + 3 * stride);
+    acc ^= a ^ b ^ c ^ d;
+  }
+  for (; i < n16; i += stride) acc ^= __builtin_nontemporal_load(p + i);
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) *sink = 1.f;  // keep the loads alive
+}
+int launch_read_bw(hipStream_t st, const void* p, size_t bytes, float* sink) {
+  hipLaunchKernelGGL(read_bw_kernel, dim3(256 * 8), dim3(256), 0, st, reinterpret_cast<const u32x4*>(p), bytes / 16, sink);
+  return DSK_OK;
+}

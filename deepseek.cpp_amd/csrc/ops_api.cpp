@@ -1,0 +1,292 @@
+// ops_api.cpp -- op-level C-ABI entry points on host buffers (copy in, run the SAME kernels the
+// token step uses, copy out).  They mirror the reference's "exposed for tests" functions
+// (src/model.h:503-535) plus its file-static helpers, so that the parity tests can pin every
+// stage of the hot path separately.
+#include "dsk_internal.h"
+
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+
+namespace {
+struct DevBuf {  // small RAII device allocation for one call
+  void* p = nullptr;
+  ~DevBuf() {
+    if (p) hipFree(p);
+  }
+  int alloc(size_t bytes) {
+    HIP_TRY(hipMalloc(&p, std::max<size_t>(bytes, 16)));
+    return DSK_OK;
+  }
+  template <typename T>
+  T* as() { return reinterpret_cast<T*>(p); }
+};
+int cdiv(int a, int b) { return (a + b - 1) / b; }
+int begin(dsk_ctx* ctx) {
+  if (!ctx) DSK_FAIL(DSK_ERR_INVALID, "null context");
+  HIP_TRY(hipSetDevice(ctx_device(ctx)));
+  return DSK_OK;
+}
+int finish(dsk_ctx* ctx) {
+  HIP_TRY(hipStreamSynchronize(ctx_stream(ctx)));
+  HIP_TRY(hipGetLastError());
+  return DSK_OK;
+}
+struct TensorGuard {
+  DTensor t;
+  ~TensorGuard() {
+    if (t.base) hipFree(t.base);
+  }
+};
+void fill_rope_cs(float* cs, int d, int pos, float theta) {  // src/infer.cpp:655-658
+  for (int j = 0; j < d / 2; ++j) {
+    const float freq = powf(theta, -((float)(2 * j) * (1.0f / (float)d)));  // see oracle/dsk_oracle.c ref_rope_freq
+    const float v = pos * freq;
+    cs[2 * j] = cosf(v);
+    cs[2 * j + 1] = sinf(v);
+  }
+}
+}  // namespace
+
+extern "C" int dsk_q8k_quantize(dsk_ctx* ctx, const float* x, int n, int8_t* qs, float* d, int16_t* bsums) {
+  DSK_TRY(begin(ctx));
+  if (!x || !qs || !d || !bsums) DSK_FAIL(DSK_ERR_INVALID, "q8k_quantize: null buffer");
+  if (n <= 0 || n % 256) DSK_FAIL(DSK_ERR_INVALID, "q8k_quantize: n=%d must be a positive multiple of 256", n);
+  DevBuf dx, dq, dd, db;
+  DSK_TRY(dx.alloc((size_t)n * 4));
+  DSK_TRY(dq.alloc(n));
+  DSK_TRY(dd.alloc((size_t)n / 256 * 4));
+  DSK_TRY(db.alloc((size_t)n / 16 * 2));
+  hipStream_t st = ctx_stream(ctx);
+  HIP_TRY(hipMemcpyAsync(dx.p, x, (size_t)n * 4, hipMemcpyHostToDevice, st));
+  DSK_TRY(launch_quantize_q8k(st, dx.as<float>(), n, dq.as<int8_t>(), dd.as<float>(), db.as<int16_t>()));
+  HIP_TRY(hipMemcpyAsync(qs, dq.p, n, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(d, dd.p, (size_t)n / 256 * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(bsums, db.p, (size_t)n / 16 * 2, hipMemcpyDeviceToHost, st));
+  return finish(ctx);
+}
+
+static int gemv_common(dsk_ctx* ctx, int quant, const void* w, size_t w_bytes, const float* scale, const int32_t* block_size,
+                       int n_experts, int expert, int d, int n, const float* x, float* out) {
+  DSK_TRY(begin(ctx));
+  if (!w || !x || !out) DSK_FAIL(DSK_ERR_INVALID, "gemv: null buffer");
+  if (quant < DSK_QUANT_F32 || quant > DSK_QUANT_Q3_K) DSK_FAIL(DSK_ERR_INVALID, "gemv: bad quant %d", quant);
+  if (d <= 0 || n <= 0) DSK_FAIL(DSK_ERR_INVALID, "gemv: empty shape");
+  if (is_kq(quant) && n % 256) DSK_FAIL(DSK_ERR_INVALID, "gemv: k-quant n=%d not a multiple of 256", n);
+  const size_t mats = n_experts > 0 ? n_experts : 1;
+  if (w_bytes != mat_bytes(quant, d, n) * mats) DSK_FAIL(DSK_ERR_INVALID, "gemv: %zu weight bytes, expected %zu", w_bytes, mat_bytes(quant, d, n) * mats);
+  if (n_experts > 0 && (expert < 0 || expert >= n_experts)) DSK_FAIL(DSK_ERR_INVALID, "gemv: expert %d of %d", expert, n_experts);
+  int b0 = 1, b1 = 1;
+  if (scale) {
+    if (!block_size || block_size[0] <= 0 || block_size[1] <= 0) DSK_FAIL(DSK_ERR_INVALID, "gemv: scale without block_size");
+    b0 = block_size[0];
+    b1 = block_size[1];
+  }
+  hipStream_t st = ctx_stream(ctx);
+  TensorGuard tg;
+  // upload only the selected expert's slice (the engine proper keeps whole stacks resident)
+  DTensor& t = tg.t;
+  DSK_TRY(alloc_tensor(b0, b1, t, quant, 0, d, n, 1, 0));
+  const char* src = (const char*)w + (size_t)(n_experts > 0 ? expert : 0) * mat_bytes(quant, d, n);
+  DSK_TRY(upload_tensor(ctx, t, src));
+  if (scale && quant != DSK_QUANT_F8E5M2 && quant != DSK_QUANT_F16 && quant != DSK_QUANT_F32)
+    DSK_FAIL(DSK_ERR_INVALID, "gemv: block scales with a k-quant");
+  DevBuf dscale;
+  const float* dsc = nullptr;
+  const size_t nsc = (size_t)cdiv(d, b0) * cdiv(n, b1);
+  if (scale) {
+    DSK_TRY(dscale.alloc(nsc * 4));
+    HIP_TRY(hipMemcpyAsync(dscale.p, scale + (size_t)(n_experts > 0 ? expert : 0) * nsc, nsc * 4, hipMemcpyHostToDevice, st));
+    dsc = dscale.as<float>();
+  }
+  DevBuf dx, dout, dq, dd, db;
+  DSK_TRY(dx.alloc((size_t)n * 4));
+  DSK_TRY(dout.alloc((size_t)d * 4));
+  HIP_TRY(hipMemcpyAsync(dx.p, x, (size_t)n * 4, hipMemcpyHostToDevice, st));
+  GemvSeg s;
+  memset(&s, 0, sizeof s);
+  s.qs = t.qs; s.sc = t.sc; s.hm = t.hm; s.dm = t.dm; s.scale = dsc;
+  s.rows = d; s.n = n; s.n_slots = 1; s.local_experts = 1;
+  s.b0 = b0; s.b1 = b1; s.sc_cols = cdiv(n, b1);
+  s.out = dout.as<float>();
+  s.epilogue = EPI_STORE;
+  if (is_kq(quant)) {  // quantize_acts then matmul_w2a8 / w3a8 (src/infer.cpp:327-345)
+    DSK_TRY(dq.alloc(n));
+    DSK_TRY(dd.alloc((size_t)n / 256 * 4));
+    DSK_TRY(db.alloc((size_t)n / 16 * 2));
+    DSK_TRY(launch_quantize_q8k(st, dx.as<float>(), n, dq.as<int8_t>(), dd.as<float>(), db.as<int16_t>()));
+    s.a_qs = dq.as<int8_t>(); s.a_d = dd.as<float>(); s.a_bsums = db.as<int16_t>();
+  } else {
+    s.a_f32 = dx.as<float>();
+  }
+  DSK_TRY(launch_gemv(st, quant, s));
+  HIP_TRY(hipMemcpyAsync(out, dout.p, (size_t)d * 4, hipMemcpyDeviceToHost, st));
+  return finish(ctx);
+}
+
+extern "C" int dsk_gemv(dsk_ctx* ctx, int quant, const void* w, size_t w_bytes, const float* scale, const int32_t block_size[2], int d,
+                        int n, const float* x, float* out) {
+  return gemv_common(ctx, quant, w, w_bytes, scale, block_size, 0, 0, d, n, x, out);
+}
+extern "C" int dsk_gemv_expert(dsk_ctx* ctx, int quant, const void* w, size_t w_bytes, const float* scale, const int32_t block_size[2],
+                               int n_experts, int expert, int d, int n, const float* x, float* out) {
+  if (n_experts <= 0) DSK_FAIL(DSK_ERR_INVALID, "gemv_expert: n_experts must be positive");
+  return gemv_common(ctx, quant, w, w_bytes, scale, block_size, n_experts, expert, d, n, x, out);
+}
+
+extern "C" int dsk_embed_row(dsk_ctx* ctx, int quant, const void* w, size_t w_bytes, const float* scale, const int32_t block_size[2],
+                             int vocab, int dim, int token, float* out) {
+  DSK_TRY(begin(ctx));
+  if (!w || !out) DSK_FAIL(DSK_ERR_INVALID, "embed_row: null buffer");
+  if (token < 0 || token >= vocab) DSK_FAIL(DSK_ERR_INVALID, "embed_row: token %d of %d", token, vocab);
+  if (is_kq(quant) && dim % 256) DSK_FAIL(DSK_ERR_INVALID, "embed_row: k-quant dim %d", dim);
+  if (w_bytes != mat_bytes(quant, vocab, dim)) DSK_FAIL(DSK_ERR_INVALID, "embed_row: %zu bytes, expected %zu", w_bytes, mat_bytes(quant, vocab, dim));
+  int b0 = 1, b1 = 1;
+  if (quant == DSK_QUANT_F8E5M2) {
+    if (!scale || !block_size || block_size[0] <= 0 || block_size[1] <= 0) DSK_FAIL(DSK_ERR_INVALID, "embed_row: f8e5m2 needs scales");
+    b0 = block_size[0];
+    b1 = block_size[1];
+  }
+  hipStream_t st = ctx_stream(ctx);
+  TensorGuard tg;
+  DSK_TRY(alloc_tensor(b0, b1, tg.t, quant, 0, vocab, dim, 1, 0));
+  DSK_TRY(upload_tensor(ctx, tg.t, w));
+  if (quant == DSK_QUANT_F8E5M2)
+    HIP_TRY(hipMemcpyAsync(tg.t.scale, scale, (size_t)cdiv(vocab, b0) * cdiv(dim, b1) * 4, hipMemcpyHostToDevice, st));
+  DevBuf dout;
+  DSK_TRY(dout.alloc((size_t)dim * 4));
+  DSK_TRY(launch_embed(st, tg.t, nullptr, token, b0, b1, dout.as<float>()));
+  HIP_TRY(hipMemcpyAsync(out, dout.p, (size_t)dim * 4, hipMemcpyDeviceToHost, st));
+  return finish(ctx);
+}
+
+extern "C" int dsk_rmsnorm(dsk_ctx* ctx, const float* x, const float* weight, int size, float eps, float* out) {
+  DSK_TRY(begin(ctx));
+  if (!x || !weight || !out || size <= 0) DSK_FAIL(DSK_ERR_INVALID, "rmsnorm: bad argument");
+  hipStream_t st = ctx_stream(ctx);
+  DevBuf dx, dw, dy;
+  DSK_TRY(dx.alloc((size_t)size * 4));
+  DSK_TRY(dw.alloc((size_t)size * 4));
+  DSK_TRY(dy.alloc((size_t)size * 4));
+  HIP_TRY(hipMemcpyAsync(dx.p, x, (size_t)size * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(dw.p, weight, (size_t)size * 4, hipMemcpyHostToDevice, st));
+  NormJob j;
+  memset(&j, 0, sizeof j);
+  j.x = dx.as<float>(); j.weight = dw.as<float>(); j.n = size; j.eps = eps; j.y_f32 = dy.as<float>();
+  DSK_TRY(launch_norm_jobs(st, &j, 1, nullptr));
+  HIP_TRY(hipMemcpyAsync(out, dy.p, (size_t)size * 4, hipMemcpyDeviceToHost, st));
+  return finish(ctx);
+}
+
+extern "C" int dsk_moe_gate(dsk_ctx* ctx, const float* scores, const float* bias, int n_routed, int n_active, int norm_topk_prob,
+                            float routed_scaling_factor, int scoring_func, int topk_method, int n_group, int topk_group,
+                            int32_t* active_experts, float* active_weights) {
+  DSK_TRY(begin(ctx));
+  if (!scores || !active_experts || !active_weights || n_routed <= 0 || n_active <= 0) DSK_FAIL(DSK_ERR_INVALID, "moe_gate: bad argument");
+  hipStream_t st = ctx_stream(ctx);
+  DevBuf ds, dbias, de, dw;
+  DSK_TRY(ds.alloc((size_t)n_routed * 4));
+  DSK_TRY(de.alloc((size_t)n_active * 4));
+  DSK_TRY(dw.alloc((size_t)n_active * 4));
+  HIP_TRY(hipMemcpyAsync(ds.p, scores, (size_t)n_routed * 4, hipMemcpyHostToDevice, st));
+  if (bias) {
+    DSK_TRY(dbias.alloc((size_t)n_routed * 4));
+    HIP_TRY(hipMemcpyAsync(dbias.p, bias, (size_t)n_routed * 4, hipMemcpyHostToDevice, st));
+  }
+  DSK_TRY(launch_gate(st, ds.as<float>(), 1, bias ? dbias.as<float>() : nullptr, n_routed, n_active, norm_topk_prob, routed_scaling_factor,
+                      scoring_func, topk_method, n_group, topk_group, de.as<int>(), dw.as<float>(), nullptr));
+  HIP_TRY(hipMemcpyAsync(active_experts, de.p, (size_t)n_active * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(active_weights, dw.p, (size_t)n_active * 4, hipMemcpyDeviceToHost, st));
+  return finish(ctx);
+}
+
+extern "C" int dsk_rope(dsk_ctx* ctx, float* vec, int n_heads, int d, int pos, float theta, int is_v3) {
+  DSK_TRY(begin(ctx));
+  if (!vec || n_heads <= 0 || d <= 0 || (d & 1) || d > 128) DSK_FAIL(DSK_ERR_INVALID, "rope: bad argument (d even, <= 128)");
+  hipStream_t st = ctx_stream(ctx);
+  float cs[128];
+  fill_rope_cs(cs, d, pos, theta);
+  DevBuf dv, dcs;
+  DSK_TRY(dv.alloc((size_t)n_heads * d * 4));
+  DSK_TRY(dcs.alloc(sizeof cs));
+  HIP_TRY(hipMemcpyAsync(dv.p, vec, (size_t)n_heads * d * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(dcs.p, cs, sizeof cs, hipMemcpyHostToDevice, st));
+  DSK_TRY(launch_rope_only(st, dv.as<float>(), n_heads, d, dcs.as<float>(), is_v3));
+  HIP_TRY(hipMemcpyAsync(vec, dv.p, (size_t)n_heads * d * 4, hipMemcpyDeviceToHost, st));
+  return finish(ctx);
+}
+
+extern "C" int dsk_attn_mha(dsk_ctx* ctx, const float* q, const uint16_t* kb, const uint16_t* vb, int n_heads, int head_dim, int v_head_dim,
+                            int kv_len, float* out) {
+  DSK_TRY(begin(ctx));
+  if (!q || !kb || !vb || !out || n_heads <= 0 || kv_len <= 0) DSK_FAIL(DSK_ERR_INVALID, "attn_mha: bad argument");
+  hipStream_t st = ctx_stream(ctx);
+  DevBuf dq, dk, dv, dout;
+  const size_t kb_n = (size_t)kv_len * n_heads * head_dim, vb_n = (size_t)kv_len * n_heads * v_head_dim;
+  DSK_TRY(dq.alloc((size_t)n_heads * head_dim * 4));
+  DSK_TRY(dk.alloc(kb_n * 2));
+  DSK_TRY(dv.alloc(vb_n * 2));
+  DSK_TRY(dout.alloc((size_t)n_heads * v_head_dim * 4));
+  HIP_TRY(hipMemcpyAsync(dq.p, q, (size_t)n_heads * head_dim * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(dk.p, kb, kb_n * 2, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(dv.p, vb, vb_n * 2, hipMemcpyHostToDevice, st));
+  AttnMhaArgs a;
+  memset(&a, 0, sizeof a);
+  a.q = dq.as<float>(); a.key_cache = dk.as<uint16_t>(); a.value_cache = dv.as<uint16_t>(); a.out = dout.as<float>();
+  a.n_heads = n_heads; a.head_dim = head_dim; a.v_dim = v_head_dim;
+  DSK_TRY(launch_attn_mha(st, a, nullptr, kv_len, kv_len));
+  HIP_TRY(hipMemcpyAsync(out, dout.p, (size_t)n_heads * v_head_dim * 4, hipMemcpyDeviceToHost, st));
+  return finish(ctx);
+}
+
+extern "C" int dsk_attn_mla(dsk_ctx* ctx, const float* q_c, const float* q_rope, const uint16_t* ckv, const uint16_t* krope, int n_heads,
+                            int head_dim, int kv_lora_rank, int rope_dim, int kv_len, float* out) {
+  DSK_TRY(begin(ctx));
+  if (!q_c || !q_rope || !ckv || !krope || !out || n_heads <= 0 || kv_len <= 0) DSK_FAIL(DSK_ERR_INVALID, "attn_mla: bad argument");
+  hipStream_t st = ctx_stream(ctx);
+  DevBuf dqc, dqr, dc, dr, dout;
+  DSK_TRY(dqc.alloc((size_t)n_heads * kv_lora_rank * 4));
+  DSK_TRY(dqr.alloc((size_t)n_heads * rope_dim * 4));
+  DSK_TRY(dc.alloc((size_t)kv_len * kv_lora_rank * 2));
+  DSK_TRY(dr.alloc((size_t)kv_len * rope_dim * 2));
+  DSK_TRY(dout.alloc((size_t)n_heads * kv_lora_rank * 4));
+  HIP_TRY(hipMemcpyAsync(dqc.p, q_c, (size_t)n_heads * kv_lora_rank * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(dqr.p, q_rope, (size_t)n_heads * rope_dim * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(dc.p, ckv, (size_t)kv_len * kv_lora_rank * 2, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(dr.p, krope, (size_t)kv_len * rope_dim * 2, hipMemcpyHostToDevice, st));
+  AttnMlaArgs a;
+  memset(&a, 0, sizeof a);
+  a.q_c = dqc.as<float>(); a.q_rope = dqr.as<float>(); a.nope_cache = dc.as<uint16_t>(); a.rope_cache = dr.as<uint16_t>();
+  a.out = dout.as<float>(); a.n_heads = n_heads; a.head_dim = head_dim; a.rope = rope_dim; a.lora = kv_lora_rank;
+  DSK_TRY(launch_attn_mla(st, a, nullptr, kv_len, kv_len));
+  HIP_TRY(hipMemcpyAsync(out, dout.p, (size_t)n_heads * kv_lora_rank * 4, hipMemcpyDeviceToHost, st));
+  return finish(ctx);
+}
+
+extern "C" int dsk_measure_read_bw(dsk_ctx* ctx, size_t bytes, int iters, double* gbps_out) {
+  DSK_TRY(begin(ctx));
+  if (!gbps_out || bytes < (1u << 20) || iters <= 0) DSK_FAIL(DSK_ERR_INVALID, "measure_read_bw: bad argument");
+  bytes = bytes / 4096 * 4096;
+  hipStream_t st = ctx_stream(ctx);
+  DevBuf buf, sink;
+  DSK_TRY(buf.alloc(bytes));
+  DSK_TRY(sink.alloc(16));
+  HIP_TRY(hipMemsetAsync(buf.p, 0x5a, bytes, st));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  double best = 0;
+  for (int i = 0; i < iters + 1; ++i) {
+    HIP_TRY(hipEventRecord(e0, st));
+    DSK_TRY(launch_read_bw(st, buf.p, bytes, sink.as<float>()));
+    HIP_TRY(hipEventRecord(e1, st));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (i > 0 && ms > 0) best = std::max(best, (double)bytes / (ms * 1e-3) / 1e9);
+  }
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  *gbps_out = best;
+  return finish(ctx);
+}

@@ -1,0 +1,301 @@
+"""ctypes binding of the gfx950 decode engine's C ABI (include/dsk.h).
+
+This is plumbing only: every call goes straight into deepseek.cpp_amd/libdsk_hip.so (hand-written
+HIP kernels).  There is NO CPU or PyTorch fallback: if the shared library is missing or no GPU is
+visible the import / context creation raises.
+
+Object model mirrors the reference (src/model.h): `Model.forward(token, pos, mode)` is
+`Model::forward(InferenceState&, token, pos, mode)` and returns what `InferenceState::logits()`
+would hold.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdsk_hip.so")
+
+MODE_HYDRATE_KV_CACHE, MODE_OUTPUT_LOGITS = 0, 1
+QUANT_IDS = {"fp32": 0, "fp16": 1, "f8e5m2": 2, "q2_k": 3, "q3_k": 4}
+
+c_f = C.POINTER(C.c_float)
+c_i32 = C.POINTER(C.c_int32)
+
+
+class DskConfig(C.Structure):
+    """dsk_config (include/dsk.h), POD mirror of reference Config (src/model.h:47-96)."""
+    _fields_ = [
+        ("dim", C.c_int32), ("hidden_dim", C.c_int32), ("n_layers", C.c_int32), ("n_heads", C.c_int32),
+        ("vocab_size", C.c_int32), ("max_seq_len", C.c_int32), ("rope_theta", C.c_float),
+        ("norm_eps", C.c_float), ("act", C.c_int32), ("first_k_dense_replace", C.c_int32),
+        ("n_shared_experts", C.c_int32), ("n_routed_experts", C.c_int32), ("n_active_routed", C.c_int32),
+        ("moe_intermediate_size", C.c_int32), ("routed_scaling_factor", C.c_float), ("n_group", C.c_int32),
+        ("norm_topk_prob", C.c_int32), ("scoring_func", C.c_int32), ("topk_group", C.c_int32),
+        ("topk_method", C.c_int32), ("has_moegate_bias", C.c_int32), ("use_mla", C.c_int32),
+        ("kv_lora_rank", C.c_int32), ("q_lora_rank", C.c_int32), ("qk_nope_head_dim", C.c_int32),
+        ("qk_rope_head_dim", C.c_int32), ("v_head_dim", C.c_int32), ("weight_quant", C.c_int32),
+        ("block_size", C.c_int32 * 2), ("rs_original_max_position_embeddings", C.c_int32),
+    ]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("launches", C.c_int32), ("total_ms", C.c_float), ("algo_bytes", C.c_double)]
+
+
+def make_config(c) -> DskConfig:
+    """Any object with the reference Config's field names (e.g. tools.synth.Cfg) -> dsk_config."""
+    d = DskConfig()
+    d.dim, d.hidden_dim, d.n_layers, d.n_heads = c.dim, c.hidden_dim, c.n_layers, c.n_heads
+    d.vocab_size, d.max_seq_len = c.vocab_size, c.max_seq_len
+    d.rope_theta, d.norm_eps = c.rope_theta, c.norm_eps
+    d.act = 1 if c.act == "silu" else 0
+    d.first_k_dense_replace = c.first_k_dense_replace
+    d.n_shared_experts, d.n_routed_experts = c.n_shared_experts, c.n_routed_experts
+    d.n_active_routed, d.moe_intermediate_size = c.n_active_routed, c.moe_intermediate_size
+    d.routed_scaling_factor, d.n_group = c.routed_scaling_factor, c.n_group
+    d.norm_topk_prob = int(c.norm_topk_prob)
+    d.scoring_func = 1 if c.scoring_func == "sigmoid" else 0
+    d.topk_group = c.topk_group
+    d.topk_method = 1 if c.topk_method == "group_limited_greedy" else 0
+    d.has_moegate_bias = int(c.has_moegate_bias)
+    d.use_mla = int(c.use_mla)
+    d.kv_lora_rank, d.q_lora_rank = c.kv_lora_rank, c.q_lora_rank
+    d.qk_nope_head_dim, d.qk_rope_head_dim, d.v_head_dim = c.qk_nope_head_dim, c.qk_rope_head_dim, c.v_head_dim
+    d.weight_quant = QUANT_IDS[c.quant]
+    d.block_size[0], d.block_size[1] = c.block_size
+    d.rs_original_max_position_embeddings = c.rs_original_max_position_embeddings
+    return d
+
+
+class DskError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libdsk_hip.so; fail loudly (the product path has no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DskError(f"{LIB_PATH} is missing: build it with `make -C deepseek.cpp_amd/csrc` "
+                           f"(or __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.dsk_last_error.restype = C.c_char_p
+        L.dsk_model_active_bytes.restype = C.c_double
+        L.dsk_model_active_bytes.argtypes = [C.c_void_p, C.c_int]
+        L.dsk_model_device_bytes.restype = C.c_double
+        L.dsk_model_device_bytes.argtypes = [C.c_void_p]
+        L.dsk_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.dsk_ctx_destroy.argtypes = [C.c_void_p]
+        L.dsk_comm_unique_id.argtypes = [C.c_void_p]
+        L.dsk_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.dsk_model_create.argtypes = [C.c_void_p, C.POINTER(DskConfig), C.POINTER(C.c_void_p)]
+        L.dsk_model_bind.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, c_i32, C.c_void_p, C.c_size_t]
+        L.dsk_model_synthesize.argtypes = [C.c_void_p, C.c_uint64]
+        L.dsk_model_finalize.argtypes = [C.c_void_p]
+        L.dsk_model_destroy.argtypes = [C.c_void_p]
+        L.dsk_forward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, c_f]
+        L.dsk_model_set_graph.argtypes = [C.c_void_p, C.c_int]
+        L.dsk_model_set_trace.argtypes = [C.c_void_p, C.c_int]
+        L.dsk_model_get_trace_x.argtypes = [C.c_void_p, C.c_int, c_f]
+        L.dsk_model_get_routing.argtypes = [C.c_void_p, c_i32, c_f]
+        L.dsk_profile_forward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(KernelTime), C.c_int, c_i32]
+        L.dsk_q8k_quantize.argtypes = [C.c_void_p, c_f, C.c_int, C.c_void_p, c_f, C.c_void_p]
+        L.dsk_gemv.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, c_f, c_i32, C.c_int, C.c_int, c_f, c_f]
+        L.dsk_gemv_expert.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, c_f, c_i32, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, c_f, c_f]
+        L.dsk_embed_row.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, c_f, c_i32, C.c_int, C.c_int,
+                                    C.c_int, c_f]
+        L.dsk_rmsnorm.argtypes = [C.c_void_p, c_f, c_f, C.c_int, C.c_float, c_f]
+        L.dsk_moe_gate.argtypes = [C.c_void_p, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, c_i32, c_f]
+        L.dsk_rope.argtypes = [C.c_void_p, c_f, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
+        L.dsk_attn_mha.argtypes = [C.c_void_p, c_f, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_f]
+        L.dsk_attn_mla.argtypes = [C.c_void_p, c_f, c_f, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, c_f]
+        L.dsk_measure_read_bw.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
+        _lib = L
+    return _lib
+
+
+def check(r):
+    if r != 0:
+        raise DskError(lib().dsk_last_error().decode())
+
+
+def _f(a):
+    return a.ctypes.data_as(c_f)
+
+
+def _fa(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+class Ctx:
+    def __init__(self, device: int = 0):
+        self.h = C.c_void_p()
+        check(lib().dsk_ctx_create(device, C.byref(self.h)))
+        self.rank, self.world = 0, 1
+
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        check(lib().dsk_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, uid: bytes, rank: int, world: int):
+        check(lib().dsk_comm_init(self.h, C.c_char_p(uid), rank, world))
+        self.rank, self.world = rank, world
+
+    def close(self):
+        if self.h:
+            lib().dsk_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    # ---- op-level entry points (host buffers) ----
+    def q8k_quantize(self, x):
+        x = _fa(x)
+        n = x.size
+        qs, d, bs = np.zeros(n, np.int8), np.zeros(n // 256, np.float32), np.zeros(n // 16, np.int16)
+        check(lib().dsk_q8k_quantize(self.h, _f(x), n, qs.ctypes.data, _f(d), bs.ctypes.data))
+        return qs, d, bs
+
+    def gemv(self, quant, w, d, n, x, scale=None, block_size=(0, 0)):
+        x, out = _fa(x), np.zeros(d, np.float32)
+        w = np.ascontiguousarray(w)
+        bsz = (C.c_int32 * 2)(*block_size)
+        sc = None if scale is None else _f(_fa(scale))
+        check(lib().dsk_gemv(self.h, quant, w.ctypes.data, w.nbytes, sc, bsz, d, n, _f(x), _f(out)))
+        return out
+
+    def gemv_expert(self, quant, w, n_experts, expert, d, n, x, scale=None, block_size=(0, 0)):
+        x, out = _fa(x), np.zeros(d, np.float32)
+        w = np.ascontiguousarray(w)
+        bsz = (C.c_int32 * 2)(*block_size)
+        sc = None if scale is None else _f(_fa(scale))
+        check(lib().dsk_gemv_expert(self.h, quant, w.ctypes.data, w.nbytes, sc, bsz, n_experts, expert, d, n, _f(x), _f(out)))
+        return out
+
+    def embed_row(self, quant, w, vocab, dim, token, scale=None, block_size=(0, 0)):
+        out = np.zeros(dim, np.float32)
+        w = np.ascontiguousarray(w)
+        bsz = (C.c_int32 * 2)(*block_size)
+        sc = None if scale is None else _f(_fa(scale))
+        check(lib().dsk_embed_row(self.h, quant, w.ctypes.data, w.nbytes, sc, bsz, vocab, dim, token, _f(out)))
+        return out
+
+    def rmsnorm(self, x, w, eps):
+        x, w = _fa(x), _fa(w)
+        out = np.zeros_like(x)
+        check(lib().dsk_rmsnorm(self.h, _f(x), _f(w), x.size, eps, _f(out)))
+        return out
+
+    def moe_gate(self, scores, bias, n_active, norm_topk_prob, scaling, scoring_func, topk_method, n_group, topk_group):
+        s = _fa(scores)
+        b = None if bias is None else _f(_fa(bias))
+        ae, aw = np.zeros(n_active, np.int32), np.zeros(n_active, np.float32)
+        check(lib().dsk_moe_gate(self.h, _f(s), b, s.size, n_active, int(norm_topk_prob), scaling, scoring_func,
+                                 topk_method, n_group, topk_group, ae.ctypes.data_as(c_i32), _f(aw)))
+        return ae, aw
+
+    def rope(self, vec, n_heads, d, pos, theta, is_v3):
+        v = np.array(vec, np.float32).copy()
+        check(lib().dsk_rope(self.h, _f(v), n_heads, d, pos, theta, int(is_v3)))
+        return v
+
+    def attn_mha(self, q, kb, vb, n_heads, head_dim, v_head_dim, kv_len):
+        q = _fa(q)
+        out = np.zeros(n_heads * v_head_dim, np.float32)
+        kb, vb = np.ascontiguousarray(kb), np.ascontiguousarray(vb)
+        check(lib().dsk_attn_mha(self.h, _f(q), kb.ctypes.data, vb.ctypes.data, n_heads, head_dim, v_head_dim, kv_len, _f(out)))
+        return out
+
+    def attn_mla(self, q_c, q_rope, ckv, krope, n_heads, head_dim, lora, rope, kv_len):
+        q_c, q_rope = _fa(q_c), _fa(q_rope)
+        out = np.zeros(n_heads * lora, np.float32)
+        ckv, krope = np.ascontiguousarray(ckv), np.ascontiguousarray(krope)
+        check(lib().dsk_attn_mla(self.h, _f(q_c), _f(q_rope), ckv.ctypes.data, krope.ctypes.data, n_heads, head_dim,
+                                 lora, rope, kv_len, _f(out)))
+        return out
+
+    def measure_read_bw(self, nbytes=8 << 30, iters=5) -> float:
+        out = C.c_double()
+        check(lib().dsk_measure_read_bw(self.h, nbytes, iters, C.byref(out)))
+        return out.value
+
+
+class Model:
+    """dsk_model_* life-cycle.  `tensors`: name -> object with .data/.shape/.quant/.scale (tools.synth.Tens),
+    named like the reference's .dseek tensors; or None + synth_seed to generate weights in HBM."""
+
+    def __init__(self, ctx: Ctx, cfg, tensors=None, synth_seed=None):
+        self.ctx, self.cfg = ctx, cfg
+        self.dcfg = make_config(cfg)
+        self.h = C.c_void_p()
+        check(lib().dsk_model_create(ctx.h, C.byref(self.dcfg), C.byref(self.h)))
+        if tensors is not None:
+            from tools import synth  # name -> role mapping shared with the test generators
+
+            def bind(role, layer, quant, shape, arr):
+                arr = np.ascontiguousarray(arr)
+                check(lib().dsk_model_bind(self.h, role, layer, quant, shape.ctypes.data_as(c_i32), arr.ctypes.data, arr.nbytes))
+
+            synth.bind_all(tensors, bind)
+        if synth_seed is not None:
+            check(lib().dsk_model_synthesize(self.h, synth_seed))
+        check(lib().dsk_model_finalize(self.h))
+        self._logits = np.zeros(cfg.vocab_size, np.float32)
+
+    def forward(self, token: int, pos: int, mode: int = MODE_OUTPUT_LOGITS):
+        check(lib().dsk_forward(self.h, token, pos, mode, _f(self._logits)))
+        return self._logits.copy() if mode == MODE_OUTPUT_LOGITS else None
+
+    def forward_nocopy(self, token: int, pos: int, mode: int = MODE_OUTPUT_LOGITS):
+        check(lib().dsk_forward(self.h, token, pos, mode, _f(self._logits)))
+        return self._logits
+
+    def set_graph(self, on: bool):
+        check(lib().dsk_model_set_graph(self.h, int(on)))
+
+    def set_trace(self, on: bool):
+        check(lib().dsk_model_set_trace(self.h, int(on)))
+
+    def trace_x(self, layer: int):
+        x = np.zeros(self.cfg.dim, np.float32)
+        check(lib().dsk_model_get_trace_x(self.h, layer, _f(x)))
+        return x
+
+    def routing(self):
+        K = max(1, self.cfg.n_active_routed)
+        e = np.zeros(self.cfg.n_layers * K, np.int32)
+        w = np.zeros(self.cfg.n_layers * K, np.float32)
+        check(lib().dsk_model_get_routing(self.h, e.ctypes.data_as(c_i32), _f(w)))
+        return e.reshape(self.cfg.n_layers, K), w.reshape(self.cfg.n_layers, K)
+
+    def profile_forward(self, token: int, pos: int):
+        arr = (KernelTime * 64)()
+        n = C.c_int32()
+        check(lib().dsk_profile_forward(self.h, token, pos, arr, 64, C.byref(n)))
+        return [dict(name=arr[i].name.decode(), launches=arr[i].launches, total_ms=arr[i].total_ms,
+                     algo_bytes=arr[i].algo_bytes) for i in range(n.value)]
+
+    def active_bytes(self, pos: int) -> float:
+        return lib().dsk_model_active_bytes(self.h, pos)
+
+    def device_bytes(self) -> float:
+        return lib().dsk_model_device_bytes(self.h)
+
+    def close(self):
+        if self.h:
+            lib().dsk_model_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

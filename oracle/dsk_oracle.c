@@ -572,12 +572,22 @@ void orc_moe_gate(const float* scores_in, const float* bias, int n_routed, int n
     active_weights[k] = x[active_experts[k]] / wsum * routed_scaling_factor;
 }
 
+/* Source: freq = 1.0f / powf(theta, (float)j_head / (float)head_dim) (src/infer.cpp:655,675).
+ * The reference's -O3 -ffast-math build (Makefile:31) evaluates it as
+ * powf(theta, -(j_head * (1.0f / head_dim))) -- seen in its assembly and checked against
+ * oracle/_ref bit-for-bit in tests/test_oracle_pin.py; at pos ~ 1e3 the two forms differ by 1e-5
+ * in cos/sin, so the oracle (and the engine's host-side table) follow the binary. */
+static inline float ref_rope_freq(float theta, int j_head, int head_dim) {
+  const float inv = 1.0f / (float)head_dim;
+  return powf(theta, -((float)j_head * inv));
+}
+
 /* rope (V2, de-interleaving output) src/infer.cpp:648-668; rope_v3 (in place) :670-685 */
 void orc_rope(float* vec, int d, int head_dim, int pos, float theta, int is_v3) {
   float buf[512];
   for (int i = 0; i < d; i += 2) {
     int j_head = i % head_dim;
-    float freq = 1.0f / powf(theta, (float)j_head / (float)head_dim);
+    float freq = ref_rope_freq(theta, j_head, head_dim);
     float val = pos * freq;
     float fcr = cosf(val), fci = sinf(val);
     float v0 = vec[i], v1 = vec[i + 1];
@@ -598,7 +608,7 @@ void orc_rope_f16(uint16_t* vec, int d, int head_dim, int pos, float theta, int 
   float buf[512];
   for (int i = 0; i < d; i += 2) {
     int j_head = i % head_dim;
-    float freq = 1.0f / powf(theta, (float)j_head / (float)head_dim);
+    float freq = ref_rope_freq(theta, j_head, head_dim);
     float val = pos * freq;
     float fcr = cosf(val), fci = sinf(val);
     float v0 = orc_half_to_float(vec[i]), v1 = orc_half_to_float(vec[i + 1]);

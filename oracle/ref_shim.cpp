@@ -235,3 +235,31 @@ void ref_get_gate_scores(void* h, int layer, float* out) {
 double ref_active_bytes(void* h, int pos) { return static_cast<RefSession*>(h)->model->active_bytes(pos); }
 
 }  // extern "C"
+
+// Per-block wall time of one forward (same statements as ref_forward_traced): seconds[l] for every
+// block, seconds[n_layers] for final norm + lm_head.  Used by bench.py's cpu_baseline leg to
+// extrapolate a full-depth token from a reduced-depth checkpoint.
+extern "C" void ref_forward_timed(void* h, int token, int pos, double* seconds) {
+  auto* S = static_cast<RefSession*>(h);
+  Model& m = *S->model;
+  InferenceState& s = *S->state;
+  const Config& c = *m.config;
+  m._copy_embedding(s, token);
+  int W = c.rs_original_max_position_embeddings;
+  int kv_sink = pos >= W ? KV_SINKS : 0;
+  int kv_pos = kv_sink + (pos - kv_sink) % (W - kv_sink);
+  int kv_len = pos >= W ? W : pos + 1;
+  for (size_t l = 0; l < m.blocks.size(); l++) {
+    double t0 = omp_get_wtime();
+    m.blocks[l]->block(s, pos, kv_sink, kv_pos, kv_len);
+    seconds[l] = omp_get_wtime() - t0;
+  }
+  double t0 = omp_get_wtime();
+  rmsnorm(s.x(), s.x(), static_cast<float*>(m.rms_final_weight->data), c.dim, c.norm_eps);
+  switch (c.weight_quant) {
+    case Quant::F32:
+    case Quant::F16: matmul_unscaled(s.logits(), s.x(), *m.wcls); break;
+    default: matmul(s.logits(), s.x(), *m.wcls, c.block_size.data(), m.scls, s.aqb()); break;
+  }
+  seconds[m.blocks.size()] = omp_get_wtime() - t0;
+}

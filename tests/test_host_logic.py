@@ -1,0 +1,79 @@
+"""Host-side logic that needs no GPU: the synthetic-checkpoint encoders (valid reference blocks),
+the .dseek writer, the tensor-name -> role mapping, and the reference-format loader round trip."""
+import json
+import os
+import struct
+import tempfile
+
+import numpy as np
+import pytest
+
+from tools import synth
+
+
+@pytest.mark.parametrize("quant,enc,tol", [(3, synth.encode_q2k, 0.45), (4, synth.encode_q3k, 0.25)], ids=["q2_k", "q3_k"])
+def test_encoders_produce_blocks_the_reference_layout_decodes(oracle, quant, enc, tol):
+    rng = np.random.default_rng(0)
+    w = rng.standard_normal((6, 1024)).astype(np.float32)
+    wb = enc(w)
+    assert wb.shape == (6, 4 * (84 if quant == 3 else 110)) and wb.dtype == np.uint8
+    deq = np.stack([oracle.dequant_row(quant, wb[r], 1024) for r in range(6)])
+    err = np.sqrt(np.mean((deq - w) ** 2)) / np.std(w)
+    assert err < tol, err  # a wrong bit layout gives ~1.4
+
+
+def test_f8_block_encoder(oracle):
+    rng = np.random.default_rng(1)
+    w = rng.standard_normal((200, 300)).astype(np.float32)
+    b, s = synth.encode_f8_blocks(w, (128, 128))
+    assert b.shape == (200, 300) and s.shape == (2, 3)
+    deq = np.array([[oracle.lib.orc_f8e5m2_to_float(int(v)) for v in row] for row in b[:4]], np.float32)
+    deq *= s[0, np.arange(300) // 128][None, :]
+    assert np.max(np.abs(deq - w[:4])) < 0.3 * np.max(np.abs(w))
+    assert not np.any((b & 0x7C) == 0x7C)  # no inf / nan encodings
+
+
+def test_name_to_role_covers_every_tensor():
+    for preset, quant, mla in (("tiny_v3", "q2_k", True), ("tiny_v3", "f8e5m2", False), ("tiny_v2lite", "q3_k", False)):
+        c = synth.preset(preset, quant, mla)
+        T = synth.synth_model(c, seed=3)
+        seen = set()
+        def bind(role, layer, q, shape, arr):
+            assert (role, layer) not in seen
+            seen.add((role, layer))
+            assert arr.nbytes > 0 and shape[0] > 0
+        synth.bind_all(T, bind)
+        assert (synth.ROLE["EMBED"], -1) in seen and (synth.ROLE["WO"], c.n_layers - 1) in seen
+        assert ((synth.ROLE["WC"], 0) in seen) == mla
+        if quant == "f8e5m2":
+            assert (synth.ROLE["W1"] + synth.ROLE["SCALE"], 1) in seen
+
+
+def test_dseek_writer_layout():
+    c = synth.preset("tiny_v2lite", "q2_k", False)
+    T = synth.synth_model(c, seed=4)
+    d = tempfile.mkdtemp()
+    synth.write_dseek(d, c, T)
+    raw = open(os.path.join(d, "shard_000.dseek"), "rb").read()
+    (hl,) = struct.unpack("<Q", raw[:8])
+    hdr = json.loads(raw[8:8 + hl])
+    md = hdr["__metadata__"]
+    assert md["quant"] == "q2_k" and md["arch"] == "DeepseekV2ForCausalLM" and all(isinstance(v, str) for v in md.values())
+    e = hdr["model.layers.1.mlp.w1.weight"]  # K-quants are stored as U8 byte arrays (src/codec.cpp:170-207)
+    assert e["dtype"] == "U8" and e["shape"] == [c.n_routed_experts, c.moe_intermediate_size, c.dim // 256 * 84]
+    a, b = e["data_offsets"]
+    assert raw[8 + hl + a:8 + hl + b] == T["model.layers.1.mlp.w1.weight"].data.tobytes()
+
+
+def test_reference_loads_what_the_writer_wrote(ref, oracle):
+    """The unmodified reference loader + forward accepts the synthetic checkpoint and agrees with the oracle."""
+    c = synth.preset("tiny_v3", "fp16", False)
+    T = synth.synth_model(c, seed=5)
+    d = tempfile.mkdtemp()
+    synth.write_dseek(d, c, T)
+    S, M = ref.session(d, c), oracle.model(c, T)
+    a, b = S.forward(7, 0), M.forward(7, 0)
+    assert np.max(np.abs(a - b)) < 1e-4 * np.max(np.abs(a))
+    assert S.active_bytes(0) > 0
+    S.close()
+    M.close()

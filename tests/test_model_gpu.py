@@ -1,0 +1,207 @@
+"""GPU parity, model level: dsk_forward (the replacement of Model::forward) vs the reference's
+recorded outputs (tests/golden/model_*.npz), the CPU oracle and -- where the prebuilt
+oracle/_ref/libdskref.so loads -- the unmodified reference running live on the host.
+"""
+import tempfile
+
+import numpy as np
+import pytest
+
+from tests.util import MODEL_CASES, assert_model_parity, case_id, is_kquant, load_case, model_parity_stats, rel_inf
+from tools import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", MODEL_CASES, ids=case_id)
+def test_model_vs_reference_golden(ctx, case):
+    import dsk
+    c, T, g, sha_ok = load_case(case)
+    if not sha_ok:
+        pytest.skip("synthetic weights differ from the fixture's (numpy RNG change)")
+    M = dsk.Model(ctx, c, T)
+    st = model_parity_stats(M, c, g)
+    M.close()
+    assert_model_parity(st, is_kquant(c.quant), "HIP vs reference")
+
+
+@pytest.mark.parametrize("case", MODEL_CASES, ids=case_id)
+def test_model_vs_oracle_live(ctx, oracle, case):
+    """Same statistics against the oracle on tokens the fixtures do not contain."""
+    import dsk
+    c, T, _, _ = load_case(case)
+    M, O = dsk.Model(ctx, c, T), oracle.model(c, T)
+    toks = [11, 400, 23, 999, 7]
+    g = dict(tokens=np.array(toks), tokens0=np.array([3, 33, 333, 600, 41, 52, 63, 74]))
+    g["logits"], g["route_e"], g["logits0"], g["route0_e"] = [], [], [], []
+    for pos, t in enumerate(toks):
+        g["logits"].append(O.forward(t % c.vocab_size, pos))
+        g["route_e"].append(O.routing()[0])
+    for t in g["tokens0"]:
+        g["logits0"].append(O.forward(int(t) % c.vocab_size, 0))
+        g["route0_e"].append(O.routing()[0])
+    st = model_parity_stats(M, c, g)
+    M.close()
+    O.close()
+    assert_model_parity(st, is_kquant(c.quant), "HIP vs oracle")
+
+
+def test_trace_x_per_layer_float_model(ctx, oracle):
+    """Residual stream after every block, fp16 weights (no W.A8 discontinuity): 1e-4 per layer."""
+    import dsk
+    c = synth.preset("tiny_v3", "fp16", False)
+    T = synth.synth_model(c, seed=21)
+    M, O = dsk.Model(ctx, c, T), oracle.model(c, T)
+    M.set_trace(True)
+    for pos, t in enumerate([4, 8, 15, 16, 23, 42]):
+        lg, lo = M.forward(t, pos), O.forward(t, pos)
+        for l in range(c.n_layers):
+            assert rel_inf(M.trace_x(l), O.trace_x(l)) < 1e-4, (pos, l)
+        assert rel_inf(lg, lo) < 1e-4
+        assert np.array_equal(M.routing()[0], O.routing()[0])
+    M.close()
+    O.close()
+
+
+@pytest.mark.parametrize("quant,mla", [("q2_k", False), ("q2_k", True), ("f8e5m2", False)])
+def test_graph_replay_equals_eager_and_is_deterministic(ctx, quant, mla):
+    import dsk
+    c = synth.preset("tiny_v3", quant, mla)
+    T = synth.synth_model(c, seed=5)
+    A, B = dsk.Model(ctx, c, T), dsk.Model(ctx, c, T)
+    B.set_graph(False)
+    for pos, t in enumerate([9, 99, 999, 5, 6, 7]):
+        la, lb = A.forward(t, pos), B.forward(t, pos)
+        assert np.array_equal(la, lb), pos  # same kernels, same order => bit-identical
+    assert np.array_equal(A.forward(9, 0), A.forward(9, 0))
+    A.close()
+    B.close()
+
+
+def test_hydrate_mode_matches_full_forward(ctx):
+    """HYDRATE_KV_CACHE must leave the caches exactly as OUTPUT_LOGITS does (src/infer.cpp:1284-1287)."""
+    import dsk
+    c = synth.preset("tiny_v3", "q2_k", True)
+    T = synth.synth_model(c, seed=6)
+    A, B = dsk.Model(ctx, c, T), dsk.Model(ctx, c, T)
+    toks = [3, 1, 4, 1, 5, 9, 2, 6]
+    for pos, t in enumerate(toks[:-1]):
+        A.forward(t, pos)
+        assert B.forward(t, pos, dsk.MODE_HYDRATE_KV_CACHE) is None
+    assert np.array_equal(A.forward(toks[-1], len(toks) - 1), B.forward(toks[-1], len(toks) - 1))
+    A.close()
+    B.close()
+
+
+@pytest.mark.parametrize("mla", [False, True], ids=["mha", "mla"])
+@pytest.mark.parametrize("arch", ["DeepseekV3ForCausalLM", "DeepseekV2ForCausalLM"], ids=["rope_v3", "rope_v2"])
+def test_kv_ring_and_sink_rotation(ctx, oracle, mla, arch):
+    """StreamingLLM ring (src/infer.cpp:1271-1277) with the two attention sinks re-rotated in f16
+    every step once pos >= W (src/infer.cpp:1004-1020, 1099-1110); W = 8 so 24 tokens wrap twice."""
+    import dsk
+    c = synth.preset("tiny_v3", "fp16", mla, arch=arch, rs_original_max_position_embeddings=8, max_seq_len=8)
+    T = synth.synth_model(c, seed=31)
+    M, O = dsk.Model(ctx, c, T), oracle.model(c, T)
+    rng = np.random.default_rng(2)
+    for pos in range(24):
+        t = int(rng.integers(0, c.vocab_size))
+        assert rel_inf(M.forward(t, pos), O.forward(t, pos)) < 1e-3, pos
+    M.close()
+    O.close()
+
+
+def test_live_reference_on_this_host(ctx, ref):
+    """HIP vs the unmodified reference executing on the host CPU (prebuilt oracle/_ref)."""
+    import dsk
+    for quant, mla in (("f8e5m2", False), ("q2_k", True)):
+        c = synth.preset("tiny_v3", quant, mla)
+        T = synth.synth_model(c, seed=77)
+        d = tempfile.mkdtemp()
+        synth.write_dseek(d, c, T)
+        S, M = ref.session(d, c), dsk.Model(ctx, c, T)
+        g = dict(tokens=np.array([2, 3, 5, 7]), tokens0=np.arange(10, 18))
+        g["logits"], g["route_e"], g["logits0"], g["route0_e"] = [], [], [], []
+        for pos, t in enumerate(g["tokens"]):
+            g["logits"].append(S.forward(int(t), pos))
+            g["route_e"].append(S.routing()[0])
+        for t in g["tokens0"]:
+            g["logits0"].append(S.forward(int(t), 0))
+            g["route0_e"].append(S.routing()[0])
+        st = model_parity_stats(M, c, g)
+        M.close()
+        S.close()
+        assert_model_parity(st, is_kquant(quant), "HIP vs live reference")
+
+
+def test_active_bytes_formula(ctx):
+    """dsk_model_active_bytes = true-block-size algorithmic bytes."""
+    import dsk
+    c = synth.preset("tiny_v3", "q2_k", False)
+    M = dsk.Model(ctx, c, synth.synth_model(c, seed=1))
+    H, hd = c.n_heads, c.head_dim
+    q = lambda r, n: r * n // 256 * 84
+    attn = q(c.q_lora_rank, c.dim) + q(H * hd, c.q_lora_rank) + q(c.kv_lora_rank + c.qk_rope_head_dim, c.dim) + \
+        q(H * (c.qk_nope_head_dim + c.v_head_dim), c.kv_lora_rank) + q(c.dim, H * c.v_head_dim)
+    norms = 4 * (2 * c.dim + c.q_lora_rank + c.kv_lora_rank)
+    dense = 3 * q(c.hidden_dim, c.dim)
+    moe = c.n_active_routed * 3 * q(c.moe_intermediate_size, c.dim) + 3 * q(c.n_shared_experts * c.moe_intermediate_size, c.dim) + \
+        4 * c.n_routed_experts * c.dim + 4 * c.n_routed_experts
+    pos = 5
+    kv = (pos + 1) * H * (hd + c.v_head_dim) * 2
+    want = q(1, c.dim) + c.n_layers * (attn + norms + kv) + dense + 2 * moe + 4 * c.dim + q(c.vocab_size, c.dim)
+    assert M.active_bytes(pos) == pytest.approx(want, rel=1e-12)
+    M.close()
+
+
+def test_error_paths_do_not_abort(ctx):
+    """The reference assert(false)s (src/model.cpp:131-132); the boundary returns codes + messages."""
+    import ctypes as C
+    import dsk
+    L = dsk.lib()
+    c = synth.preset("tiny_v3", "q2_k", False)
+    T = synth.synth_model(c, seed=1)
+    M = dsk.Model(ctx, c, T)
+    logits = np.zeros(c.vocab_size, np.float32)
+    lp = logits.ctypes.data_as(dsk.c_f)
+    assert L.dsk_forward(M.h, c.vocab_size, 0, 1, lp) == -1 and b"token" in L.dsk_last_error()
+    assert L.dsk_forward(M.h, 0, -1, 1, lp) == -1
+    assert L.dsk_forward(M.h, 0, 0, 7, lp) == -1
+    assert L.dsk_forward(M.h, 0, 0, 1, None) == -1
+    assert L.dsk_forward(M.h, 0, c.max_seq_len, 1, lp) == -1 and b"max_seq_len" in L.dsk_last_error()
+    assert L.dsk_forward(None, 0, 0, 1, lp) == -1
+    M.close()
+    # forward before finalize / missing tensor / wrong shape / wrong byte count / double bind
+    h = C.c_void_p()
+    dc = dsk.make_config(c)
+    assert L.dsk_model_create(ctx.h, C.byref(dc), C.byref(h)) == 0
+    assert L.dsk_forward(h, 0, 0, 1, lp) == -4
+    assert L.dsk_model_finalize(h) == -4 and b"not bound" in L.dsk_last_error()
+    t = T["model.norm.weight"]
+    bad_shape = synth.shape4((c.dim + 1,))
+    assert L.dsk_model_bind(h, 1, -1, 0, bad_shape.ctypes.data_as(dsk.c_i32), t.data.ctypes.data, t.data.nbytes) == -1
+    ok_shape = synth.shape4((c.dim,))
+    assert L.dsk_model_bind(h, 1, -1, 0, ok_shape.ctypes.data_as(dsk.c_i32), t.data.ctypes.data, t.data.nbytes - 4) == -1
+    assert L.dsk_model_bind(h, 1, -1, 3, ok_shape.ctypes.data_as(dsk.c_i32), t.data.ctypes.data, t.data.nbytes) == -1
+    assert L.dsk_model_bind(h, 1, -1, 0, ok_shape.ctypes.data_as(dsk.c_i32), t.data.ctypes.data, t.data.nbytes) == 0
+    assert L.dsk_model_bind(h, 1, -1, 0, ok_shape.ctypes.data_as(dsk.c_i32), t.data.ctypes.data, t.data.nbytes) == -4
+    assert L.dsk_model_bind(h, 20, 0, 3, ok_shape.ctypes.data_as(dsk.c_i32), t.data.ctypes.data, t.data.nbytes) == -1  # WC in an MHA model
+    assert L.dsk_model_destroy(h) == 0
+    # configuration the reference rejects: MLA without q_lora_rank (src/infer.cpp:1057)
+    bad = synth.preset("tiny_v2lite", "fp16", False)
+    bad.use_mla = True
+    dc = dsk.make_config(bad)
+    assert L.dsk_model_create(ctx.h, C.byref(dc), C.byref(h)) == -1 and b"q_lora_rank" in L.dsk_last_error()
+
+
+def test_synthesized_weights_are_valid_and_deterministic(ctx):
+    import dsk
+    for quant in ("q2_k", "q3_k", "f8e5m2", "fp16"):
+        c = synth.preset("tiny_v3", quant, quant != "fp16")
+        A, B = dsk.Model(ctx, c, None, synth_seed=123), dsk.Model(ctx, c, None, synth_seed=123)
+        la, lb = A.forward(17, 0), B.forward(17, 0)
+        assert np.all(np.isfinite(la)) and np.array_equal(la, lb) and np.std(la) > 0
+        e, w = A.routing()
+        moe = e[c.first_k_dense_replace:]
+        assert moe.min() >= 0 and moe.max() < c.n_routed_experts and all(len(set(r)) == len(r) for r in moe)
+        A.close()
+        B.close()

@@ -1,0 +1,144 @@
+"""Pin the CPU oracle (oracle/dsk_oracle.c) to the reference.
+
+Three layers of evidence, all CPU-only:
+  1. the known-answer vectors inside the reference's own src/test.cpp;
+  2. tests/golden/ops.npz + model_*.npz: outputs of the unmodified reference compiled from
+     /root/reference (tools/make_golden.py), committed as fixtures;
+  3. when oracle/_ref/libdskref.so is loadable, live comparisons on fresh random inputs.
+Integer work (Q8_K ints, top-k indices, codecs) must be bit-exact; the AVX2-lane-exact GEMVs are
+bit-exact too; stages whose float order the reference leaves to -ffast-math are by tolerance.
+"""
+import numpy as np
+import pytest
+
+from tests.util import MODEL_CASES, assert_model_parity, case_id, is_kquant, load_case, model_parity_stats, rel_inf
+from tools import synth
+
+# --------------------------------------------------------------------------- 1. reference KATs
+KAT_X = np.array([2.0624e-01, 1.6975e+00, 8.4918e-01, -1.7186e-01, -9.0164e-01, 6.1108e-01, 2.2116e-01, 1.0412e+00,
+                  -1.6616e-03, 8.2840e-01, 2.2667e-01, -1.3993e+00, 4.1013e-01, -1.2223e+00, 2.2723e-01, 6.3558e-01],
+                 np.float32)  # src/test.cpp:132-137
+KAT_W = np.array([[-1.1210, -0.0235, -1.3527, 0.6300, 0.2566, -0.4517, -0.3528, 0.4422,
+                   -0.4032, -1.0949, -0.7834, 1.1425, 0.6263, -0.3680, 0.3226, -0.2984],
+                  [0.1176, -1.1462, -0.8181, -2.0047, 0.0932, 1.4665, -0.8682, -0.8490,
+                   -1.3017, -1.0068, -0.2890, 0.0167, 1.1607, 0.7196, 1.7701, 0.2891]], np.float32)  # src/test.cpp:138-145
+KAT_Y = np.array([-3.7454, -3.2738], np.float32)  # src/test.cpp:150,157,164 (with shape {2,16})
+
+
+def test_kat_matmul_f32_f16(oracle):
+    assert np.allclose(oracle.gemv(0, KAT_W, 2, 16, KAT_X), KAT_Y, atol=1e-4)
+    assert np.allclose(oracle.gemv(1, KAT_W.astype(np.float16), 2, 16, KAT_X), KAT_Y, atol=1e-3)
+
+
+def test_kat_f8e5m2(oracle):
+    L = oracle.lib
+    for v in (1.0, -1.5, 0.109375):  # src/test.cpp:129-131
+        assert L.orc_f8e5m2_to_float(L.orc_float_to_f8e5m2(v)) == v
+    w8 = np.array([L.orc_float_to_f8e5m2(float(v)) for v in KAT_W.ravel()], np.uint8).reshape(2, 16)
+    y = oracle.gemv(2, w8, 2, 16, KAT_X)
+    assert np.allclose(y, KAT_Y, atol=3.78e-1)                     # the file's own tolerance (src/test.cpp:167)
+    assert np.allclose(y, [-3.36792, -2.92358], atol=2e-5)         # what the shipped (truncating) code gives
+    rt = np.array([L.orc_f8e5m2_to_float(L.orc_float_to_f8e5m2(float(v))) for v in KAT_X], np.float32)
+    assert np.array_equal(rt, np.array([0.1875, 1.5, 0.75, -0.15625, -0.875, 0.5, 0.21875, 1, -0.00146484, 0.75, 0.21875,
+                                        -1.25, 0.375, -1, 0.21875, 0.625], np.float32).astype(np.float16).astype(np.float32))
+
+
+def test_kat_attn_onehot(oracle):
+    # src/test.cpp:84-125 with the single-KV-head stride the shipped attn() expects
+    kb = np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1], [-1, 0, 0]], np.float32).astype(np.float16).view(np.uint16)
+    for q, want in (([0., 1e4, 0.], [0, 1, 0]), ([0., 0., 1e4], [0, 0, 1])):
+        out = oracle.attn_mha(np.array(q, np.float32), kb, kb, 1, 3, 3, 4)
+        assert np.allclose(out, want, atol=1e-6)
+
+
+# --------------------------------------------------------------------------- 2. golden fixtures
+def test_golden_q8k(oracle, ops_gold):
+    qs, d, bs = oracle.q8k_quantize(ops_gold["q8_x"])
+    assert np.array_equal(qs, ops_gold["q8_qs"])
+    assert np.array_equal(bs, ops_gold["q8_bsums"])
+    assert np.array_equal(d, ops_gold["q8_d"])
+
+
+@pytest.mark.parametrize("key,quant", [("q2k", 3), ("q3k", 4), ("q2k_ref", 3), ("q3k_ref", 4), ("f16", 1), ("f32", 0)])
+def test_golden_gemv_bitexact(oracle, ops_gold, key, quant):
+    w = ops_gold["w_" + key]
+    y = oracle.gemv(quant, w, 48, 1024, ops_gold["gemv_x"])
+    assert np.array_equal(y, ops_gold["y_" + key])
+
+
+def test_golden_gemv_f8(oracle, ops_gold):
+    y = oracle.gemv(2, ops_gold["w_f8"], 256, 1024, ops_gold["gemv_x"], ops_gold["s_f8"], (128, 128))
+    assert np.array_equal(y, ops_gold["y_f8"])
+
+
+def test_golden_experts_and_dequant(oracle, ops_gold):
+    for e in range(4):
+        y = oracle.gemv_expert(3, ops_gold["we_q2k"], e, 32, 512, ops_gold["xe"])
+        assert np.array_equal(y, ops_gold["ye_q2k"][e])
+    assert np.array_equal(oracle.dequant_row(3, ops_gold["w_q2k_ref"][5], 1024), ops_gold["deq_q2k"])
+    assert np.array_equal(oracle.dequant_row(4, ops_gold["w_q3k_ref"][5], 1024), ops_gold["deq_q3k"])
+
+
+def test_golden_small_ops(oracle, ops_gold):
+    g = ops_gold
+    assert rel_inf(oracle.rmsnorm(g["rms_x"], g["rms_w"], 1e-6), g["rms_y"]) < 1e-6
+    e, w, sc = oracle.moe_gate(g["gate3_s"], g["gate3_b"], 8, True, 2.5, 1, 1, 8, 4)
+    assert np.array_equal(e, g["gate3_e"]) and rel_inf(w, g["gate3_w"]) < 1e-6 and rel_inf(sc, g["gate3_scores"]) < 1e-6
+    e, w, sc = oracle.moe_gate(g["gate2_s"], None, 6, False, 1.0, 0, 0, 1, 1)
+    assert np.array_equal(e, g["gate2_e"]) and rel_inf(w, g["gate2_w"]) < 1e-6
+    assert np.allclose(oracle.rope(g["rope_in"], 64, 1234, 10000.0, False), g["rope_v2"], atol=1e-6)
+    assert np.allclose(oracle.rope(g["rope_in"], 64, 1234, 10000.0, True), g["rope_v3"], atol=1e-6)
+    assert rel_inf(oracle.attn_mha(g["att_q"], g["att_k"], g["att_v"], 4, 192, 128, 70), g["att_y"]) < 1e-5
+    assert rel_inf(oracle.attn_mla(g["mla_qc"], g["mla_qr"], g["mla_ckv"], g["mla_kr"], 4, 192, 512, 64, 70), g["mla_y"]) < 1e-5
+
+
+def test_golden_codecs(oracle, ops_gold):
+    L = oracle.lib
+    vals = ops_gold["codec_in"]
+    assert np.array_equal(np.array([L.orc_float_to_half(float(v)) for v in vals], np.uint16), ops_gold["codec_f16"])
+    assert np.array_equal(np.array([L.orc_float_to_f8e5m2(float(v)) for v in vals], np.uint8), ops_gold["codec_f8"])
+    h2f = np.array([L.orc_half_to_float(int(h)) for h in range(0, 65536, 97)], np.float32)
+    assert np.array_equal(h2f.view(np.uint32), ops_gold["codec_h2f"].view(np.uint32))
+
+
+@pytest.mark.parametrize("case", MODEL_CASES, ids=case_id)
+def test_golden_model(oracle, case):
+    """Free-running token steps: oracle vs the reference's recorded logits / routing.
+
+    Float (fp32/fp16/f8) models must agree to 1e-3 of the logit scale on every token.  W2A8/W3A8
+    models are discontinuous in their inputs (a 1e-7 perturbation of an activation flips an int8
+    rounding, SURVEY 7 "hard parts"), so on these tiny dims a flipped rounding moves the logits by
+    up to ~1e-2: the median token must still be within 1e-3 and every token within 5e-2.
+    """
+    c, T, g, sha_ok = load_case(case)
+    if not sha_ok:
+        pytest.skip("synthetic weights differ from the ones the fixture was generated with (numpy RNG change)")
+    M = oracle.model(c, T)
+    st = model_parity_stats(M, c, g)
+    M.close()
+    assert_model_parity(st, is_kquant(c.quant), "oracle vs reference")
+
+
+# --------------------------------------------------------------------------- 3. live vs the reference build
+def test_live_gemv_and_q8_bitexact(oracle, ref):
+    rng = np.random.default_rng(3)
+    for n, d in ((256, 5), (512, 16), (1536, 24), (7168, 8)):
+        x = (rng.standard_normal(n) * rng.uniform(0.01, 30)).astype(np.float32)
+        a, b = oracle.q8k_quantize(x), ref.q8k_quantize(x)
+        assert all(np.array_equal(u, v) for u, v in zip(a, b))
+        w = (rng.standard_normal((d, n)) / np.sqrt(n)).astype(np.float32)
+        for quant, enc in ((3, synth.encode_q2k), (4, synth.encode_q3k)):
+            wb = enc(w)
+            assert np.array_equal(oracle.gemv(quant, wb, d, n, x), ref.gemv(quant, wb, d, n, x))
+        w8, s8 = synth.encode_f8_blocks(w, (128, 128))
+        assert np.array_equal(oracle.gemv(2, w8, d, n, x, s8, (128, 128)), ref.gemv(2, w8, d, n, x, s8, (128, 128)))
+
+
+def test_live_router_gate_exact(oracle, ref):
+    rng = np.random.default_rng(4)
+    for _ in range(20):
+        s = rng.standard_normal(256).astype(np.float32)
+        b = (0.1 * rng.standard_normal(256)).astype(np.float32)
+        eo, wo, _ = oracle.moe_gate(s, b, 8, True, 2.5, 1, 1, 8, 4)
+        er, wr, _ = ref.moe_gate(s, b, 8, True, 2.5, 1, 1, 8, 4)
+        assert np.array_equal(eo, er) and rel_inf(wo, wr) < 1e-6
