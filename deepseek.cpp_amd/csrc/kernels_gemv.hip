@@ -27,6 +27,9 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 DEV int sdot4(u32 a, u32 b, int c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, false); }
 DEV float h2f(u32 bits16) { return (float)__builtin_bit_cast(_Float16, (unsigned short)bits16); }
+// NB: __builtin_bit_cast applied directly to an ext_vector component (w.y) is miscompiled by hipcc 7.2
+// (every component reads element 0); always go through a by-value scalar.
+DEV float u2f(u32 v) { return __builtin_bit_cast(float, v); }
 template <typename T>
 DEV T ldg_nt(const T* p) { return __builtin_nontemporal_load(p); }
 
@@ -261,10 +264,10 @@ __global__ __launch_bounds__(256) void gemv_kq_kernel(GemvSeg sg, int lpr_log2) 
 template <int QT>
 DEV float fitem(u32x4 w, const float* xa, float partial) {
   if (QT == DSK_QUANT_F32) {
-    partial = fmaf(__builtin_bit_cast(float, w.x), xa[0], partial);
-    partial = fmaf(__builtin_bit_cast(float, w.y), xa[1], partial);
-    partial = fmaf(__builtin_bit_cast(float, w.z), xa[2], partial);
-    partial = fmaf(__builtin_bit_cast(float, w.w), xa[3], partial);
+    partial = fmaf(u2f(w.x), xa[0], partial);
+    partial = fmaf(u2f(w.y), xa[1], partial);
+    partial = fmaf(u2f(w.z), xa[2], partial);
+    partial = fmaf(u2f(w.w), xa[3], partial);
   } else if (QT == DSK_QUANT_F16) {
     const u32 ww[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
@@ -351,10 +354,10 @@ __global__ __launch_bounds__(256) void gemv_f_kernel(GemvSeg sg, int lpr_log2) {
 #pragma unroll
     for (int k = 0; k < EPI / 4; ++k) {
       const u32x4 v = *reinterpret_cast<const u32x4*>(l_x + item * EPI + 4 * k);
-      xa[4 * k] = __builtin_bit_cast(float, v.x);
-      xa[4 * k + 1] = __builtin_bit_cast(float, v.y);
-      xa[4 * k + 2] = __builtin_bit_cast(float, v.z);
-      xa[4 * k + 3] = __builtin_bit_cast(float, v.w);
+      xa[4 * k] = u2f(v.x);
+      xa[4 * k + 1] = u2f(v.y);
+      xa[4 * k + 2] = u2f(v.z);
+      xa[4 * k + 3] = u2f(v.w);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {

@@ -94,7 +94,7 @@ def test_gemv_f8e5m2_blocks(ctx, oracle, d, n):
 
 
 @pytest.mark.parametrize("quant,dt", [(0, np.float32), (1, np.float16)], ids=["f32", "f16"])
-@pytest.mark.parametrize("d,n", [(2, 16), (64, 2048), (257, 7168), (19, 24)])
+@pytest.mark.parametrize("d,n", [(2, 16), (64, 2048), (257, 7168), (19, 48)])
 def test_gemv_f32_f16(ctx, oracle, quant, dt, d, n):
     rng = np.random.default_rng(d * 7 + n)
     w = (rng.standard_normal((d, n)) / np.sqrt(n)).astype(dt)
