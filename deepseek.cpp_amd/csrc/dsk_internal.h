@@ -54,37 +54,61 @@ struct DTensor {
   bool bound() const { return base != nullptr; }
 };
 
-// One GEMV "segment": rows of one matrix (or one expert slot of a stacked tensor).
-struct GemvSeg {
-  const uint8_t* qs;  // K-quant: qs plane; F8/F16/F32: the row-major matrix
-  const uint8_t* sc;
-  const uint8_t* hm;
-  const uint8_t* dm;
-  const float* scale;  // F8 block scales (row-major (ceil(d/b0), ncols)) or null
-  // second matrix for the fused GLU pair (w3); same shape as the first
-  const uint8_t* qs2;
-  const uint8_t* sc2;
-  const uint8_t* hm2;
-  const uint8_t* dm2;
+// ---- GEMV launch descriptors (kernels_gemv.hip) ----------------------------------
+// A launch descriptor lives in device memory (built once per layer at finalize time: every
+// pointer in it is fixed for the life of the model, so a captured graph can replay it).
+enum { EPI_STORE = 0, EPI_ADD = 1 };
+enum { ACT_Q8 = 0, ACT_F32 = 1, ACT_F32_NORM = 2, ACT_F32_BMAX = 3 };
+enum { GEMV_MODE_TASKS = 0, GEMV_MODE_ACCUM = 1 };
+#define GEMV_MAX_TASKS 12
+
+struct GemvTask {
+  // weights: K-quant planes, or qs = the row-major F8/F16/F32 matrix; second set = w3 of a GLU pair
+  const uint8_t *qs, *sc, *hm, *dm;
+  const float* scale;
+  const uint8_t *qs2, *sc2, *hm2, *dm2;
   const float* scale2;
-  size_t e_qs, e_sc, e_hm, e_dm, e_scale;  // expert strides (bytes; scale in floats)
-  const int* expert_ids;    // device: slot -> expert id (null: slot s uses expert `s`, or none)
-  int expert_base, local_experts;  // sharding: skip slots whose expert is not local
-  int n_slots;              // grid.y
+  size_t e_qs, e_sc, e_hm, e_dm, e_scale;  // expert strides (bytes; scale in floats); e_qs == 0: not a stack
+  const int* expert_ids;                    // device: slot -> expert id (null: expert = slot)
+  int slot, expert_base, local_experts;
   int rows, n;
-  // activation: q8 (K-quants) or f32
-  const int8_t* a_qs;
+  // activation vector
+  int act_mode;            // ACT_*
+  const int8_t* a_qs;      // ACT_Q8: ready Q8_K vector
   const float* a_d;
   const int16_t* a_bsums;
-  const float* a_f32;
-  size_t a_slot_stride;     // elements between consecutive slots' activations (0 = shared)
-  float* out;               // out[slot * out_slot_stride + row]
-  size_t out_slot_stride;
-  int epilogue;             // EPI_*
-  int act;                  // DSK_ACT_* for EPI_GLU
-  int sc_cols, b0, b1;      // F8 scale geometry
+  const float* a_f32;      // ACT_F32 / ACT_F32_NORM: f32 vector (quantised / normed in the prologue)
+  const float* norm_w;     // rmsnorm weight
+  float eps;
+  float* norm_out;         // optional: workgroup 0 of the task also stores the normed f32 vector
+  // ACT_F32_BMAX: the producer already found, per 256-block, the first element of largest magnitude
+  // (64-bit key, see bmax_key() in kernels_gemv.hip); the prologue only rounds.
+  const unsigned long long* a_bmax;
+  unsigned long long* bmax_out;  // producer side: GLU epilogue atomically maxes its output's block keys
+  // output
+  float* out;
+  int epilogue;            // EPI_*
+  const float* accum_w;    // GEMV_MODE_ACCUM: device pointer to this slot's mixing weight (null: 1)
+  int wg_begin, wg_end;    // workgroup range of this task
 };
-enum { EPI_STORE = 0, EPI_ADD = 1, EPI_GLU = 2 };
+
+struct GemvLaunch {
+  GemvTask t[GEMV_MAX_TASKS];
+  int n_tasks;
+  int quant, mode, glu, act;  // act = DSK_ACT_* of the GLU epilogue
+  int lpr_log2, R, U, grid;
+  int force_lpr, force_R, force_U;  // > 0: override the planner (micro-benchmarks)
+  int b0, b1;                 // F8 block-scale geometry
+  // block-diagonal stack (MLA per-head wv_b, src/infer.cpp:1134-1137): t[0] describes head 0 of
+  // `bd_heads` equal (rows, n) matrices stacked along rows; head h reads activation a_f32 + h*n and
+  // writes out + h*rows; bd_wgs workgroups per head
+  int bd_heads, bd_wgs;
+  size_t lds_bytes;
+  double algo_bytes;          // host-side bookkeeping for the roofline report
+};
+
+int gemv_plan(GemvLaunch& h, int target_wgs);
+int gemv_launch(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& host);
 
 // per-token parameters living in device memory so that a captured graph can be replayed
 struct StepParams {
@@ -115,14 +139,28 @@ struct NormJob {         // one workgroup of norm_q8_kernel
   int rope_v3;
 };
 
-// ---- launchers (kernels_*.hip) --------------------------------------------------
-int launch_gemv(hipStream_t st, int quant, const GemvSeg& seg);
+// ---- launchers (kernels_misc.hip) --------------------------------------------------
 int launch_quantize_q8k(hipStream_t st, const float* x, int n, int8_t* qs, float* d, int16_t* bsums);
 int launch_norm_jobs(hipStream_t st, const NormJob* jobs, int n_jobs, const StepParams* sp);
 int launch_repack_q2k(hipStream_t st, const uint8_t* aos, size_t n_blocks, uint8_t* qs, uint8_t* sc, uint8_t* dm);
 int launch_repack_q3k(hipStream_t st, const uint8_t* aos, size_t n_blocks, uint8_t* qs, uint8_t* hm, uint8_t* sc, uint8_t* dm);
 int launch_embed(hipStream_t st, const DTensor& t, const StepParams* sp, int token_override, int b0, int b1, float* x);
-int launch_router(hipStream_t st, const float* w, const float* x, int n_routed, int dim, float* partial, int ksplit);
+struct RouterArgs {       // F32 router GEMV (+ optional rmsnorm prologue) + moe_gate in the last workgroup
+  const float* w;         // (E, dim)
+  const float* x;         // input vector (f32)
+  const float* norm_w;    // if non-null: x is normalised first (rmsnorm with eps)
+  float eps;
+  int n_routed, dim, ksplit;
+  float* partial;         // (ksplit, E)
+  unsigned* counter;      // arrival counter (zeroed by the kernel that consumes it)
+  const float* bias;
+  int n_active, norm_topk_prob, scoring, topk_method, n_group, topk_group;
+  float scaling;
+  int* active_experts;
+  float* active_weights;
+  float* scores_out;
+};
+int launch_router_gate(hipStream_t st, const RouterArgs& a);
 int launch_gate(hipStream_t st, const float* partial, int ksplit, const float* bias, int n_routed, int n_active,
                 int norm_topk_prob, float scaling, int scoring, int topk_method, int n_group, int topk_group,
                 int* active_experts, float* active_weights, float* scores_out);

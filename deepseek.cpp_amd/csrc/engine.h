@@ -1,0 +1,95 @@
+// engine.h -- host-side data structures of the decode engine (shared by engine.cpp / forward.cpp).
+#pragma once
+#include "dsk_internal.h"
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include <rccl/rccl.h>
+
+struct dsk_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1;
+  // scratch for op-level entry points
+  void* op_buf[8] = {nullptr};
+  size_t op_cap[8] = {0};
+};
+
+static const int NROLES = 32;
+int cdiv_i(int a, int b);
+static const int KV_SINKS_GUARD = 2;  // KV_SINKS, src/model.h:14
+
+struct Layer {
+  DTensor t[NROLES];
+  uint16_t *key_cache = nullptr, *value_cache = nullptr;    // MHA (src/model.cpp:459-460)
+  uint16_t *nope_cache = nullptr, *rope_cache = nullptr;    // MLA (src/model.cpp:618-619)
+  bool is_moe = false;
+};
+
+struct Q8Buf {  // Q8_K activation vector in HBM (struct-of-arrays of block_q8_K, src/quant.h:104-109)
+  int8_t* qs = nullptr;
+  float* d = nullptr;
+  int16_t* bsums = nullptr;
+  int cap = 0;
+};
+
+struct KTime {
+  const char* name;
+  int launches = 0;
+  double algo_bytes = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+};
+
+struct dsk_model {
+  dsk_ctx* ctx = nullptr;
+  dsk_config c{};
+  int head_dim = 0;
+  DTensor g[4];  // EMBED, FINAL_NORM, OUTPUT
+  std::vector<Layer> L;
+  bool finalized = false;
+  bool tied = false;
+  double weight_bytes = 0, cache_bytes = 0, scratch_bytes = 0;
+  // activations (src/model.h:151-178)
+  float *x = nullptr, *xb = nullptr, *q_a = nullptr, *q = nullptr, *kv_a = nullptr, *kv_b = nullptr, *att_out = nullptr,
+        *hb = nullptr, *eout = nullptr, *q_c = nullptr, *q_rope = nullptr, *vb_out = nullptr, *router_partial = nullptr,
+        *gate_scores = nullptr, *logits = nullptr, *trace_x = nullptr;
+  int* route_e = nullptr;    // [n_layers][K] : every layer keeps its own routing decision
+  float* route_w = nullptr;  // [n_layers][K]
+  Q8Buf a_xb, a_qa, a_kva, a_att, a_hb;
+  StepParams* sp_dev = nullptr;
+  StepParams* sp_host = nullptr;  // pinned
+  float* logits_host = nullptr;   // pinned
+  int router_ksplit = 1;
+  int n_slots = 0;  // routed slots (K) + 1 if shared experts
+  // graphs
+  bool use_graph = true, trace = false;
+  hipGraphExec_t graph[2] = {nullptr, nullptr};
+  // GEMV launch descriptors (forward.cpp): host copies + one device array
+  std::vector<GemvLaunch> plans;
+  GemvLaunch* plans_dev = nullptr;
+  std::vector<int> lp_qkv_a, lp_qkv_b, lp_wv_b, lp_wo, lp_w13, lp_w2, lp_w2_shared;  // per-layer indices into plans (-1: none)
+  int lp_head = -1;
+  unsigned* router_counter = nullptr;
+  unsigned long long* bmax = nullptr;  // [n_layers][bmax_per_layer] block-max keys of the hidden vectors (zeroed per token)
+  size_t bmax_per_layer = 0;
+  int target_wgs = 1024;
+  // profiling
+  bool profiling = false;
+  std::vector<KTime> ktimes;
+  std::map<std::string, int> kindex;
+};
+
+// expected logical shape of a role (src/model.cpp:184-285, 393-457, 557-616, 766-871)
+struct RoleShape {
+  int quant;      // expected quant
+  int e, rows, n; // e = 0: 2-D
+  bool ok;
+};
+RoleShape role_shape(const dsk_model* m, int role, int layer);
+extern const int ALL_LAYER_ROLES[];
+extern const int N_LAYER_ROLES;
+int build_plans(dsk_model* m);   // forward.cpp: GEMV launch descriptors, built once at finalize
+void free_plans(dsk_model* m);

@@ -1,0 +1,562 @@
+// forward.cpp -- the token step: Model::_forward_cpu / Block::_block_cpu (src/infer.cpp:1265-1317,
+// 810-932) as a short chain of fused HIP launches on one stream, captured into a hipGraph.
+//
+// Per block (single GPU; K-quants shown, the F8/F16/F32 path has the same shape):
+//   1. gemv  wq_a || wkv_a            prologue: rmsnorm(x, attn_norm) -> Q8_K        (infer.cpp:823,943,954)
+//   2. gemv  wq_b || wkv_b            prologue: rmsnorm(q_a) / rmsnorm(kv_a[:lora]) -> Q8_K   (:946,974,950,977)
+//   3. rope + KV-cache write + sinks                                                  (:956-1020)
+//   4. attention (per head)                                                           (:1022-1045)
+//   5. Q8_K of the attention output
+//   6. gemv  wo, epilogue x += .                                                      (:1048, 832-834)
+//   7. router GEMV + moe_gate         prologue: rmsnorm(x, ffn_norm); gate in the last workgroup (:839,847-852)
+//   8. gemv  experts w1/w3 (k slots) || shared w1/w3, SiLU-GLU epilogue               (:857-872, 882-897)
+//   9. gemv  experts w2 + shared w2, accumulate x += w_k * . in k order, then shared  (:873-878, 899-903)
+// Routing decisions never leave HBM (the reference reads them on the host, :854).
+#include "engine.h"
+
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+
+static int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------------
+// per-kernel-class timing (dsk_profile_forward)
+// ---------------------------------------------------------------------------------
+struct Prof {
+  dsk_model* m;
+  int idx = -1;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+};
+static int prof_begin(dsk_model* m, const char* name, double bytes, Prof* p) {
+  p->m = m;
+  if (!m->profiling) return DSK_OK;
+  auto it = m->kindex.find(name);
+  if (it == m->kindex.end()) {
+    m->kindex[name] = (int)m->ktimes.size();
+    KTime k;
+    k.name = name;
+    m->ktimes.push_back(k);
+    it = m->kindex.find(name);
+  }
+  p->idx = it->second;
+  KTime& k = m->ktimes[p->idx];
+  k.launches++;
+  k.algo_bytes += bytes;
+  HIP_TRY(hipEventCreate(&p->e0));
+  HIP_TRY(hipEventCreate(&p->e1));
+  HIP_TRY(hipEventRecord(p->e0, m->ctx->stream));
+  return DSK_OK;
+}
+static int prof_end(Prof* p) {
+  if (!p->m->profiling) return DSK_OK;
+  HIP_TRY(hipEventRecord(p->e1, p->m->ctx->stream));
+  p->m->ktimes[p->idx].ev.push_back({p->e0, p->e1});
+  return DSK_OK;
+}
+#define PROFILED(name, bytes, call)                     \
+  do {                                                  \
+    Prof _p;                                            \
+    DSK_TRY(prof_begin(m, name, (double)(bytes), &_p)); \
+    DSK_TRY(call);                                      \
+    DSK_TRY(prof_end(&_p));                             \
+  } while (0)
+
+// ---------------------------------------------------------------------------------
+// launch descriptors
+// ---------------------------------------------------------------------------------
+static double weight_bytes_2d(const dsk_model* m, int quant, int rows, int n) {
+  double b = (double)mat_bytes(quant, rows, n);
+  if (quant == DSK_QUANT_F8E5M2) b += 4.0 * cdiv(rows, m->c.block_size[0]) * cdiv(n, m->c.block_size[1]);
+  return b;
+}
+// activation + output bytes of one GEMV (SURVEY 8d per-GEMV unit: (n/256)*292 + 4*d for K-quants)
+static double io_bytes(int quant, int n, int rows) { return (is_kq(quant) ? (double)n / 256 * 292 : (double)n * 4) + 4.0 * rows; }
+
+static void task_weights(GemvTask& T, const DTensor& t) {
+  T.qs = t.qs; T.sc = t.sc; T.hm = t.hm; T.dm = t.dm; T.scale = t.scale;
+  T.rows = t.rows; T.n = t.n;
+  T.local_experts = 1;
+}
+static void task_weights2(GemvTask& T, const DTensor& t3) {
+  T.qs2 = t3.qs; T.sc2 = t3.sc; T.hm2 = t3.hm; T.dm2 = t3.dm; T.scale2 = t3.scale;
+}
+static void task_expert(GemvTask& T, const DTensor& t, const int* ids, int slot) {
+  T.e_qs = t.e_qs; T.e_sc = t.e_sc; T.e_hm = t.e_hm; T.e_dm = t.e_dm; T.e_scale = t.e_scale;
+  T.expert_ids = ids; T.slot = slot; T.expert_base = t.expert_base; T.local_experts = t.local_experts;
+}
+static void task_act_norm(GemvTask& T, const float* x, const DTensor& norm, float eps) {
+  T.act_mode = ACT_F32_NORM; T.a_f32 = x; T.norm_w = reinterpret_cast<const float*>(norm.qs); T.eps = eps;
+}
+static void task_act_f32(GemvTask& T, const float* x) { T.act_mode = ACT_F32; T.a_f32 = x; }
+// hidden vector produced by a GLU launch that also recorded its per-256-block maxima (K-quants)
+static void task_act_hb(const dsk_model* m, GemvTask& T, int layer, size_t off) {
+  T.a_f32 = m->hb + off;
+  if (is_kq(m->c.weight_quant)) { T.act_mode = ACT_F32_BMAX; T.a_bmax = m->bmax + (size_t)layer * m->bmax_per_layer + off / 256; }
+  else T.act_mode = ACT_F32;
+}
+static void task_out_hb(const dsk_model* m, GemvTask& T, int layer, size_t off) {
+  T.out = m->hb + off;
+  if (is_kq(m->c.weight_quant)) T.bmax_out = m->bmax + (size_t)layer * m->bmax_per_layer + off / 256;
+}
+static void task_act_q8(GemvTask& T, const Q8Buf& q) { T.act_mode = ACT_Q8; T.a_qs = q.qs; T.a_d = q.d; T.a_bsums = q.bsums; }
+
+static int add_plan(dsk_model* m, GemvLaunch& h, int* idx_out) {
+  h.b0 = std::max(1, m->c.block_size[0]);
+  h.b1 = std::max(1, m->c.block_size[1]);
+  h.act = m->c.act;
+  DSK_TRY(gemv_plan(h, m->target_wgs));
+  *idx_out = (int)m->plans.size();
+  m->plans.push_back(h);
+  return DSK_OK;
+}
+
+int build_plans(dsk_model* m) {
+  const dsk_config& c = m->c;
+  const int nl = c.n_layers, H = c.n_heads, K = c.n_active_routed, mi = c.moe_intermediate_size;
+  const int wq = c.weight_quant;
+  const bool kq = is_kq(wq);
+  const int shared_n = c.n_shared_experts * mi;
+  const int hb_stride = std::max(std::max(mi, shared_n), 1);
+  m->lp_qkv_a.assign(nl, -1); m->lp_qkv_b.assign(nl, -1); m->lp_wv_b.assign(nl, -1); m->lp_wo.assign(nl, -1);
+  m->lp_w13.assign(nl, -1); m->lp_w2.assign(nl, -1); m->lp_w2_shared.assign(nl, -1);
+  m->plans.clear();
+  for (int l = 0; l < nl; ++l) {
+    Layer& L = m->L[l];
+    {  // 1. wq_a (or wq) || wkv_a on rmsnorm(x, attn_norm)
+      GemvLaunch h;
+      memset(&h, 0, sizeof h);
+      h.quant = wq; h.mode = GEMV_MODE_TASKS;
+      GemvTask& a = h.t[h.n_tasks++];
+      const DTensor& tq = c.q_lora_rank > 0 ? L.t[DSK_ROLE_WQ_A] : L.t[DSK_ROLE_WQ];
+      task_weights(a, tq);
+      task_act_norm(a, m->x, L.t[DSK_ROLE_ATTN_NORM], c.norm_eps);
+      a.out = c.q_lora_rank > 0 ? m->q_a : m->q;
+      GemvTask& b = h.t[h.n_tasks++];
+      task_weights(b, L.t[DSK_ROLE_WKV_A]);
+      task_act_norm(b, m->x, L.t[DSK_ROLE_ATTN_NORM], c.norm_eps);
+      b.out = m->kv_a;
+      h.algo_bytes = weight_bytes_2d(m, wq, a.rows, a.n) + weight_bytes_2d(m, wq, b.rows, b.n) + c.dim * 8.0 + 4.0 * (a.rows + b.rows);
+      DSK_TRY(add_plan(m, h, &m->lp_qkv_a[l]));
+    }
+    {  // 2. second-stage projections on the normed latents
+      GemvLaunch h;
+      memset(&h, 0, sizeof h);
+      h.quant = wq; h.mode = GEMV_MODE_TASKS;
+      double bytes = 0;
+      auto add = [&](const DTensor& t, const float* x, const DTensor& norm, float* out) {
+        GemvTask& T = h.t[h.n_tasks++];
+        task_weights(T, t);
+        task_act_norm(T, x, norm, c.norm_eps);
+        T.out = out;
+        bytes += weight_bytes_2d(m, wq, t.rows, t.n) + t.n * 8.0 + 4.0 * t.rows;
+      };
+      if (c.use_mla) {
+        add(L.t[DSK_ROLE_WQ_ROPE_B], m->q_a, L.t[DSK_ROLE_Q_A_NORM], m->q_rope);
+        add(L.t[DSK_ROLE_WC], m->q_a, L.t[DSK_ROLE_Q_A_NORM], m->q_c);
+      } else {
+        if (c.q_lora_rank > 0) add(L.t[DSK_ROLE_WQ_B], m->q_a, L.t[DSK_ROLE_Q_A_NORM], m->q);
+        add(L.t[DSK_ROLE_WKV_B], m->kv_a, L.t[DSK_ROLE_KV_A_NORM], m->kv_b);
+      }
+      h.algo_bytes = bytes;
+      DSK_TRY(add_plan(m, h, &m->lp_qkv_b[l]));
+    }
+    if (c.use_mla) {  // per-head wv_b on the per-head latent outputs (src/infer.cpp:1134-1137): block-diagonal
+      GemvLaunch h;
+      memset(&h, 0, sizeof h);
+      h.quant = wq; h.mode = GEMV_MODE_TASKS;
+      h.bd_heads = H;
+      GemvTask& T = h.t[h.n_tasks++];
+      task_weights(T, L.t[DSK_ROLE_WV_B]);
+      T.rows = c.v_head_dim; T.n = c.kv_lora_rank;
+      task_act_f32(T, m->att_out);
+      T.out = m->vb_out;
+      h.algo_bytes = weight_bytes_2d(m, wq, H * c.v_head_dim, c.kv_lora_rank) + 4.0 * H * (c.kv_lora_rank + c.v_head_dim);
+      DSK_TRY(add_plan(m, h, &m->lp_wv_b[l]));
+    }
+    {  // 6. wo, x += .
+      GemvLaunch h;
+      memset(&h, 0, sizeof h);
+      h.quant = wq; h.mode = GEMV_MODE_TASKS;
+      GemvTask& T = h.t[h.n_tasks++];
+      task_weights(T, L.t[DSK_ROLE_WO]);
+      const float* src = c.use_mla ? m->vb_out : m->att_out;
+      if (kq) task_act_q8(T, m->a_att);
+      else task_act_f32(T, src);
+      T.out = m->x; T.epilogue = EPI_ADD;
+      h.algo_bytes = weight_bytes_2d(m, wq, T.rows, T.n) + io_bytes(wq, T.n, T.rows) + 4.0 * T.rows;
+      DSK_TRY(add_plan(m, h, &m->lp_wo[l]));
+    }
+    if (!L.is_moe) {
+      {  // dense w1/w3 GLU on rmsnorm(x, ffn_norm)
+        GemvLaunch h;
+        memset(&h, 0, sizeof h);
+        h.quant = wq; h.mode = GEMV_MODE_TASKS; h.glu = 1;
+        GemvTask& T = h.t[h.n_tasks++];
+        task_weights(T, L.t[DSK_ROLE_W1]);
+        task_weights2(T, L.t[DSK_ROLE_W3]);
+        task_act_norm(T, m->x, L.t[DSK_ROLE_FFN_NORM], c.norm_eps);
+        task_out_hb(m, T, l, 0);
+        h.algo_bytes = 2 * weight_bytes_2d(m, wq, T.rows, T.n) + c.dim * 8.0 + 4.0 * T.rows;
+        DSK_TRY(add_plan(m, h, &m->lp_w13[l]));
+      }
+      {  // dense w2, x += .
+        GemvLaunch h;
+        memset(&h, 0, sizeof h);
+        h.quant = wq; h.mode = GEMV_MODE_TASKS;
+        GemvTask& T = h.t[h.n_tasks++];
+        task_weights(T, L.t[DSK_ROLE_W2]);
+        task_act_hb(m, T, l, 0);
+        T.out = m->x; T.epilogue = EPI_ADD;
+        h.algo_bytes = weight_bytes_2d(m, wq, T.rows, T.n) + 4.0 * T.n + 8.0 * T.rows;
+        DSK_TRY(add_plan(m, h, &m->lp_w2[l]));
+      }
+      continue;
+    }
+    if (K + 1 > GEMV_MAX_TASKS) DSK_FAIL(DSK_ERR_UNSUPPORTED, "n_active_routed %d > %d", K, GEMV_MAX_TASKS - 1);
+    const int* ae = m->route_e + (size_t)l * K;
+    const float* aw = m->route_w + (size_t)l * K;
+    const DTensor &w1 = L.t[DSK_ROLE_W1], &w2 = L.t[DSK_ROLE_W2], &w3 = L.t[DSK_ROLE_W3];
+    const double e13 = 2 * weight_bytes_2d(m, wq, mi, c.dim), e2 = weight_bytes_2d(m, wq, c.dim, mi);
+    {  // 8. routed w1/w3 (k slots) || shared w1/w3, GLU
+      GemvLaunch h;
+      memset(&h, 0, sizeof h);
+      h.quant = wq; h.mode = GEMV_MODE_TASKS; h.glu = 1;
+      for (int k = 0; k < K; ++k) {
+        GemvTask& T = h.t[h.n_tasks++];
+        task_weights(T, w1);
+        task_weights2(T, w3);
+        task_expert(T, w1, ae, k);
+        task_act_norm(T, m->x, L.t[DSK_ROLE_FFN_NORM], c.norm_eps);
+        task_out_hb(m, T, l, (size_t)k * hb_stride);
+      }
+      double bytes = K * e13 + c.dim * 8.0 + 4.0 * K * mi;
+      if (c.n_shared_experts > 0) {
+        GemvTask& T = h.t[h.n_tasks++];
+        task_weights(T, L.t[DSK_ROLE_SHARED_W1]);
+        task_weights2(T, L.t[DSK_ROLE_SHARED_W3]);
+        task_act_norm(T, m->x, L.t[DSK_ROLE_FFN_NORM], c.norm_eps);
+        task_out_hb(m, T, l, (size_t)K * hb_stride);
+        bytes += 2 * weight_bytes_2d(m, wq, shared_n, c.dim) + 4.0 * shared_n;
+      }
+      h.algo_bytes = bytes;
+      DSK_TRY(add_plan(m, h, &m->lp_w13[l]));
+    }
+    if (m->ctx->world == 1) {  // 9. accumulate: x += w_k * W2_k h_k (k order), then shared
+      GemvLaunch h;
+      memset(&h, 0, sizeof h);
+      h.quant = wq; h.mode = GEMV_MODE_ACCUM;
+      for (int k = 0; k < K; ++k) {
+        GemvTask& T = h.t[h.n_tasks++];
+        task_weights(T, w2);
+        task_expert(T, w2, ae, k);
+        task_act_hb(m, T, l, (size_t)k * hb_stride);
+        T.out = m->x; T.accum_w = aw + k;
+      }
+      double bytes = K * (e2 + 4.0 * mi) + 8.0 * c.dim;
+      if (c.n_shared_experts > 0) {
+        GemvTask& T = h.t[h.n_tasks++];
+        task_weights(T, L.t[DSK_ROLE_SHARED_W2]);
+        task_act_hb(m, T, l, (size_t)K * hb_stride);
+        T.out = m->x; T.accum_w = nullptr;
+        bytes += weight_bytes_2d(m, wq, c.dim, shared_n) + 4.0 * shared_n;
+      }
+      h.algo_bytes = bytes;
+      DSK_TRY(add_plan(m, h, &m->lp_w2[l]));
+    } else {  // expert-sharded: per-slot outputs -> all-reduce -> combine (bit-identical to 1 GPU)
+      GemvLaunch h;
+      memset(&h, 0, sizeof h);
+      h.quant = wq; h.mode = GEMV_MODE_TASKS;
+      for (int k = 0; k < K; ++k) {
+        GemvTask& T = h.t[h.n_tasks++];
+        task_weights(T, w2);
+        task_expert(T, w2, ae, k);
+        task_act_hb(m, T, l, (size_t)k * hb_stride);
+        T.out = m->eout + (size_t)k * c.dim; T.epilogue = EPI_STORE;
+      }
+      double bytes = K * (e2 + 4.0 * mi + 4.0 * c.dim);
+      if (c.n_shared_experts > 0) {
+        GemvTask& T = h.t[h.n_tasks++];
+        task_weights(T, L.t[DSK_ROLE_SHARED_W2]);
+        task_act_hb(m, T, l, (size_t)K * hb_stride);
+        T.out = m->eout + (size_t)K * c.dim; T.epilogue = EPI_STORE;
+        bytes += weight_bytes_2d(m, wq, c.dim, shared_n) + 4.0 * shared_n + 4.0 * c.dim;
+      }
+      h.algo_bytes = bytes;
+      DSK_TRY(add_plan(m, h, &m->lp_w2[l]));
+    }
+  }
+  {  // classifier on rmsnorm(x, final_norm) (src/infer.cpp:1292-1316)
+    GemvLaunch h;
+    memset(&h, 0, sizeof h);
+    h.quant = wq; h.mode = GEMV_MODE_TASKS;
+    GemvTask& T = h.t[h.n_tasks++];
+    const DTensor& cls = m->tied ? m->g[DSK_ROLE_EMBED] : m->g[DSK_ROLE_OUTPUT];
+    task_weights(T, cls);
+    task_act_norm(T, m->x, m->g[DSK_ROLE_FINAL_NORM], c.norm_eps);
+    T.out = m->logits;
+    h.algo_bytes = weight_bytes_2d(m, wq, T.rows, T.n) + c.dim * 8.0 + 4.0 * T.rows;
+    DSK_TRY(add_plan(m, h, &m->lp_head));
+  }
+  (void)H;
+  HIP_TRY(hipMalloc((void**)&m->plans_dev, m->plans.size() * sizeof(GemvLaunch)));
+  HIP_TRY(hipMemcpy(m->plans_dev, m->plans.data(), m->plans.size() * sizeof(GemvLaunch), hipMemcpyHostToDevice));
+  m->scratch_bytes += (double)m->plans.size() * sizeof(GemvLaunch);
+  return DSK_OK;
+}
+
+void free_plans(dsk_model* m) {
+  if (m->plans_dev) hipFree(m->plans_dev);
+  m->plans_dev = nullptr;
+}
+
+static int run_plan(dsk_model* m, const char* name, int idx) {
+  if (idx < 0) DSK_FAIL(DSK_ERR_STATE, "missing launch plan for %s", name);
+  PROFILED(name, m->plans[idx].algo_bytes, gemv_launch(m->ctx->stream, m->plans_dev + idx, m->plans[idx]));
+  return DSK_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// one token
+// ---------------------------------------------------------------------------------
+static int fill_step_params(dsk_model* m, int token, int pos) {
+  const dsk_config& c = m->c;
+  StepParams* sp = m->sp_host;
+  const int W = c.rs_original_max_position_embeddings;
+  sp->token = token;
+  sp->pos = pos;
+  sp->kv_sink = pos >= W ? 2 : 0;  // KV_SINKS, src/model.h:14; ring arithmetic src/infer.cpp:1274-1277
+  sp->kv_pos = sp->kv_sink + (pos - sp->kv_sink) % (W - sp->kv_sink);
+  sp->kv_len = pos >= W ? W : pos + 1;
+  if (sp->kv_pos >= c.max_seq_len || sp->kv_len > c.max_seq_len)
+    DSK_FAIL(DSK_ERR_INVALID, "forward: pos %d exceeds the max_seq_len=%d allocation (the reference overruns its cache here)", pos, c.max_seq_len);
+  const int rd = c.qk_rope_head_dim;
+  for (int j = 0; j < rd / 2; ++j) {  // same libm calls as src/infer.cpp:655-658
+    // 1/powf(theta, j/d) as the reference's -ffast-math build evaluates it (see oracle/dsk_oracle.c ref_rope_freq)
+    const float freq = powf(c.rope_theta, -((float)(2 * j) * (1.0f / (float)rd)));
+    const float v = pos * freq, v1 = 1 * freq;
+    sp->rope_cs[2 * j] = cosf(v);
+    sp->rope_cs[2 * j + 1] = sinf(v);
+    sp->rope_cs1[2 * j] = cosf(v1);
+    sp->rope_cs1[2 * j + 1] = sinf(v1);
+  }
+  return DSK_OK;
+}
+
+static int run_quant(dsk_model* m, const float* x, int n, Q8Buf& q8) {
+  if (!is_kq(m->c.weight_quant)) return DSK_OK;
+  PROFILED("quantize_q8k", (double)n * 5.2, launch_quantize_q8k(m->ctx->stream, x, n, q8.qs, q8.d, q8.bsums));
+  return DSK_OK;
+}
+
+static int attention_mha(dsk_model* m, int l, int max_kv) {
+  const dsk_config& c = m->c;
+  Layer& L = m->L[l];
+  hipStream_t st = m->ctx->stream;
+  const int H = c.n_heads, hd = m->head_dim;
+  DSK_TRY(run_plan(m, "gemv_qkv_a", m->lp_qkv_a[l]));
+  DSK_TRY(run_plan(m, "gemv_qkv_b", m->lp_qkv_b[l]));
+  AttnMhaArgs a;
+  a.q = m->q; a.kv_b = m->kv_b; a.kv_a = m->kv_a; a.key_cache = L.key_cache; a.value_cache = L.value_cache; a.out = m->att_out;
+  a.n_heads = H; a.head_dim = hd; a.nope = c.qk_nope_head_dim; a.rope = c.qk_rope_head_dim; a.v_dim = c.v_head_dim;
+  a.lora = c.kv_lora_rank; a.is_v3 = c.has_moegate_bias;
+  PROFILED("rope_kv", (double)H * (hd * 6 + c.v_head_dim * 6), launch_rope_kv_mha(st, a, m->sp_dev));
+  PROFILED("attn_mha", (double)m->sp_host->kv_len * H * (hd + c.v_head_dim) * 2, launch_attn_mha(st, a, m->sp_dev, 0, max_kv));
+  DSK_TRY(run_quant(m, m->att_out, H * c.v_head_dim, m->a_att));
+  DSK_TRY(run_plan(m, "gemv_wo", m->lp_wo[l]));  // residual: src/infer.cpp:832-834
+  return DSK_OK;
+}
+
+static int attention_mla(dsk_model* m, int l, int max_kv) {
+  const dsk_config& c = m->c;
+  Layer& L = m->L[l];
+  hipStream_t st = m->ctx->stream;
+  const int H = c.n_heads;
+  DSK_TRY(run_plan(m, "gemv_qkv_a", m->lp_qkv_a[l]));
+  {  // rmsnorm of the latent (src/infer.cpp:1089); the rope part of kv_a stays raw for rope_kv
+    NormJob j;
+    memset(&j, 0, sizeof j);
+    j.x = m->kv_a; j.weight = reinterpret_cast<const float*>(L.t[DSK_ROLE_KV_A_NORM].qs); j.n = c.kv_lora_rank; j.eps = c.norm_eps;
+    j.y_f32 = m->kv_a;
+    PROFILED("norm_latent", (double)c.kv_lora_rank * 12, launch_norm_jobs(st, &j, 1, m->sp_dev));
+  }
+  DSK_TRY(run_plan(m, "gemv_qkv_b", m->lp_qkv_b[l]));
+  AttnMlaArgs a;
+  a.q_rope = m->q_rope; a.q_c = m->q_c; a.kv_a = m->kv_a; a.nope_cache = L.nope_cache; a.rope_cache = L.rope_cache; a.out = m->att_out;
+  a.n_heads = H; a.head_dim = m->head_dim; a.rope = c.qk_rope_head_dim; a.lora = c.kv_lora_rank; a.is_v3 = c.has_moegate_bias;
+  PROFILED("rope_kv", (double)H * c.qk_rope_head_dim * 8 + c.kv_lora_rank * 6, launch_rope_kv_mla(st, a, m->sp_dev));
+  PROFILED("attn_mla", (double)m->sp_host->kv_len * (c.kv_lora_rank + c.qk_rope_head_dim) * 2, launch_attn_mla(st, a, m->sp_dev, 0, max_kv));
+  DSK_TRY(run_plan(m, "gemv_wv_b", m->lp_wv_b[l]));  // per-head wv_b (src/infer.cpp:1134-1137)
+  DSK_TRY(run_quant(m, m->vb_out, H * c.v_head_dim, m->a_att));
+  DSK_TRY(run_plan(m, "gemv_wo", m->lp_wo[l]));
+  return DSK_OK;
+}
+
+// MoE / dense FFN of one block (src/infer.cpp:844-931)
+static int ffn(dsk_model* m, int l) {
+  const dsk_config& c = m->c;
+  Layer& L = m->L[l];
+  hipStream_t st = m->ctx->stream;
+  if (!L.is_moe) {
+    DSK_TRY(run_plan(m, "gemv_dense_w13", m->lp_w13[l]));
+    DSK_TRY(run_plan(m, "gemv_dense_w2", m->lp_w2[l]));
+    return DSK_OK;
+  }
+  const int K = c.n_active_routed, E = c.n_routed_experts;
+  RouterArgs r;
+  memset(&r, 0, sizeof r);
+  r.w = reinterpret_cast<const float*>(L.t[DSK_ROLE_MOEGATE].qs);
+  r.x = m->x;
+  r.norm_w = reinterpret_cast<const float*>(L.t[DSK_ROLE_FFN_NORM].qs);
+  r.eps = c.norm_eps;
+  r.n_routed = E; r.dim = c.dim; r.ksplit = m->router_ksplit;
+  r.partial = m->router_partial; r.counter = m->router_counter;
+  r.bias = L.t[DSK_ROLE_MOEGATE_BIAS].bound() ? reinterpret_cast<const float*>(L.t[DSK_ROLE_MOEGATE_BIAS].qs) : nullptr;
+  r.n_active = K; r.norm_topk_prob = c.norm_topk_prob; r.scoring = c.scoring_func; r.topk_method = c.topk_method;
+  r.n_group = c.n_group; r.topk_group = c.topk_group; r.scaling = c.routed_scaling_factor;
+  r.active_experts = m->route_e + (size_t)l * K;
+  r.active_weights = m->route_w + (size_t)l * K;
+  r.scores_out = m->gate_scores + (size_t)l * E;
+  PROFILED("router_gate", (double)E * c.dim * 4 + c.dim * 8.0, launch_router_gate(st, r));
+  if (m->ctx->world > 1) HIP_TRY(hipMemsetAsync(m->eout, 0, (size_t)K * c.dim * 4, st));
+  DSK_TRY(run_plan(m, "gemv_experts_w13", m->lp_w13[l]));
+  DSK_TRY(run_plan(m, "gemv_experts_w2", m->lp_w2[l]));
+  if (m->ctx->world > 1) {
+    // every routed slot is non-zero on exactly one rank: a sum all-reduce is exact and order-independent
+    ncclResult_t rr = ncclAllReduce(m->eout, m->eout, (size_t)K * c.dim, ncclFloat, ncclSum, m->ctx->comm, st);
+    if (rr != ncclSuccess) DSK_FAIL(DSK_ERR_COMM, "ncclAllReduce: %s", ncclGetErrorString(rr));
+    NormJob j;  // combine in k order, then the shared expert (src/infer.cpp:874-877, 900-903)
+    memset(&j, 0, sizeof j);
+    j.x = m->x; j.n = c.dim; j.eps = c.norm_eps;
+    j.eout = m->eout; j.eweights = m->route_w + (size_t)l * K; j.n_routed_slots = K;
+    j.add_shared = c.n_shared_experts > 0; j.x_store = m->x;
+    PROFILED("moe_combine", (double)c.dim * (K + 3) * 4, launch_norm_jobs(st, &j, 1, m->sp_dev));
+  }
+  return DSK_OK;
+}
+
+// enqueue one whole token on the stream (no host synchronisation inside)
+static int enqueue_forward(dsk_model* m, int mode, int max_kv) {
+  const dsk_config& c = m->c;
+  hipStream_t st = m->ctx->stream;
+  HIP_TRY(hipMemcpyAsync(m->sp_dev, m->sp_host, sizeof(StepParams), hipMemcpyHostToDevice, st));
+  if (m->bmax) HIP_TRY(hipMemsetAsync(m->bmax, 0, (size_t)c.n_layers * m->bmax_per_layer * 8, st));
+  PROFILED("embed", (double)mat_bytes(c.weight_quant, 1, c.dim), launch_embed(st, m->g[DSK_ROLE_EMBED], m->sp_dev, -1, std::max(1, c.block_size[0]),
+                                                                              std::max(1, c.block_size[1]), m->x));
+  for (int l = 0; l < c.n_layers; ++l) {
+    if (c.use_mla) DSK_TRY(attention_mla(m, l, max_kv));
+    else DSK_TRY(attention_mha(m, l, max_kv));
+    DSK_TRY(ffn(m, l));
+    if (m->trace) HIP_TRY(hipMemcpyAsync(m->trace_x + (size_t)l * c.dim, m->x, (size_t)c.dim * 4, hipMemcpyDeviceToDevice, st));
+  }
+  if (mode == DSK_MODE_HYDRATE_KV_CACHE) return DSK_OK;  // src/infer.cpp:1284-1287
+  DSK_TRY(run_plan(m, "gemv_lm_head", m->lp_head));
+  HIP_TRY(hipMemcpyAsync(m->logits_host, m->logits, (size_t)c.vocab_size * 4, hipMemcpyDeviceToHost, st));
+  return DSK_OK;
+}
+
+static int check_forward_args(dsk_model* m, int token, int pos, int mode, float* host_logits) {
+  if (!m) DSK_FAIL(DSK_ERR_INVALID, "forward: null model");
+  if (!m->finalized) DSK_FAIL(DSK_ERR_STATE, "forward before finalize");
+  if (token < 0 || token >= m->c.vocab_size) DSK_FAIL(DSK_ERR_INVALID, "forward: token %d out of range", token);
+  if (pos < 0) DSK_FAIL(DSK_ERR_INVALID, "forward: negative pos");
+  if (mode != DSK_MODE_HYDRATE_KV_CACHE && mode != DSK_MODE_OUTPUT_LOGITS) DSK_FAIL(DSK_ERR_INVALID, "forward: bad mode %d", mode);
+  if (mode == DSK_MODE_OUTPUT_LOGITS && !host_logits) DSK_FAIL(DSK_ERR_INVALID, "forward: OUTPUT_LOGITS needs a logits buffer");
+  return DSK_OK;
+}
+
+extern "C" int dsk_forward(dsk_model* m, int token, int pos, int mode, float* host_logits) {
+  DSK_TRY(check_forward_args(m, token, pos, mode, host_logits));
+  HIP_TRY(hipSetDevice(m->ctx->device));
+  hipStream_t st = m->ctx->stream;
+  DSK_TRY(fill_step_params(m, token, pos));
+  const int max_kv = m->c.max_seq_len;  // LDS for attention scores is sized for the allocation: graph-replay safe
+  const bool graphable = m->use_graph && !m->trace && !m->profiling;
+  if (graphable) {
+    const int gi = mode == DSK_MODE_OUTPUT_LOGITS ? 1 : 0;
+    if (!m->graph[gi]) {
+      hipGraph_t g = nullptr;
+      HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      int r = enqueue_forward(m, mode, max_kv);
+      hipError_t e = hipStreamEndCapture(st, &g);
+      if (r != DSK_OK) {
+        if (g) hipGraphDestroy(g);
+        return r;
+      }
+      if (e != hipSuccess) DSK_FAIL(DSK_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+      HIP_TRY(hipGraphInstantiate(&m->graph[gi], g, nullptr, nullptr, 0));
+      HIP_TRY(hipGraphDestroy(g));
+    }
+    HIP_TRY(hipGraphLaunch(m->graph[gi], st));
+  } else {
+    DSK_TRY(enqueue_forward(m, mode, max_kv));
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipGetLastError());
+  if (mode == DSK_MODE_OUTPUT_LOGITS) memcpy(host_logits, m->logits_host, (size_t)m->c.vocab_size * 4);
+  return DSK_OK;
+}
+
+extern "C" int dsk_model_set_graph(dsk_model* m, int enable) {
+  if (!m) DSK_FAIL(DSK_ERR_INVALID, "null model");
+  m->use_graph = enable != 0;
+  return DSK_OK;
+}
+extern "C" int dsk_model_set_trace(dsk_model* m, int enable) {
+  if (!m) DSK_FAIL(DSK_ERR_INVALID, "null model");
+  m->trace = enable != 0;
+  return DSK_OK;
+}
+extern "C" int dsk_model_get_trace_x(dsk_model* m, int layer, float* x_out) {
+  if (!m || !m->finalized || layer < 0 || layer >= m->c.n_layers || !x_out) DSK_FAIL(DSK_ERR_INVALID, "get_trace_x: bad argument");
+  HIP_TRY(hipSetDevice(m->ctx->device));
+  HIP_TRY(hipMemcpy(x_out, m->trace_x + (size_t)layer * m->c.dim, (size_t)m->c.dim * 4, hipMemcpyDeviceToHost));
+  return DSK_OK;
+}
+extern "C" int dsk_model_get_routing(dsk_model* m, int32_t* experts, float* weights) {
+  if (!m || !m->finalized || !experts || !weights) DSK_FAIL(DSK_ERR_INVALID, "get_routing: bad argument");
+  HIP_TRY(hipSetDevice(m->ctx->device));
+  const int K = std::max(1, m->c.n_active_routed);
+  const size_t n = (size_t)m->c.n_layers * K;
+  HIP_TRY(hipMemcpy(experts, m->route_e, n * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(weights, m->route_w, n * 4, hipMemcpyDeviceToHost));
+  for (int l = 0; l < m->c.n_layers; ++l)
+    if (!m->L[l].is_moe)
+      for (int k = 0; k < K; ++k) { experts[(size_t)l * K + k] = -1; weights[(size_t)l * K + k] = 0.f; }
+  return DSK_OK;
+}
+
+extern "C" int dsk_profile_forward(dsk_model* m, int token, int pos, dsk_kernel_time* out, int max_classes, int* n_classes) {
+  DSK_TRY(check_forward_args(m, token, pos, DSK_MODE_OUTPUT_LOGITS, m ? m->logits_host : nullptr));
+  if (!out || !n_classes) DSK_FAIL(DSK_ERR_INVALID, "profile_forward: null output");
+  HIP_TRY(hipSetDevice(m->ctx->device));
+  DSK_TRY(fill_step_params(m, token, pos));
+  for (auto& k : m->ktimes) { k.launches = 0; k.algo_bytes = 0; }
+  m->profiling = true;
+  int r = enqueue_forward(m, DSK_MODE_OUTPUT_LOGITS, m->c.max_seq_len);
+  m->profiling = false;
+  if (r != DSK_OK) return r;
+  HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+  int n = 0;
+  for (auto& k : m->ktimes) {
+    float total = 0.f;
+    for (auto& e : k.ev) {
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, e.first, e.second));
+      total += ms;
+      hipEventDestroy(e.first);
+      hipEventDestroy(e.second);
+    }
+    k.ev.clear();
+    if (k.launches == 0) continue;
+    if (n < max_classes) {
+      out[n].name = k.name;
+      out[n].launches = k.launches;
+      out[n].total_ms = total;
+      out[n].algo_bytes = k.algo_bytes;
+      ++n;
+    }
+  }
+  *n_classes = n;
+  return DSK_OK;
+}

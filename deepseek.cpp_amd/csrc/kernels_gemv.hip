@@ -3,24 +3,33 @@
 // Replaces the reference's five _matmul overloads and matmul_expert
 // (src/infer.cpp:121-379, 423-469) and the vec_dot kernels (src/quant.cpp:434-614, 666-783).
 //
-// K-quants are W2A8 / W3A8 exactly like the reference: activations arrive as Q8_K
+// K-quants are W2A8 / W3A8 exactly like the reference: activations are Q8_K
 // (int8 + per-256 scale + per-16 sums, src/quant.cpp:616-653), the sub-block dot products
 // are integer (v_dot4_i32_i8) and only the per-super-block scaling is float.
 //
-// Work decomposition (HBM-bound, no MFMA -- one token, so there is no N dimension):
-//   * the unit of work ("item") is 16 contiguous bytes of the qs plane = 64 weights
-//     (a quarter of a super-block): one global_load_dwordx4 per lane, adjacent lanes read
-//     adjacent 16 B, so every load instruction covers whole 128-B lines;
-//   * LPR lanes cooperate on one row (LPR = largest power of two dividing the row's item
-//     count), a wave works on 64/LPR rows at a time and on R such row groups back to back
-//     with the Q8 activations of the current column item held in registers;
-//   * the Q8 activation vector is staged once per workgroup in LDS (n + 36*n/256 bytes);
-//   * partial sums are combined with wave shuffles; no atomics, fixed order => deterministic.
+// Structure (HBM-bound, no MFMA -- one token, so there is no N dimension):
+//   * one launch = up to GEMV_MAX_TASKS "tasks" (matrix x vector jobs: e.g. wq_a || wkv_a, or the
+//     8 routed expert slots + the shared expert), each owning a contiguous range of workgroups;
+//   * workgroups are persistent: the grid is sized to the machine and every workgroup walks
+//     its task's row groups with a grid stride, so the per-workgroup prologue is amortised;
+//   * prologue = stage the activation vector in LDS once: copy a ready Q8_K vector, or quantise
+//     an f32 vector, or RMSNorm (src/infer.cpp:601-611) + quantise -- this fuses the reference's
+//     rmsnorm() and quantize_row_q8_K_ref() calls into their consumer;
+//   * the unit of work ("item") is 16 contiguous bytes of the qs plane = 64 weights: one
+//     global_load_dwordx4 per lane, adjacent lanes adjacent 16 B => whole 128-B lines;
+//     LPR lanes cooperate on one row, a wave holds 64/LPR rows x R row groups, and U column
+//     steps are issued back to back so every lane keeps R*U 16-byte loads in flight;
+//   * epilogues: store, residual add (src/infer.cpp:832-834), SiLU/GELU-GLU pair
+//     (src/infer.cpp:859-872) and the MoE accumulate x += w_k * (W2_k . h_k) over the routed
+//     slots in k order, then the shared expert (src/infer.cpp:873-878, 899-903);
+//   * all reductions are fixed-order shuffles: no atomics, bit-reproducible run to run.
 #include "dsk_internal.h"
+#include <type_traits>
 
 typedef unsigned int u32;
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 #define DEV __device__ __forceinline__
@@ -111,156 +120,240 @@ DEV float q3k_item(u32x4 w, u32x4 hm, u32 s0, u32 s1, u32 s2, u32 d16, int h, in
 }
 
 // ------------------------------------------------------------------------------------
-// K-quant GEMV kernel
+// Q8_K quantisation of one 256-block by one wave (quantize_row_q8_K_ref, src/quant.cpp:616-653;
+// same arithmetic as kernels_misc.hip q8k_block) writing the LDS staging layout:
+// qs natural order, bsums in quarter order, d.
 // ------------------------------------------------------------------------------------
-template <int QT, int R, bool GLU>
-__global__ __launch_bounds__(256) void gemv_kq_kernel(GemvSeg sg, int lpr_log2) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const int LPR = 1 << lpr_log2, RPW = 64 >> lpr_log2;
-  const int tid = threadIdx.x;
-  const int slot = blockIdx.y;
-  const int n = sg.n, nb = n >> 8;
+// DPP lane exchanges (VALU speed; __shfl_xor lowers to ds_bpermute, ~100 cycles each)
+template <int CTRL>
+DEV u32 dpp_u32(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true); }
+template <int CTRL>
+DEV float dpp_f32(float v) { return u2f(dpp_u32<CTRL>(__builtin_bit_cast(u32, v))); }
+#define DPP_XOR1 0xB1        // quad_perm [1,0,3,2]
+#define DPP_XOR2 0x4E        // quad_perm [2,3,0,1]
+#define DPP_HALF_MIRROR 0x141
+#define DPP_MIRROR 0x140
+// max over the wave of a non-negative float's bit pattern, as a wave-uniform value
+DEV u32 wave_max_bits(u32 v) {
+  v = max(v, dpp_u32<DPP_XOR1>(v));
+  v = max(v, dpp_u32<DPP_XOR2>(v));
+  v = max(v, dpp_u32<DPP_HALF_MIRROR>(v));
+  v = max(v, dpp_u32<DPP_MIRROR>(v));  // every lane of a 16-lane row holds the row maximum
+  const u32 a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+  const u32 c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+  return max(max(a, b), max(c, d));
+}
 
-  // slot -> expert (on-device routing: the reference reads active_experts on the host,
-  // src/infer.cpp:854; here the ids never leave HBM)
-  int le = 0;
-  if (sg.e_qs != 0) {
-    const int e = sg.expert_ids ? sg.expert_ids[slot] : slot;
-    le = e - sg.expert_base;
-    if (le < 0 || le >= sg.local_experts) return;  // expert lives on another GPU
-  }
-  const uint8_t* QS = sg.qs + (size_t)le * sg.e_qs;
-  const uint8_t* SC = sg.sc + (size_t)le * sg.e_sc;
-  const uint8_t* DM = sg.dm + (size_t)le * sg.e_dm;
-  const uint8_t* HM = QT == DSK_QUANT_Q3_K ? sg.hm + (size_t)le * sg.e_hm : nullptr;
-  const uint8_t *QS2 = nullptr, *SC2 = nullptr, *DM2 = nullptr, *HM2 = nullptr;
-  if (GLU) {
-    QS2 = sg.qs2 + (size_t)le * sg.e_qs;
-    SC2 = sg.sc2 + (size_t)le * sg.e_sc;
-    DM2 = sg.dm2 + (size_t)le * sg.e_dm;
-    if (QT == DSK_QUANT_Q3_K) HM2 = sg.hm2 + (size_t)le * sg.e_hm;
-  }
+// 64-bit key whose maximum over a 256-block identifies "the first element with the largest |x|"
+// (src/quant.cpp:622-629): |x| bits | inverted index | sign.  Producers atomicMax it per block.
+DEV unsigned long long bmax_key(float x, int idx) {
+  const u32 bits = __builtin_bit_cast(u32, x);
+  return ((unsigned long long)(bits & 0x7fffffffu) << 32) | ((unsigned long long)(0x7fffffffu - (u32)idx) << 1) | (bits >> 31);
+}
+DEV float bmax_value(unsigned long long key) {  // signed value of the winning element
+  return u2f((u32)(key >> 32) | ((u32)(key & 1) << 31));
+}
 
-  // ---- stage the Q8 activation vector in LDS: qs | bsums (quarter order) | d ----
-  uint8_t* l_qs = smem;
-  short* l_bs = reinterpret_cast<short*>(smem + n);
-  float* l_d = reinterpret_cast<float*>(smem + n + nb * 32);
-  {
-    const size_t aoff = (size_t)slot * sg.a_slot_stride;
-    const u32x4* src = reinterpret_cast<const u32x4*>(sg.a_qs + aoff);
+// rounding half of quantize_row_q8_K_ref given the block's signed max (src/quant.cpp:630-650)
+DEV void q8k_round_lds(const float (&v)[4], float vmax, int lane, uint8_t* qs_blk, float* d_out, short* bs_blk);
+
+DEV void q8k_block_lds(const float (&v)[4], int lane, uint8_t* qs_blk, float* d_out, short* bs_blk) {
+  // max = signed value of the FIRST element with the largest |x| (src/quant.cpp:622-629)
+  float amax_l = 0.f, vmax_l = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float ax = fabsf(v[i]);
+    if (ax > amax_l) { amax_l = ax; vmax_l = v[i]; }
+  }
+  const u32 amax_bits = wave_max_bits(__builtin_bit_cast(u32, amax_l));
+  // the lowest lane holding the maximum owns the first occurrence (lanes hold consecutive elements)
+  const unsigned long long owners = __ballot(__builtin_bit_cast(u32, amax_l) == amax_bits);
+  const int owner = __ffsll((long long)owners) - 1;
+  const float vmax = u2f(__builtin_amdgcn_readlane(__builtin_bit_cast(u32, vmax_l), owner));
+  q8k_round_lds(v, vmax, lane, qs_blk, d_out, bs_blk);
+}
+
+DEV void q8k_round_lds(const float (&v)[4], float vmax, int lane, uint8_t* qs_blk, float* d_out, short* bs_blk) {
+  int q[4] = {0, 0, 0, 0};
+  float d = 0.f;
+  if (vmax != 0.f) {
+    const float iscale = __fdiv_rn(-127.f, vmax);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = (int)rintf(__fmul_rn(iscale, v[i]));
+      q[i] = r < 127 ? r : 127;
+    }
+    d = __fmul_rn(vmax, 1.0f / -127.f);
+  }
+  reinterpret_cast<u32*>(qs_blk)[lane] = (u32)(q[0] & 0xff) | ((u32)(q[1] & 0xff) << 8) | ((u32)(q[2] & 0xff) << 16) | ((u32)(q[3] & 0xff) << 24);
+  int s = q[0] + q[1] + q[2] + q[3];
+  s += (int)dpp_u32<DPP_XOR1>((u32)s);
+  s += (int)dpp_u32<DPP_XOR2>((u32)s);
+  if ((lane & 3) == 0) {
+    const int j = lane >> 2, h = j >> 3, sh = (j >> 1) & 3, lh = j & 1;
+    bs_blk[(2 * h + lh) * 4 + sh] = (short)s;
+  }
+  if (lane == 0) *d_out = d;
+}
+
+DEV float wave_sum(float v) {  // fixed order: quads, rows of 16, then the four rows
+  v += dpp_f32<DPP_XOR1>(v);
+  v += dpp_f32<DPP_XOR2>(v);
+  v += dpp_f32<DPP_HALF_MIRROR>(v);
+  v += dpp_f32<DPP_MIRROR>(v);
+  const float a = u2f(__builtin_amdgcn_readlane(__builtin_bit_cast(u32, v), 0));
+  const float b = u2f(__builtin_amdgcn_readlane(__builtin_bit_cast(u32, v), 16));
+  const float c = u2f(__builtin_amdgcn_readlane(__builtin_bit_cast(u32, v), 32));
+  const float d = u2f(__builtin_amdgcn_readlane(__builtin_bit_cast(u32, v), 48));
+  return (a + b) + (c + d);
+}
+
+// sum over the 2^lpr_log2 lanes that share a row (every lane of the group gets the total);
+// fixed order, DPP inside a 16-lane row, ds_bpermute only across rows
+DEV float lanes_sum(float v, int lpr_log2) {
+  if (lpr_log2 >= 1) v += dpp_f32<DPP_XOR1>(v);
+  if (lpr_log2 >= 2) v += dpp_f32<DPP_XOR2>(v);
+  if (lpr_log2 >= 3) v += dpp_f32<DPP_HALF_MIRROR>(v);
+  if (lpr_log2 >= 4) v += dpp_f32<DPP_MIRROR>(v);
+  if (lpr_log2 >= 5) v += __shfl_xor(v, 16);
+  if (lpr_log2 >= 6) v += __shfl_xor(v, 32);
+  return v;
+}
+
+// sum of squares of x[0..n) over the whole workgroup (256 threads), deterministic order
+DEV float wg_sumsq(const float* __restrict__ x, int n, int tid, float* scratch) {
+  float ss = 0.f;
+  for (int i0 = tid * 4; i0 < n; i0 += 8 * 1024) {
+    f32x4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (i0 + k * 1024 < n) v[k] = *reinterpret_cast<const f32x4*>(x + i0 + k * 1024);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (i0 + k * 1024 < n) {
+        ss = fmaf(v[k].x, v[k].x, ss);
+        ss = fmaf(v[k].y, v[k].y, ss);
+        ss = fmaf(v[k].z, v[k].z, ss);
+        ss = fmaf(v[k].w, v[k].w, ss);
+      }
+  }
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) scratch[tid >> 6] = ss;
+  __syncthreads();
+  const float t = (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+  __syncthreads();
+  return t;
+}
+
+// Stage one activation vector of a K-quant task in LDS (qs | bsums(quarter order) | d).
+DEV void stage_q8(const GemvTask& T, uint8_t* l_qs, short* l_bs, float* l_d, int tid, float* scratch) {
+  const int n = T.n, nb = n >> 8;
+  if (T.act_mode == ACT_Q8) {
+    const u32x4* src = reinterpret_cast<const u32x4*>(T.a_qs);
     u32x4* dst = reinterpret_cast<u32x4*>(l_qs);
     for (int i = tid; i < (n >> 4); i += 256) dst[i] = src[i];
-    const short* bsrc = sg.a_bsums + (aoff >> 4);
     for (int i = tid; i < nb * 16; i += 256) {
       const int b = i >> 4, j = i & 15;
       const int h = j >> 3, s = (j >> 1) & 3, lh = j & 1;
-      l_bs[b * 16 + (2 * h + lh) * 4 + s] = bsrc[i];
+      l_bs[b * 16 + (2 * h + lh) * 4 + s] = T.a_bsums[i];
     }
-    const float* dsrc = sg.a_d + (aoff >> 8);
-    for (int i = tid; i < nb; i += 256) l_d[i] = dsrc[i];
+    for (int i = tid; i < nb; i += 256) l_d[i] = T.a_d[i];
+    return;
   }
-  __syncthreads();
-
-  const int wave = tid >> 6, lane = tid & 63;
-  const int sub = lane & (LPR - 1), rloc = lane >> lpr_log2;
-  const int row0 = (blockIdx.x * 4 + wave) * (RPW * R);
-  if (row0 >= sg.rows) return;
-  const int its = (nb * 4) >> lpr_log2;
-
-  size_t roff[R];
-  bool valid[R];
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  if (T.act_mode == ACT_F32_NORM && nb <= 32) {
+    // rmsnorm (src/infer.cpp:601-611) + Q8_K in ONE memory round trip: wave w owns blocks w, w+4, ...
+    // (<= 8 per wave); x and the norm weight are loaded once and stay in registers across the
+    // sum-of-squares reduction.
+    f32x4 t[8], wv[8];
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    int row = row0 + r * RPW + rloc;
-    valid[r] = row < sg.rows;
-    roff[r] = (size_t)(valid[r] ? row : sg.rows - 1) * nb;
-  }
-  float acc[R], acc2[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) acc[r] = acc2[r] = 0.f;
-
-  for (int it = 0; it < its; ++it) {
-    const int item = sub + it * LPR;
-    const int b = item >> 2, q = item & 3, h = q >> 1, lh = q & 1;
-    // weights first: independent of LDS, keeps HBM requests in flight as early as possible
-    u32x4 w[R], w2[R], hmv[R], hmv2[R];
-    u32 scw[R], scw2[R], dmw[R], dmw2[R], s1w[R], s2w[R], s1w2[R], s2w2[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      w[r] = ldg_nt(reinterpret_cast<const u32x4*>(QS + roff[r] * 64 + (size_t)item * 16));
-      if (QT == DSK_QUANT_Q2_K) {
-        scw[r] = ldg_nt(reinterpret_cast<const u32*>(SC + roff[r] * 16 + (size_t)item * 4));
-        dmw[r] = ldg_nt(reinterpret_cast<const u32*>(DM + (roff[r] + b) * 4));
-      } else {
-        hmv[r] = ldg_nt(reinterpret_cast<const u32x4*>(HM + (roff[r] + b) * 32 + lh * 16));
-        const u32* sp = reinterpret_cast<const u32*>(SC + (roff[r] + b) * 12);
-        scw[r] = ldg_nt(sp);
-        s1w[r] = ldg_nt(sp + 1);
-        s2w[r] = ldg_nt(sp + 2);
-        dmw[r] = ldg_nt(reinterpret_cast<const unsigned short*>(DM + (roff[r] + b) * 2));
+    for (int k = 0; k < 8; ++k) {
+      const int b = wave + 4 * k;
+      if (b < nb) {
+        t[k] = *reinterpret_cast<const f32x4*>(T.a_f32 + b * 256 + lane * 4);
+        wv[k] = *reinterpret_cast<const f32x4*>(T.norm_w + b * 256 + lane * 4);
       }
-      if (GLU) {
-        w2[r] = ldg_nt(reinterpret_cast<const u32x4*>(QS2 + roff[r] * 64 + (size_t)item * 16));
-        if (QT == DSK_QUANT_Q2_K) {
-          scw2[r] = ldg_nt(reinterpret_cast<const u32*>(SC2 + roff[r] * 16 + (size_t)item * 4));
-          dmw2[r] = ldg_nt(reinterpret_cast<const u32*>(DM2 + (roff[r] + b) * 4));
-        } else {
-          hmv2[r] = ldg_nt(reinterpret_cast<const u32x4*>(HM2 + (roff[r] + b) * 32 + lh * 16));
-          const u32* sp = reinterpret_cast<const u32*>(SC2 + (roff[r] + b) * 12);
-          scw2[r] = ldg_nt(sp);
-          s1w2[r] = ldg_nt(sp + 1);
-          s2w2[r] = ldg_nt(sp + 2);
-          dmw2[r] = ldg_nt(reinterpret_cast<const unsigned short*>(DM2 + (roff[r] + b) * 2));
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (wave + 4 * k < nb) {
+        ss = fmaf(t[k].x, t[k].x, ss);
+        ss = fmaf(t[k].y, t[k].y, ss);
+        ss = fmaf(t[k].z, t[k].z, ss);
+        ss = fmaf(t[k].w, t[k].w, ss);
+      }
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) scratch[wave] = ss;
+    __syncthreads();
+    const float total = (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+    const float scale = 1.0f / sqrtf(total / (float)n + T.eps);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int b = wave + 4 * k;
+      if (b < nb) {
+        float v[4] = {t[k].x * scale * wv[k].x, t[k].y * scale * wv[k].y, t[k].z * scale * wv[k].z, t[k].w * scale * wv[k].w};
+        if (T.norm_out) *reinterpret_cast<f32x4*>(T.norm_out + b * 256 + lane * 4) = f32x4{v[0], v[1], v[2], v[3]};
+        q8k_block_lds(v, lane, l_qs + b * 256, l_d + b, l_bs + b * 16);
+      }
+    }
+    return;
+  }
+  float scale = 1.0f;
+  if (T.act_mode == ACT_F32_NORM) {  // long vectors: two passes
+    const float total = wg_sumsq(T.a_f32, n, tid, scratch);
+    scale = 1.0f / sqrtf(total / (float)n + T.eps);
+  }
+  // wave w quantises blocks w, w+4, ...; the loads of 4 blocks are issued together (one L2 latency)
+  for (int b0 = wave; b0 < nb; b0 += 16) {
+    f32x4 t[4], wv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int b = b0 + 4 * k;
+      if (b < nb) {
+        t[k] = *reinterpret_cast<const f32x4*>(T.a_f32 + b * 256 + lane * 4);
+        if (T.act_mode == ACT_F32_NORM) wv[k] = *reinterpret_cast<const f32x4*>(T.norm_w + b * 256 + lane * 4);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int b = b0 + 4 * k;
+      if (b < nb) {
+        float v[4] = {t[k].x, t[k].y, t[k].z, t[k].w};
+        if (T.act_mode == ACT_F32_NORM) {
+          v[0] = v[0] * scale * wv[k].x;
+          v[1] = v[1] * scale * wv[k].y;
+          v[2] = v[2] * scale * wv[k].z;
+          v[3] = v[3] * scale * wv[k].w;
+          if (T.norm_out) *reinterpret_cast<f32x4*>(T.norm_out + b * 256 + lane * 4) = f32x4{v[0], v[1], v[2], v[3]};
         }
+        if (T.act_mode == ACT_F32_BMAX) q8k_round_lds(v, bmax_value(T.a_bmax[b]), lane, l_qs + b * 256, l_d + b, l_bs + b * 16);
+        else q8k_block_lds(v, lane, l_qs + b * 256, l_d + b, l_bs + b * 16);
       }
-    }
-    // activations of this column item (shared by all R rows and both GLU matrices)
-    u32x4 a[4];
-    const uint8_t* ap = l_qs + b * 256 + h * 128 + lh * 16;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) a[s] = *reinterpret_cast<const u32x4*>(ap + s * 32);
-    const u32x2 bsp = *reinterpret_cast<const u32x2*>(l_bs + b * 16 + q * 4);
-    const float dx = l_d[b];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      if (QT == DSK_QUANT_Q2_K) {
-        acc[r] = q2k_item(w[r], scw[r], dmw[r], a, bsp, dx, acc[r]);
-        if (GLU) acc2[r] = q2k_item(w2[r], scw2[r], dmw2[r], a, bsp, dx, acc2[r]);
-      } else {
-        acc[r] = q3k_item(w[r], hmv[r], scw[r], s1w[r], s2w[r], dmw[r], h, lh, a, bsp, dx, acc[r]);
-        if (GLU) acc2[r] = q3k_item(w2[r], hmv2[r], scw2[r], s1w2[r], s2w2[r], dmw2[r], h, lh, a, bsp, dx, acc2[r]);
-      }
-    }
-  }
-
-  // ---- combine the LPR lanes of each row (fixed butterfly order) ----
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    for (int off = LPR >> 1; off >= 1; off >>= 1) {
-      acc[r] += __shfl_xor(acc[r], off);
-      if (GLU) acc2[r] += __shfl_xor(acc2[r], off);
-    }
-  }
-  if (sub == 0) {
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      if (!valid[r]) continue;
-      const int row = row0 + r * RPW + rloc;
-      float* o = sg.out + (size_t)slot * sg.out_slot_stride + row;
-      if (GLU) *o = act_fn(acc[r], sg.act) * acc2[r];   // src/infer.cpp:859-872
-      else if (sg.epilogue == EPI_ADD) *o += acc[r];    // residual add, src/infer.cpp:832-834,928-930
-      else *o = acc[r];
     }
   }
 }
 
-// ------------------------------------------------------------------------------------
-// F8E5M2 / F16 / F32 weights, f32 activations staged in LDS.
-// item = 16 bytes of one row = 16 / 8 / 4 weights.  fp8 byte -> f16 is the byte shifted into
-// the high half (src/codec.h:40-48), f16 -> f32 is exact; products are f32 FMAs like the
-// reference (src/infer.cpp:289-297); the block scale is applied once per item (the reference
-// scales every weight before the FMA: same value up to one f32 rounding per item).
-// ------------------------------------------------------------------------------------
+// Stage an f32 activation vector (F8 / F16 / F32 weights)
+DEV void stage_f32(const GemvTask& T, float* l_x, int tid, float* scratch) {
+  const int n = T.n;
+  if (T.act_mode == ACT_F32_NORM) {
+    const float total = wg_sumsq(T.a_f32, n, tid, scratch);
+    const float scale = 1.0f / sqrtf(total / (float)n + T.eps);
+    for (int i = tid; i < n; i += 256) {
+      const float y = T.a_f32[i] * scale * T.norm_w[i];
+      l_x[i] = y;
+      if (T.norm_out) T.norm_out[i] = y;
+    }
+  } else {
+    const f32x4* src = reinterpret_cast<const f32x4*>(T.a_f32);
+    f32x4* dst = reinterpret_cast<f32x4*>(l_x);
+    for (int i = tid; i < (n >> 2); i += 256) dst[i] = src[i];
+    for (int i = (n & ~3) + tid; i < n; i += 256) l_x[i] = T.a_f32[i];
+  }
+}
+
 template <int QT>
 DEV float fitem(u32x4 w, const float* xa, float partial) {
   if (QT == DSK_QUANT_F32) {
@@ -276,7 +369,7 @@ DEV float fitem(u32x4 w, const float* xa, float partial) {
       partial = fmaf((float)p.x, xa[2 * k], partial);
       partial = fmaf((float)p.y, xa[2 * k + 1], partial);
     }
-  } else {
+  } else {  // fp8 byte -> f16 is the byte shifted into the high half (src/codec.h:40-48)
     const u32 ww[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -291,182 +384,574 @@ DEV float fitem(u32x4 w, const float* xa, float partial) {
   return partial;
 }
 
-template <int QT, int R, bool GLU>
-__global__ __launch_bounds__(256) void gemv_f_kernel(GemvSeg sg, int lpr_log2) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const int LPR = 1 << lpr_log2, RPW = 64 >> lpr_log2;
-  constexpr int EPI = QT == DSK_QUANT_F32 ? 4 : (QT == DSK_QUANT_F16 ? 8 : 16);  // elements per item
-  constexpr int ESZ = 16 / EPI;
-  const int tid = threadIdx.x, slot = blockIdx.y, n = sg.n;
+// resolved per-task weight pointers
+struct WPtr {
+  const uint8_t *qs, *sc, *hm, *dm, *qs2, *sc2, *hm2, *dm2;
+  const float *scale, *scale2;
+  bool present;
+};
+DEV WPtr resolve(const GemvTask& T) {
+  WPtr p;
   int le = 0;
-  if (sg.e_qs != 0) {
-    const int e = sg.expert_ids ? sg.expert_ids[slot] : slot;
-    le = e - sg.expert_base;
-    if (le < 0 || le >= sg.local_experts) return;
+  p.present = true;
+  if (T.e_qs != 0) {
+    // slot -> expert on the device (the reference reads active_experts on the host, src/infer.cpp:854)
+    const int e = T.expert_ids ? T.expert_ids[T.slot] : T.slot;
+    le = e - T.expert_base;
+    p.present = le >= 0 && le < T.local_experts;  // otherwise the expert lives on another GPU
+    if (!p.present) le = 0;
   }
-  const uint8_t* W = sg.qs + (size_t)le * sg.e_qs;
-  const uint8_t* W2 = GLU ? sg.qs2 + (size_t)le * sg.e_qs : nullptr;
-  const float* S = sg.scale ? sg.scale + (size_t)le * sg.e_scale : nullptr;
-  const float* S2 = (GLU && sg.scale2) ? sg.scale2 + (size_t)le * sg.e_scale : nullptr;
+  p.qs = T.qs + (size_t)le * T.e_qs;
+  p.sc = T.sc ? T.sc + (size_t)le * T.e_sc : nullptr;
+  p.hm = T.hm ? T.hm + (size_t)le * T.e_hm : nullptr;
+  p.dm = T.dm ? T.dm + (size_t)le * T.e_dm : nullptr;
+  p.scale = T.scale ? T.scale + (size_t)le * T.e_scale : nullptr;
+  p.qs2 = T.qs2 ? T.qs2 + (size_t)le * T.e_qs : nullptr;
+  p.sc2 = T.sc2 ? T.sc2 + (size_t)le * T.e_sc : nullptr;
+  p.hm2 = T.hm2 ? T.hm2 + (size_t)le * T.e_hm : nullptr;
+  p.dm2 = T.dm2 ? T.dm2 + (size_t)le * T.e_dm : nullptr;
+  p.scale2 = T.scale2 ? T.scale2 + (size_t)le * T.e_scale : nullptr;
+  return p;
+}
 
-  float* l_x = reinterpret_cast<float*>(smem);
-  {
-    const u32x4* src = reinterpret_cast<const u32x4*>(sg.a_f32 + (size_t)slot * sg.a_slot_stride);
-    u32x4* dst = reinterpret_cast<u32x4*>(l_x);
-    for (int i = tid; i < (n >> 2); i += 256) dst[i] = src[i];
-  }
-  __syncthreads();
 
-  const int wave = tid >> 6, lane = tid & 63;
-  const int sub = lane & (LPR - 1), rloc = lane >> lpr_log2;
-  const int row0 = (blockIdx.x * 4 + wave) * (RPW * R);
-  if (row0 >= sg.rows) return;
-  const int items = n / EPI;
-  const int its = items >> lpr_log2;
-  const size_t row_bytes = (size_t)n * ESZ;
+// ------------------------------------------------------------------------------------
+// One "chunk" = U column steps x R rows of weight data held in registers.  Loading and computing
+// are separate so that the first chunk can be requested from HBM BEFORE the workgroup stages its
+// activation vector (the prologue then overlaps the memory latency instead of preceding it).
+// ------------------------------------------------------------------------------------
+template <int QT, int R, int U, bool GLU>
+struct ChunkKQ {
+  u32x4 w[U][R], w2[U][R], hmv[U][R], hmv2[U][R];
+  u32 scw[U][R], scw2[U][R], dmw[U][R], dmw2[U][R], s1w[U][R], s2w[U][R], s1w2[U][R], s2w2[U][R];
+  int itemv[U];
+};
 
-  int rowi[R];
-  bool valid[R];
+template <int QT, int R, int U, bool GLU>
+DEV void load_chunk_kq(ChunkKQ<QT, R, U, GLU>& c, const WPtr& P, int nb, int lpr_log2, int lane, const int (&row)[R], int it0) {
+  const int LPR = 1 << lpr_log2;
+  const int sub = lane & (LPR - 1);
+  const int items = nb * 4;
+  const int its = (items + LPR - 1) >> lpr_log2;
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    int row = row0 + r * RPW + rloc;
-    valid[r] = row < sg.rows;
-    rowi[r] = valid[r] ? row : sg.rows - 1;
-  }
-  float acc[R], acc2[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) acc[r] = acc2[r] = 0.f;
-
-  for (int it = 0; it < its; ++it) {
-    const int item = sub + it * LPR;
-    u32x4 w[R], w2[R];
-    float sv[R], sv2[R];
+  for (int u = 0; u < U; ++u) {
+    const int it = it0 + u;
+    if (it >= its) break;  // wave-uniform: the trailing steps of the last chunk do no work at all
+    int item = sub + (it << lpr_log2);
+    const bool live = item < items;
+    if (!live) item = items - 1;
+    c.itemv[u] = item;
+    const int b = item >> 2, lh = item & 1;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      w[r] = ldg_nt(reinterpret_cast<const u32x4*>(W + (size_t)rowi[r] * row_bytes + (size_t)item * 16));
-      sv[r] = S ? S[(size_t)(rowi[r] / sg.b0) * sg.sc_cols + (item * EPI) / sg.b1] : 1.0f;
+      const size_t roff = (size_t)row[r] * nb;
+      c.w[u][r] = ldg_nt(reinterpret_cast<const u32x4*>(P.qs + roff * 64 + (size_t)item * 16));
+      if (QT == DSK_QUANT_Q2_K) {
+        c.scw[u][r] = ldg_nt(reinterpret_cast<const u32*>(P.sc + roff * 16 + (size_t)item * 4));
+        c.dmw[u][r] = ldg_nt(reinterpret_cast<const u32*>(P.dm + (roff + b) * 4));
+      } else {
+        c.hmv[u][r] = ldg_nt(reinterpret_cast<const u32x4*>(P.hm + (roff + b) * 32 + lh * 16));
+        const u32* sp = reinterpret_cast<const u32*>(P.sc + (roff + b) * 12);
+        c.scw[u][r] = ldg_nt(sp);
+        c.s1w[u][r] = ldg_nt(sp + 1);
+        c.s2w[u][r] = ldg_nt(sp + 2);
+        c.dmw[u][r] = ldg_nt(reinterpret_cast<const unsigned short*>(P.dm + (roff + b) * 2));
+      }
       if (GLU) {
-        w2[r] = ldg_nt(reinterpret_cast<const u32x4*>(W2 + (size_t)rowi[r] * row_bytes + (size_t)item * 16));
-        sv2[r] = S2 ? S2[(size_t)(rowi[r] / sg.b0) * sg.sc_cols + (item * EPI) / sg.b1] : 1.0f;
+        c.w2[u][r] = ldg_nt(reinterpret_cast<const u32x4*>(P.qs2 + roff * 64 + (size_t)item * 16));
+        if (QT == DSK_QUANT_Q2_K) {
+          c.scw2[u][r] = ldg_nt(reinterpret_cast<const u32*>(P.sc2 + roff * 16 + (size_t)item * 4));
+          c.dmw2[u][r] = ldg_nt(reinterpret_cast<const u32*>(P.dm2 + (roff + b) * 4));
+        } else {
+          c.hmv2[u][r] = ldg_nt(reinterpret_cast<const u32x4*>(P.hm2 + (roff + b) * 32 + lh * 16));
+          const u32* sp = reinterpret_cast<const u32*>(P.sc2 + (roff + b) * 12);
+          c.scw2[u][r] = ldg_nt(sp);
+          c.s1w2[u][r] = ldg_nt(sp + 1);
+          c.s2w2[u][r] = ldg_nt(sp + 2);
+          c.dmw2[u][r] = ldg_nt(reinterpret_cast<const unsigned short*>(P.dm2 + (roff + b) * 2));
+        }
+      }
+      if (!live) {  // a zero super-block scale removes the (finite) contribution
+        c.dmw[u][r] = 0;
+        if (GLU) c.dmw2[u][r] = 0;
       }
     }
+  }
+}
+
+template <int QT, int R, int U, bool GLU>
+DEV void compute_chunk_kq(const ChunkKQ<QT, R, U, GLU>& c, int nb, int lpr_log2, int it0, const uint8_t* l_qs, const short* l_bs,
+                          const float* l_d, float (&acc)[R], float (&acc2)[R]) {
+  const int its = (nb * 4 + (1 << lpr_log2) - 1) >> lpr_log2;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (it0 + u >= its) break;
+    const int item = c.itemv[u];
+    const int b = item >> 2, q = item & 3, h = q >> 1, lh = q & 1;
+    u32x4 a[4];
+    const uint8_t* ap = l_qs + b * 256 + h * 128 + lh * 16;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) a[s] = *reinterpret_cast<const u32x4*>(ap + s * 32);
+    const u32x2 bsp = *reinterpret_cast<const u32x2*>(l_bs + b * 16 + q * 4);
+    const float dx = l_d[b];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (QT == DSK_QUANT_Q2_K) {
+        acc[r] = q2k_item(c.w[u][r], c.scw[u][r], c.dmw[u][r], a, bsp, dx, acc[r]);
+        if (GLU) acc2[r] = q2k_item(c.w2[u][r], c.scw2[u][r], c.dmw2[u][r], a, bsp, dx, acc2[r]);
+      } else {
+        acc[r] = q3k_item(c.w[u][r], c.hmv[u][r], c.scw[u][r], c.s1w[u][r], c.s2w[u][r], c.dmw[u][r], h, lh, a, bsp, dx, acc[r]);
+        if (GLU) acc2[r] = q3k_item(c.w2[u][r], c.hmv2[u][r], c.scw2[u][r], c.s1w2[u][r], c.s2w2[u][r], c.dmw2[u][r], h, lh, a, bsp, dx, acc2[r]);
+      }
+    }
+  }
+}
+
+// F8E5M2 / F16 / F32 weights; products are f32 FMAs like the reference (src/infer.cpp:289-297);
+// the block scale is applied once per 16-byte item (the reference scales every weight before the
+// FMA: same value up to one f32 rounding per item).
+template <int QT, int R, int U, bool GLU>
+struct ChunkF {
+  u32x4 w[U][R], w2[U][R];
+  float sv[U][R], sv2[U][R];
+  int itemv[U];
+};
+template <int QT>
+struct FTraits {
+  static constexpr int EPI = QT == DSK_QUANT_F32 ? 4 : (QT == DSK_QUANT_F16 ? 8 : 16);  // elements per 16-byte item
+  static constexpr int ESZ = 16 / EPI;
+};
+
+template <int QT, int R, int U, bool GLU>
+DEV void load_chunk_f(ChunkF<QT, R, U, GLU>& c, const WPtr& P, int n, int b0, int b1, int lpr_log2, int lane, const int (&row)[R], int it0) {
+  constexpr int EPI = FTraits<QT>::EPI, ESZ = FTraits<QT>::ESZ;
+  const int LPR = 1 << lpr_log2;
+  const int sub = lane & (LPR - 1);
+  const int items = n / EPI;
+  const int its = (items + LPR - 1) >> lpr_log2;
+  const size_t row_bytes = (size_t)n * ESZ;
+  const int sc_cols = (n + b1 - 1) / b1;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int it = it0 + u;
+    if (it >= its) break;
+    int item = sub + (it << lpr_log2);
+    const bool live = item < items;
+    if (!live) item = items - 1;
+    c.itemv[u] = item;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      c.w[u][r] = ldg_nt(reinterpret_cast<const u32x4*>(P.qs + (size_t)row[r] * row_bytes + (size_t)item * 16));
+      c.sv[u][r] = P.scale ? P.scale[(size_t)(row[r] / b0) * sc_cols + (item * EPI) / b1] : 1.0f;
+      c.sv2[u][r] = 0.f;
+      if (GLU) {
+        c.w2[u][r] = ldg_nt(reinterpret_cast<const u32x4*>(P.qs2 + (size_t)row[r] * row_bytes + (size_t)item * 16));
+        c.sv2[u][r] = P.scale2 ? P.scale2[(size_t)(row[r] / b0) * sc_cols + (item * EPI) / b1] : 1.0f;
+      }
+      if (!live) c.sv[u][r] = c.sv2[u][r] = 0.f;
+    }
+  }
+}
+
+template <int QT, int R, int U, bool GLU>
+DEV void compute_chunk_f(const ChunkF<QT, R, U, GLU>& c, int n, int lpr_log2, int it0, const float* l_x, float (&acc)[R], float (&acc2)[R]) {
+  constexpr int EPI = FTraits<QT>::EPI;
+  const int its = (n / EPI + (1 << lpr_log2) - 1) >> lpr_log2;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (it0 + u >= its) break;
+    const int item = c.itemv[u];
     float xa[EPI];
 #pragma unroll
     for (int k = 0; k < EPI / 4; ++k) {
-      const u32x4 v = *reinterpret_cast<const u32x4*>(l_x + item * EPI + 4 * k);
-      xa[4 * k] = u2f(v.x);
-      xa[4 * k + 1] = u2f(v.y);
-      xa[4 * k + 2] = u2f(v.z);
-      xa[4 * k + 3] = u2f(v.w);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(l_x + item * EPI + 4 * k);
+      xa[4 * k] = v.x;
+      xa[4 * k + 1] = v.y;
+      xa[4 * k + 2] = v.z;
+      xa[4 * k + 3] = v.w;
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      acc[r] = fmaf(fitem<QT>(w[r], xa, 0.f), sv[r], acc[r]);
-      if (GLU) acc2[r] = fmaf(fitem<QT>(w2[r], xa, 0.f), sv2[r], acc2[r]);
+      acc[r] = fmaf(fitem<QT>(c.w[u][r], xa, 0.f), c.sv[u][r], acc[r]);
+      if (GLU) acc2[r] = fmaf(fitem<QT>(c.w2[u][r], xa, 0.f), c.sv2[u][r], acc2[r]);
+    }
+  }
+}
+
+// dot products of R rows (x 64/LPR rows per wave) with a staged activation vector.
+// `pre`: the first chunk was already requested by the caller (prefetch across the prologue).
+template <int QT, int R, int U, bool GLU, typename Chunk>
+DEV void rows_dot(Chunk& c, bool pre, const WPtr& P, int n, int b0, int b1, int lpr_log2, int lane, const int (&row)[R],
+                  const uint8_t* lds, float (&acc)[R], float (&acc2)[R]) {
+  constexpr bool KQ = QT == DSK_QUANT_Q2_K || QT == DSK_QUANT_Q3_K;
+  const int nb = n >> 8;
+  const int items = KQ ? nb * 4 : n / FTraits<QT>::EPI;
+  const int its = (items + (1 << lpr_log2) - 1) >> lpr_log2;
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = acc2[r] = 0.f;
+  for (int it0 = 0; it0 < its; it0 += U) {
+    if constexpr (KQ) {
+      if (!(pre && it0 == 0)) load_chunk_kq<QT, R, U, GLU>(c, P, nb, lpr_log2, lane, row, it0);
+      compute_chunk_kq<QT, R, U, GLU>(c, nb, lpr_log2, it0, lds, reinterpret_cast<const short*>(lds + n),
+                                      reinterpret_cast<const float*>(lds + n + nb * 32), acc, acc2);
+    } else {
+      if (!(pre && it0 == 0)) load_chunk_f<QT, R, U, GLU>(c, P, n, b0, b1, lpr_log2, lane, row, it0);
+      compute_chunk_f<QT, R, U, GLU>(c, n, lpr_log2, it0, reinterpret_cast<const float*>(lds), acc, acc2);
     }
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    for (int off = LPR >> 1; off >= 1; off >>= 1) {
-      acc[r] += __shfl_xor(acc[r], off);
-      if (GLU) acc2[r] += __shfl_xor(acc2[r], off);
-    }
+    acc[r] = lanes_sum(acc[r], lpr_log2);
+    if (GLU) acc2[r] = lanes_sum(acc2[r], lpr_log2);
   }
-  if (sub == 0) {
+}
+
+template <int QT, int R, int U, bool GLU>
+struct ChunkOf {
+  using type = typename std::conditional<(QT == DSK_QUANT_Q2_K || QT == DSK_QUANT_Q3_K), ChunkKQ<QT, R, U, GLU>, ChunkF<QT, R, U, GLU>>::type;
+};
+
+// Stage the activation vectors of ALL tasks of an accumulate launch (K-quants): the 256-blocks of
+// every slot form one list that the four waves walk together, 4 loads in flight per lane.
+DEV void stage_accum_q8(const GemvLaunch& L, uint8_t* smem, int tid) {
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  int NB = 0;
+  for (int ti = 0; ti < L.n_tasks; ++ti) NB += L.t[ti].n >> 8;
+  for (int g0 = wave; g0 < NB; g0 += 16) {
+    f32x4 t[4];
+    float vm[4];
+    int dst_off[4], bidx[4];
+    bool hasmax[4];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      if (!valid[r]) continue;
-      const int row = row0 + r * RPW + rloc;
-      float* o = sg.out + (size_t)slot * sg.out_slot_stride + row;
-      if (GLU) *o = act_fn(acc[r], sg.act) * acc2[r];
-      else if (sg.epilogue == EPI_ADD) *o += acc[r];
-      else *o = acc[r];
+    for (int k = 0; k < 4; ++k) {
+      const int gb = g0 + 4 * k;
+      if (gb < NB) {
+        int ti = 0, b = gb;
+        size_t off = 0;
+        while (b >= (L.t[ti].n >> 8)) {  // wave-uniform scan: which slot owns block gb
+          b -= L.t[ti].n >> 8;
+          off += ((size_t)L.t[ti].n + (size_t)(L.t[ti].n >> 8) * 36 + 15) & ~(size_t)15;
+          ++ti;
+        }
+        const GemvTask& T = L.t[ti];
+        t[k] = *reinterpret_cast<const f32x4*>(T.a_f32 + b * 256 + lane * 4);
+        hasmax[k] = T.act_mode == ACT_F32_BMAX;
+        vm[k] = hasmax[k] ? bmax_value(T.a_bmax[b]) : 0.f;
+        dst_off[k] = (int)off;
+        bidx[k] = b | (T.n << 8);  // block index and the slot's n (for the bsums / d sub-offsets)
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int gb = g0 + 4 * k;
+      if (gb < NB) {
+        const int b = bidx[k] & 255, n = bidx[k] >> 8;
+        uint8_t* base = smem + dst_off[k];
+        float v[4] = {t[k].x, t[k].y, t[k].z, t[k].w};
+        uint8_t* qs = base + b * 256;
+        float* dd = reinterpret_cast<float*>(base + n + (n >> 8) * 32) + b;
+        short* bs = reinterpret_cast<short*>(base + n) + b * 16;
+        if (hasmax[k]) q8k_round_lds(v, vm[k], lane, qs, dd, bs);
+        else q8k_block_lds(v, lane, qs, dd, bs);
+      }
     }
   }
 }
 
 // ------------------------------------------------------------------------------------
-// host-side dispatch
+// the kernel.  GEMV_MODE_TASKS: every workgroup serves one task.  GEMV_MODE_ACCUM: every workgroup
+// serves a row range of ALL tasks (the MoE combine: tasks = routed slots in k order, then shared).
 // ------------------------------------------------------------------------------------
-static int pick_lpr(int items) {
-  int lpr = 64;
-  while (lpr > 1 && (items % lpr) != 0) lpr >>= 1;
-  return lpr;
-}
-static int pick_r(long rows, int lpr, int n_slots) {
-  const long groups = (rows + (64 / lpr) - 1) / (64 / lpr);  // waves at R = 1, per slot
-  const long waves1 = groups * (n_slots > 0 ? n_slots : 1);
-  if (waves1 / 4 >= 2048) return 4;
-  if (waves1 / 2 >= 2048) return 2;
-  return 1;
-}
+template <int QT, int R, int U, bool GLU, int MODE>
+__global__ __launch_bounds__(256) void gemv_kernel(const GemvLaunch* __restrict__ Lp) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ float scratch[4];
+  const GemvLaunch& L = *Lp;
+  constexpr bool KQ = QT == DSK_QUANT_Q2_K || QT == DSK_QUANT_Q3_K;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int lpr_log2 = L.lpr_log2;
+  const int RPW = 64 >> lpr_log2;
+  const int rloc = lane >> lpr_log2, sub = lane & ((1 << lpr_log2) - 1);
+  const int RG = 4 * RPW * R;  // rows per workgroup step
 
-template <int QT, int R>
-static int launch_kq(hipStream_t st, const GemvSeg& sg, int lpr_log2) {
-  const int rpw = 64 >> lpr_log2;
-  const int groups = (sg.rows + rpw * R - 1) / (rpw * R);
-  dim3 grid((groups + 3) / 4, sg.n_slots > 0 ? sg.n_slots : 1);
-  const size_t lds = (size_t)sg.n + (size_t)(sg.n / 256) * 36;
-  if (sg.epilogue == EPI_GLU)
-    hipLaunchKernelGGL((gemv_kq_kernel<QT, R, true>), grid, dim3(256), lds, st, sg, lpr_log2);
-  else
-    hipLaunchKernelGGL((gemv_kq_kernel<QT, R, false>), grid, dim3(256), lds, st, sg, lpr_log2);
-  return DSK_OK;
-}
-template <int QT>
-static int launch_kq_r(hipStream_t st, const GemvSeg& sg, int lpr_log2, int r) {
-  switch (r) {
-    case 4: return launch_kq<QT, 4>(st, sg, lpr_log2);
-    case 2: return launch_kq<QT, 2>(st, sg, lpr_log2);
-    default: return launch_kq<QT, 1>(st, sg, lpr_log2);
+  if (MODE == GEMV_MODE_TASKS) {
+    GemvTask T;
+    int wi, nwg;
+    if (L.bd_heads > 0) {  // block-diagonal stack: workgroup -> head
+      const int head = blockIdx.x / L.bd_wgs;
+      wi = blockIdx.x - head * L.bd_wgs;
+      nwg = L.bd_wgs;
+      T = L.t[0];
+      const size_t per = (size_t)T.rows * T.n;
+      if (QT == DSK_QUANT_Q2_K) {
+        T.qs += head * (per / 256 * 64); T.sc += head * (per / 256 * 16); T.dm += head * (per / 256 * 4);
+      } else if (QT == DSK_QUANT_Q3_K) {
+        T.qs += head * (per / 256 * 64); T.hm += head * (per / 256 * 32); T.sc += head * (per / 256 * 12); T.dm += head * (per / 256 * 2);
+      } else {
+        T.qs += head * per * FTraits<QT>::ESZ;
+        // reference indexing: expert_index * cdiv(d,b0)*cdiv(n,b1) (src/infer.cpp:437-438)
+        if (T.scale) T.scale += (size_t)head * ((T.rows + L.b0 - 1) / L.b0) * ((T.n + L.b1 - 1) / L.b1);
+      }
+      T.a_f32 += (size_t)head * T.n;
+      T.out += (size_t)head * T.rows;
+    } else {
+      int ti = 0;
+      while (ti + 1 < L.n_tasks && (int)blockIdx.x >= L.t[ti].wg_end) ++ti;
+      T = L.t[ti];
+      wi = blockIdx.x - T.wg_begin;
+      nwg = T.wg_end - T.wg_begin;
+    }
+    const WPtr P = resolve(T);
+    if (!P.present) return;
+    const int n_groups = (T.rows + RG - 1) / RG;
+    if (wi >= n_groups) return;
+
+    auto row0_of = [&](int g) { return g * RG + wave * (RPW * R); };
+    auto rows_of = [&](int g, int (&row)[R], bool (&valid)[R]) {
+      const int row0 = g * RG + wave * (RPW * R);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int rr = row0 + r * RPW + rloc;
+        valid[r] = rr < T.rows;
+        row[r] = valid[r] ? rr : T.rows - 1;
+      }
+      return row0 < T.rows;
+    };
+    typename ChunkOf<QT, R, U, GLU>::type c;
+    int row[R];
+    bool valid[R];
+    bool has_rows = rows_of(wi, row, valid);
+    if (KQ) stage_q8(T, smem, reinterpret_cast<short*>(smem + T.n), reinterpret_cast<float*>(smem + T.n + (T.n >> 8) * 32), tid, scratch);
+    else stage_f32(T, reinterpret_cast<float*>(smem), tid, scratch);
+    __syncthreads();
+    for (int g = wi; g < n_groups; g += nwg) {
+      if (g != wi) has_rows = rows_of(g, row, valid);
+      if (!has_rows) continue;
+      float acc[R], acc2[R];
+      rows_dot<QT, R, U, GLU>(c, false, P, T.n, L.b0, L.b1, lpr_log2, lane, row, smem, acc, acc2);
+      unsigned long long mykey = 0;
+      int myblk = -1;
+      if (sub == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if (!valid[r]) continue;
+          float* o = T.out + row[r];
+          if (GLU) {
+            const float hv = act_fn(acc[r], L.act) * acc2[r];  // src/infer.cpp:859-872
+            *o = hv;
+            if (T.bmax_out) {
+              const unsigned long long key = bmax_key(hv, row[r] & 255);
+              if (key > mykey) { mykey = key; myblk = row[r] >> 8; }
+            }
+          } else if (T.epilogue == EPI_ADD) {
+            *o += acc[r];  // residual add, src/infer.cpp:832-834,928-930
+          } else {
+            *o = acc[r];
+          }
+        }
+      }
+      if (GLU && T.bmax_out) {
+        // the rows of one wave are consecutive and (RPW*R divides 256) share a 256-block: reduce the
+        // key over the wave, then ONE atomic per wave (contended L2 atomics serialise at ~0.2 us each)
+        u32 hi = (u32)(mykey >> 32), lo = (u32)mykey;
+        const u32 hmax = wave_max_bits(hi);
+        if (hi != hmax) lo = 0;
+        const u32 lmax = wave_max_bits(lo);
+        const int blk = __builtin_amdgcn_readfirstlane((row0_of(g)) >> 8);
+        if (lane == 0 && (hmax | lmax)) atomicMax(T.bmax_out + blk, ((unsigned long long)hmax << 32) | lmax);
+        (void)myblk;
+      }
+    }
+  } else {
+    // ---- MoE combine: x[row] += sum_k w_k * (W2_{e_k}[row] . h_k) in k order, then + shared ----
+    const int nt = L.n_tasks;
+    const int rows = L.t[0].rows;
+    const int n_groups = (rows + RG - 1) / RG;
+    if ((int)blockIdx.x >= n_groups) return;
+    // stage every slot's activation once per (persistent) workgroup
+    if (KQ) {
+      stage_accum_q8(L, smem, tid);
+    } else {
+      size_t off = 0;
+      for (int ti = 0; ti < nt; ++ti) {
+        stage_f32(L.t[ti], reinterpret_cast<float*>(smem + off), tid, scratch);
+        off += ((size_t)L.t[ti].n * 4 + 15) & ~(size_t)15;
+      }
+    }
+    __syncthreads();
+    typename ChunkOf<QT, R, U, false>::type c;
+    for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
+      const int row0 = g * RG + wave * (RPW * R);
+      if (row0 >= rows) continue;
+      int row[R];
+      bool valid[R];
+      float xacc[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int rr = row0 + r * RPW + rloc;
+        valid[r] = rr < rows;
+        row[r] = valid[r] ? rr : rows - 1;
+        xacc[r] = L.t[0].out[row[r]];
+      }
+      size_t off = 0;
+      for (int ti = 0; ti < nt; ++ti) {
+        const GemvTask& T = L.t[ti];
+        const WPtr P = resolve(T);
+        float acc[R], acc2[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = acc2[r] = 0.f;
+        if (P.present) rows_dot<QT, R, U, false>(c, false, P, T.n, L.b0, L.b1, lpr_log2, lane, row, smem + off, acc, acc2);
+        off += KQ ? (((size_t)T.n + (size_t)(T.n >> 8) * 36 + 15) & ~(size_t)15) : (((size_t)T.n * 4 + 15) & ~(size_t)15);
+        if (!P.present) continue;
+        if (T.accum_w) {
+          const float wk = *T.accum_w;  // src/infer.cpp:874-877
+#pragma unroll
+          for (int r = 0; r < R; ++r) xacc[r] = fmaf(acc[r], wk, xacc[r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < R; ++r) xacc[r] += acc[r];  // shared expert, src/infer.cpp:900-903
+        }
+      }
+      if (sub == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          if (valid[r]) L.t[0].out[row[r]] = xacc[r];
+      }
+    }
   }
 }
 
-template <int QT, int R, bool GLU>
-static int launch_f2(hipStream_t st, const GemvSeg& sg, int lpr_log2) {
-  const int rpw = 64 >> lpr_log2;
-  const int groups = (sg.rows + rpw * R - 1) / (rpw * R);
-  dim3 grid((groups + 3) / 4, sg.n_slots > 0 ? sg.n_slots : 1);
-  const size_t lds = (size_t)sg.n * 4;
-  auto k = gemv_f_kernel<QT, R, GLU>;
-  if (lds > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, sg, lpr_log2);
-  return DSK_OK;
-}
-template <int QT>
-static int launch_f_r(hipStream_t st, const GemvSeg& sg, int lpr_log2, int r) {
-  const bool glu = sg.epilogue == EPI_GLU;
-  switch (r) {
-    case 4: return glu ? launch_f2<QT, 4, true>(st, sg, lpr_log2) : launch_f2<QT, 4, false>(st, sg, lpr_log2);
-    case 2: return glu ? launch_f2<QT, 2, true>(st, sg, lpr_log2) : launch_f2<QT, 2, false>(st, sg, lpr_log2);
-    default: return glu ? launch_f2<QT, 1, true>(st, sg, lpr_log2) : launch_f2<QT, 1, false>(st, sg, lpr_log2);
-  }
-}
+// ------------------------------------------------------------------------------------
+// host side: choose the launch geometry and fill the descriptor
+// ------------------------------------------------------------------------------------
 static int ilog2(int v) {
   int l = 0;
   while ((1 << (l + 1)) <= v) ++l;
   return l;
 }
 
-int launch_gemv(hipStream_t st, int quant, const GemvSeg& sg) {
-  if (sg.rows <= 0 || sg.n <= 0) DSK_FAIL(DSK_ERR_INVALID, "gemv: empty shape %d x %d", sg.rows, sg.n);
-  if (quant == DSK_QUANT_Q2_K || quant == DSK_QUANT_Q3_K) {
-    if (sg.n % QK_K) DSK_FAIL(DSK_ERR_INVALID, "k-quant gemv: n=%d is not a multiple of 256 (src/quantizer.cpp:8)", sg.n);
-    const int items = sg.n / 64;
-    const int lpr = pick_lpr(items);  // items is a multiple of 4
-    const int r = pick_r(sg.rows, lpr, sg.n_slots);
-    if (quant == DSK_QUANT_Q2_K) return launch_kq_r<DSK_QUANT_Q2_K>(st, sg, ilog2(lpr), r);
-    return launch_kq_r<DSK_QUANT_Q3_K>(st, sg, ilog2(lpr), r);
+template <int QT, int R, int U>
+static void launch_one(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& h) {
+  dim3 grid(h.grid), block(256);
+  if (h.mode == GEMV_MODE_ACCUM) {
+    auto k = gemv_kernel<QT, R, U, false, GEMV_MODE_ACCUM>;
+    if (h.lds_bytes > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds_bytes);
+    hipLaunchKernelGGL(k, grid, block, h.lds_bytes, st, dev);
+  } else if (h.glu) {
+    auto k = gemv_kernel<QT, R, U, true, GEMV_MODE_TASKS>;
+    if (h.lds_bytes > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds_bytes);
+    hipLaunchKernelGGL(k, grid, block, h.lds_bytes, st, dev);
+  } else {
+    auto k = gemv_kernel<QT, R, U, false, GEMV_MODE_TASKS>;
+    if (h.lds_bytes > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds_bytes);
+    hipLaunchKernelGGL(k, grid, block, h.lds_bytes, st, dev);
   }
-  const int epi = quant == DSK_QUANT_F32 ? 4 : (quant == DSK_QUANT_F16 ? 8 : 16);
-  if (sg.n % epi) DSK_FAIL(DSK_ERR_INVALID, "gemv: n=%d is not a multiple of %d (src/infer.cpp:169,246)", sg.n, epi);
-  if ((size_t)sg.n * 4 > 160 * 1024) DSK_FAIL(DSK_ERR_UNSUPPORTED, "gemv: n=%d does not fit LDS", sg.n);
-  const int lpr = pick_lpr(sg.n / epi);
-  const int r = pick_r(sg.rows, lpr, sg.n_slots);
-  switch (quant) {
-    case DSK_QUANT_F32: return launch_f_r<DSK_QUANT_F32>(st, sg, ilog2(lpr), r);
-    case DSK_QUANT_F16: return launch_f_r<DSK_QUANT_F16>(st, sg, ilog2(lpr), r);
-    case DSK_QUANT_F8E5M2: return launch_f_r<DSK_QUANT_F8E5M2>(st, sg, ilog2(lpr), r);
+}
+template <int QT>
+static int launch_q(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& h) {
+  // (R, U) variants: R rows x U column steps = the 16-byte loads a lane keeps in flight
+  switch (h.R * 16 + h.U) {
+    case 1 * 16 + 8: launch_one<QT, 1, 8>(st, dev, h); break;
+    case 1 * 16 + 4: launch_one<QT, 1, 4>(st, dev, h); break;
+    case 1 * 16 + 2: launch_one<QT, 1, 2>(st, dev, h); break;
+    case 1 * 16 + 1: launch_one<QT, 1, 1>(st, dev, h); break;
+    case 2 * 16 + 4: launch_one<QT, 2, 4>(st, dev, h); break;
+    case 2 * 16 + 2: launch_one<QT, 2, 2>(st, dev, h); break;
+    case 2 * 16 + 1: launch_one<QT, 2, 1>(st, dev, h); break;
+    case 4 * 16 + 2: launch_one<QT, 4, 2>(st, dev, h); break;
+    case 4 * 16 + 1: launch_one<QT, 4, 1>(st, dev, h); break;
+    default: DSK_FAIL(DSK_ERR_INVALID, "gemv: no kernel variant R=%d U=%d", h.R, h.U);
   }
-  DSK_FAIL(DSK_ERR_INVALID, "gemv: bad quant %d", quant);
+  return DSK_OK;
+}
+
+int gemv_launch(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& h) {
+  switch (h.quant) {
+    case DSK_QUANT_F32: return launch_q<DSK_QUANT_F32>(st, dev, h);
+    case DSK_QUANT_F16: return launch_q<DSK_QUANT_F16>(st, dev, h);
+    case DSK_QUANT_F8E5M2: return launch_q<DSK_QUANT_F8E5M2>(st, dev, h);
+    case DSK_QUANT_Q2_K: return launch_q<DSK_QUANT_Q2_K>(st, dev, h);
+    case DSK_QUANT_Q3_K: return launch_q<DSK_QUANT_Q3_K>(st, dev, h);
+  }
+  DSK_FAIL(DSK_ERR_INVALID, "gemv: bad quant %d", h.quant);
+}
+
+// Decide lanes-per-row, rows-per-wave, grid and workgroup ranges.  `target_wgs` ~ a few per CU.
+int gemv_plan(GemvLaunch& h, int target_wgs) {
+  if (h.n_tasks < 1 || h.n_tasks > GEMV_MAX_TASKS) DSK_FAIL(DSK_ERR_INVALID, "gemv: %d tasks", h.n_tasks);
+  const bool kq = h.quant == DSK_QUANT_Q2_K || h.quant == DSK_QUANT_Q3_K;
+  const int epi = kq ? 64 : (h.quant == DSK_QUANT_F32 ? 4 : (h.quant == DSK_QUANT_F16 ? 8 : 16));
+  size_t lds_max = 0, lds_sum = 0;
+  long total_rows = 0;
+  double total_work = 0;
+  int min_items = 1 << 30;
+  for (int i = 0; i < h.n_tasks; ++i) {
+    GemvTask& T = h.t[i];
+    if (T.rows <= 0 || T.n <= 0) DSK_FAIL(DSK_ERR_INVALID, "gemv: empty shape %d x %d", T.rows, T.n);
+    if (kq && T.n % QK_K) DSK_FAIL(DSK_ERR_INVALID, "k-quant gemv: n=%d is not a multiple of 256 (quantizer.cpp:8)", T.n);
+    if (!kq && T.n % epi) DSK_FAIL(DSK_ERR_INVALID, "gemv: n=%d is not a multiple of %d (src/infer.cpp:169,246)", T.n, epi);
+    const size_t lds = kq ? (size_t)T.n + (size_t)(T.n / 256) * 36 : (size_t)T.n * 4;
+    lds_max = lds > lds_max ? lds : lds_max;
+    lds_sum += (lds + 15) & ~(size_t)15;
+    total_rows += T.rows;
+    total_work += (double)T.rows * T.n * (h.glu ? 2 : 1);
+    min_items = T.n / epi < min_items ? T.n / epi : min_items;
+    if (h.mode == GEMV_MODE_ACCUM && T.rows != h.t[0].rows) DSK_FAIL(DSK_ERR_INVALID, "gemv accumulate: tasks must share the row count");
+  }
+  h.lds_bytes = h.mode == GEMV_MODE_ACCUM ? lds_sum : lds_max;
+  if (h.lds_bytes > 150 * 1024) DSK_FAIL(DSK_ERR_UNSUPPORTED, "gemv: activation vector(s) need %zu B of LDS", h.lds_bytes);
+  if (h.b0 < 1) h.b0 = 1;
+  if (h.b1 < 1) h.b1 = 1;
+  // lanes per row: the largest power of two <= 64 dividing every task's item count
+  int lpr = 64;
+  while (lpr > 1) {
+    bool ok = true;
+    for (int i = 0; i < h.n_tasks; ++i) ok = ok && ((h.t[i].n / epi) % lpr == 0);
+    if (ok) break;
+    lpr >>= 1;
+  }
+  if (h.force_lpr > 0) lpr = h.force_lpr;
+  const long rows_eff = h.mode == GEMV_MODE_ACCUM ? h.t[0].rows : (h.bd_heads > 0 ? (long)h.t[0].rows * h.bd_heads : total_rows);
+  h.lpr_log2 = ilog2(lpr);
+  // (R, U) variant.  Measured on MI355X (tools/kbench.py): occupancy beats per-wave unrolling --
+  // the GLU pair and the MoE accumulate are fastest at R = U = 1 (few VGPRs, 8 waves/SIMD), a plain
+  // GEMV gains a little from U = 4 (plain 32768x7168: 4.18 vs 3.97 TB/s).
+  const int its = (min_items + lpr - 1) / lpr;
+  h.R = 1;
+  h.U = 1;
+  if (!h.glu && h.mode != GEMV_MODE_ACCUM) h.U = its >= 4 ? 4 : (its >= 2 ? 2 : 1);
+  (void)rows_eff;
+  if (h.force_R > 0) h.R = h.force_R;
+  if (h.force_U > 0) h.U = h.force_U;
+  const int RG = 4 * (64 / lpr) * h.R;
+  if (h.mode == GEMV_MODE_ACCUM) {
+    const int n_groups = (h.t[0].rows + RG - 1) / RG;
+    h.grid = n_groups < target_wgs ? n_groups : target_wgs;
+    for (int i = 0; i < h.n_tasks; ++i) { h.t[i].wg_begin = 0; h.t[i].wg_end = h.grid; }
+    return DSK_OK;
+  }
+  if (h.bd_heads > 0) {
+    const int n_groups = (h.t[0].rows + RG - 1) / RG;
+    int per_head = target_wgs / h.bd_heads;
+    if (per_head < 1) per_head = 1;
+    if (per_head > n_groups) per_head = n_groups;
+    h.bd_wgs = per_head;
+    h.grid = per_head * h.bd_heads;
+    h.t[0].wg_begin = 0;
+    h.t[0].wg_end = h.grid;
+    return DSK_OK;
+  }
+  int wg = 0;
+  for (int i = 0; i < h.n_tasks; ++i) {
+    GemvTask& T = h.t[i];
+    const int n_groups = (T.rows + RG - 1) / RG;
+    int share = (int)(target_wgs * ((double)T.rows * T.n * (h.glu ? 2 : 1) / total_work) + 0.5);
+    if (share < 1) share = 1;
+    if (share > n_groups) share = n_groups;
+    T.wg_begin = wg;
+    wg += share;
+    T.wg_end = wg;
+  }
+  h.grid = wg;
+  return DSK_OK;
 }

@@ -309,58 +309,22 @@ int launch_embed(hipStream_t st, const DTensor& t, const StepParams* sp, int tok
 }
 
 // ------------------------------------------------------------------------------------
-// MoE router: F32 GEMV (src/infer.cpp:847, 121-157), split over K so that E = 256 rows still
-// fill the chip; partial[c][e] are summed in c order by the gate kernel (deterministic).
-// ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void router_kernel(const float* __restrict__ w, const float* __restrict__ x, int n_routed,
-                                                     int dim, float* __restrict__ partial, int ksplit) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (row >= n_routed) return;
-  const int c = blockIdx.y;
-  const int chunk = ((dim / 4 + ksplit - 1) / ksplit + 63) / 64 * 64 * 4;  // floats per K slice, multiple of 256
-  const int k0 = c * chunk, k1 = min(dim, k0 + chunk);
-  float acc = 0.f;
-  const float* wr = w + (size_t)row * dim;
-  for (int i = k0 + lane * 4; i < k1; i += 256) {
-    const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wr + i));
-    const f32x4 b = *reinterpret_cast<const f32x4*>(x + i);
-    acc = fmaf(a.x, b.x, acc);
-    acc = fmaf(a.y, b.y, acc);
-    acc = fmaf(a.z, b.z, acc);
-    acc = fmaf(a.w, b.w, acc);
-  }
-  acc = wave_sum(acc);
-  if (lane == 0) partial[(size_t)c * n_routed + row] = acc;
-}
-int launch_router(hipStream_t st, const float* w, const float* x, int n_routed, int dim, float* partial, int ksplit) {
-  if (dim % 4) DSK_FAIL(DSK_ERR_INVALID, "router: dim %% 4 != 0");
-  hipLaunchKernelGGL(router_kernel, dim3((n_routed + 3) / 4, ksplit), dim3(256), 0, st, w, x, n_routed, dim, partial, ksplit);
-  return DSK_OK;
-}
-
-// ------------------------------------------------------------------------------------
-// moe_gate: src/infer.cpp:493-599.  The reference's k rounds of "argmax over unmasked with
-// strict >" select experts in descending score order, lowest index first among equals; that
-// is the rank of e under the order (score desc, index asc), computed here by all E threads
-// in parallel: rank(e) = #{ j : s[j] > s[e] or (s[j] == s[e] and j < e) }.
+// MoE router + gate in ONE launch.
+// Router: F32 GEMV (src/infer.cpp:847, 121-157) over the FFN-normed x (the rmsnorm of
+// src/infer.cpp:839 is recomputed in every workgroup's prologue: 28 KB from L2), split over K so
+// that E = 256 rows still fill the chip; partial[c][e] are summed in c order (deterministic).
+// Gate: the LAST workgroup to arrive (agent-scope release -> relaxed counter -> acquire) runs
+// moe_gate, src/infer.cpp:493-599.  The reference's k rounds of "argmax over unmasked with strict >"
+// select experts in descending score order, lowest index first among equals; that is the rank of
+// e under the order (score desc, index asc), computed by all E threads in parallel:
+//   rank(e) = #{ j : s[j] > s[e] or (s[j] == s[e] and j < e) }.
 // Group-limited (:545-588): first keep the topk_group best of every group, then rank the
 // survivors globally.  Weights: x[e_k] / wsum * scaling with wsum accumulated in k order.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ partial, int ksplit, const float* __restrict__ bias,
-                                                   int E, int K, int norm_topk_prob, float scaling, int scoring, int topk_method,
-                                                   int n_group, int topk_group, int* __restrict__ active_experts,
-                                                   float* __restrict__ active_weights, float* __restrict__ scores_out) {
-  __shared__ float s[256];
-  __shared__ int surv[256];
-  __shared__ float scratch[4];
-  __shared__ int sel[256];
-  const int e = threadIdx.x;
-  float v = -INFINITY;
-  if (e < E) {
-    v = 0.f;
-    for (int c = 0; c < ksplit; ++c) v += partial[(size_t)c * E + e];
-  }
+DEV void gate_body(int e, float v, const float* __restrict__ bias, int E, int K, int norm_topk_prob, float scaling, int scoring,
+                   int topk_method, int n_group, int topk_group, int* __restrict__ active_experts,
+                   float* __restrict__ active_weights, float* __restrict__ scores_out, float* s, int* surv, int* sel, float* scratch) {
+  if (e >= E) v = -INFINITY;
   if (scoring == DSK_SCORE_SOFTMAX) {  // softmax, src/infer.cpp:472-487
     const float mx = block_max(v, scratch, e, 256);
     const float ex = e < E ? expf(v - mx) : 0.f;
@@ -370,22 +334,29 @@ __global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ par
     v = 1.0f / (1.0f + expf(-v));  // sigmoid, src/infer.cpp:489-491
   }
   if (bias && e < E) v += bias[e];
-  if (e < E) {
-    s[e] = v;
-    if (scores_out) scores_out[e] = v;
-  }
+  if (e >= E) v = -INFINITY;
+  s[e] = v;
+  if (e < E && scores_out) scores_out[e] = v;
   surv[e] = e < E ? 1 : 0;
   __syncthreads();
   if (topk_method == DSK_TOPK_GROUP_LIMITED_GREEDY && e < E) {
     const int gs = E / n_group, g0 = (e / gs) * gs;
     int rank = 0;
     for (int j = g0; j < g0 + gs; ++j) rank += (s[j] > v || (s[j] == v && j < e)) ? 1 : 0;
-    surv[e] = rank < topk_group ? 1 : 0;
+    surv[e] = rank < topk_group ? 1 : 0;  // only s[] is read above: no hazard with this write
   }
   __syncthreads();
   if (e < E && surv[e]) {
     int rank = 0;
-    for (int j = 0; j < E; ++j) rank += (surv[j] && (s[j] > v || (s[j] == v && j < e))) ? 1 : 0;
+#pragma unroll 4
+    for (int j0 = 0; j0 < 256; j0 += 4) {  // s/surv are padded to 256 entries (-inf / 0)
+      const f32x4 sv = *reinterpret_cast<const f32x4*>(s + j0);
+      const u32x4 mk = *reinterpret_cast<const u32x4*>(surv + j0);
+      rank += (mk.x && (sv.x > v || (sv.x == v && j0 + 0 < e))) ? 1 : 0;
+      rank += (mk.y && (sv.y > v || (sv.y == v && j0 + 1 < e))) ? 1 : 0;
+      rank += (mk.z && (sv.z > v || (sv.z == v && j0 + 2 < e))) ? 1 : 0;
+      rank += (mk.w && (sv.w > v || (sv.w == v && j0 + 3 < e))) ? 1 : 0;
+    }
     if (rank < K) sel[rank] = e;
   }
   __syncthreads();
@@ -399,6 +370,22 @@ __global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ par
     }
   }
 }
+
+__global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ partial, int ksplit, const float* __restrict__ bias,
+                                                   int E, int K, int norm_topk_prob, float scaling, int scoring, int topk_method,
+                                                   int n_group, int topk_group, int* __restrict__ active_experts,
+                                                   float* __restrict__ active_weights, float* __restrict__ scores_out) {
+  __shared__ __attribute__((aligned(16))) float s[256];
+  __shared__ __attribute__((aligned(16))) int surv[256];
+  __shared__ float scratch[4];
+  __shared__ int sel[256];
+  const int e = threadIdx.x;
+  float v = 0.f;
+  if (e < E)
+    for (int c = 0; c < ksplit; ++c) v += partial[(size_t)c * E + e];
+  gate_body(e, v, bias, E, K, norm_topk_prob, scaling, scoring, topk_method, n_group, topk_group, active_experts, active_weights,
+            scores_out, s, surv, sel, scratch);
+}
 int launch_gate(hipStream_t st, const float* partial, int ksplit, const float* bias, int n_routed, int n_active,
                 int norm_topk_prob, float scaling, int scoring, int topk_method, int n_group, int topk_group,
                 int* active_experts, float* active_weights, float* scores_out) {
@@ -408,6 +395,86 @@ int launch_gate(hipStream_t st, const float* partial, int ksplit, const float* b
     DSK_FAIL(DSK_ERR_INVALID, "moe_gate: bad group config (E=%d, n_group=%d, topk_group=%d, k=%d)", n_routed, n_group, topk_group, n_active);
   hipLaunchKernelGGL(gate_kernel, dim3(1), dim3(256), 0, st, partial, ksplit, bias, n_routed, n_active, norm_topk_prob, scaling,
                      scoring, topk_method, n_group, topk_group, active_experts, active_weights, scores_out);
+  return DSK_OK;
+}
+
+__global__ __launch_bounds__(256) void router_gate_kernel(RouterArgs a) {
+  __shared__ __attribute__((aligned(16))) float s[256];
+  __shared__ __attribute__((aligned(16))) int surv[256];
+  __shared__ float scratch[4];
+  __shared__ int sel[256];
+  __shared__ int is_last;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int row = blockIdx.x * 4 + (tid >> 6);
+  const int c = blockIdx.y, dim = a.dim, E = a.n_routed;
+  float scale = 1.0f;
+  if (a.norm_w) {  // rmsnorm of the residual stream (src/infer.cpp:839, 601-611), once per workgroup
+    float ss = 0.f;
+    for (int i = tid * 4; i < dim; i += 1024) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + i);
+      ss = fmaf(v.x, v.x, ss);
+      ss = fmaf(v.y, v.y, ss);
+      ss = fmaf(v.z, v.z, ss);
+      ss = fmaf(v.w, v.w, ss);
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) scratch[tid >> 6] = ss;
+    __syncthreads();
+    const float total = (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+    scale = 1.0f / sqrtf(total / (float)dim + a.eps);
+    __syncthreads();
+  }
+  if (row < E) {
+    const int chunk = ((dim / 4 + a.ksplit - 1) / a.ksplit + 63) / 64 * 64 * 4;  // floats per K slice, multiple of 256
+    const int k0 = c * chunk, k1 = min(dim, k0 + chunk);
+    float acc = 0.f;
+    const float* wr = a.w + (size_t)row * dim;
+    for (int i = k0 + lane * 4; i < k1; i += 256) {
+      const f32x4 wv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wr + i));
+      f32x4 xv = *reinterpret_cast<const f32x4*>(a.x + i);
+      if (a.norm_w) {
+        const f32x4 nw = *reinterpret_cast<const f32x4*>(a.norm_w + i);
+        xv.x = xv.x * scale * nw.x;
+        xv.y = xv.y * scale * nw.y;
+        xv.z = xv.z * scale * nw.z;
+        xv.w = xv.w * scale * nw.w;
+      }
+      acc = fmaf(wv.x, xv.x, acc);
+      acc = fmaf(wv.y, xv.y, acc);
+      acc = fmaf(wv.z, xv.z, acc);
+      acc = fmaf(wv.w, xv.w, acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) a.partial[(size_t)c * E + row] = acc;
+  }
+  // ---- publish the partials; the last workgroup to arrive runs the gate ----
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned total = gridDim.x * gridDim.y;
+    const unsigned old = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = old == total - 1;
+    if (is_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  if (!is_last) return;
+  if (tid == 0) __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
+  float v = 0.f;
+  if (tid < E)
+    for (int cc = 0; cc < a.ksplit; ++cc)
+      v += __hip_atomic_load(a.partial + (size_t)cc * E + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  gate_body(tid, v, a.bias, E, a.n_active, a.norm_topk_prob, a.scaling, a.scoring, a.topk_method, a.n_group, a.topk_group,
+            a.active_experts, a.active_weights, a.scores_out, s, surv, sel, scratch);
+}
+int launch_router_gate(hipStream_t st, const RouterArgs& a) {
+  if (a.dim % 4) DSK_FAIL(DSK_ERR_INVALID, "router: dim %% 4 != 0");
+  if (a.n_routed > 256) DSK_FAIL(DSK_ERR_UNSUPPORTED, "moe_gate: more than 256 routed experts (src/infer.cpp:527)");
+  if (a.n_active > a.n_routed) DSK_FAIL(DSK_ERR_INVALID, "moe_gate: n_active > n_routed");
+  if (a.topk_method == DSK_TOPK_GROUP_LIMITED_GREEDY && (a.n_group <= 0 || a.n_routed % a.n_group || a.topk_group * a.n_group < a.n_active))
+    DSK_FAIL(DSK_ERR_INVALID, "moe_gate: bad group config (E=%d, n_group=%d, topk_group=%d, k=%d)", a.n_routed, a.n_group, a.topk_group, a.n_active);
+  hipLaunchKernelGGL(router_gate_kernel, dim3((a.n_routed + 3) / 4, a.ksplit), dim3(256), 0, st, a);
   return DSK_OK;
 }
 

@@ -7,6 +7,7 @@
 #include <math.h>
 #include <string.h>
 #include <algorithm>
+#include <vector>
 
 namespace {
 struct DevBuf {  // small RAII device allocation for one call
@@ -103,23 +104,21 @@ static int gemv_common(dsk_ctx* ctx, int quant, const void* w, size_t w_bytes, c
   DSK_TRY(dx.alloc((size_t)n * 4));
   DSK_TRY(dout.alloc((size_t)d * 4));
   HIP_TRY(hipMemcpyAsync(dx.p, x, (size_t)n * 4, hipMemcpyHostToDevice, st));
-  GemvSeg s;
-  memset(&s, 0, sizeof s);
-  s.qs = t.qs; s.sc = t.sc; s.hm = t.hm; s.dm = t.dm; s.scale = dsc;
-  s.rows = d; s.n = n; s.n_slots = 1; s.local_experts = 1;
-  s.b0 = b0; s.b1 = b1; s.sc_cols = cdiv(n, b1);
-  s.out = dout.as<float>();
-  s.epilogue = EPI_STORE;
-  if (is_kq(quant)) {  // quantize_acts then matmul_w2a8 / w3a8 (src/infer.cpp:327-345)
-    DSK_TRY(dq.alloc(n));
-    DSK_TRY(dd.alloc((size_t)n / 256 * 4));
-    DSK_TRY(db.alloc((size_t)n / 16 * 2));
-    DSK_TRY(launch_quantize_q8k(st, dx.as<float>(), n, dq.as<int8_t>(), dd.as<float>(), db.as<int16_t>()));
-    s.a_qs = dq.as<int8_t>(); s.a_d = dd.as<float>(); s.a_bsums = db.as<int16_t>();
-  } else {
-    s.a_f32 = dx.as<float>();
-  }
-  DSK_TRY(launch_gemv(st, quant, s));
+  // one-task launch of the same kernel the token step uses; the Q8_K quantisation of x
+  // (quantize_acts, src/infer.cpp:327-337) happens in the kernel prologue (ACT_F32)
+  GemvLaunch h;
+  memset(&h, 0, sizeof h);
+  h.quant = quant; h.mode = GEMV_MODE_TASKS; h.n_tasks = 1; h.b0 = b0; h.b1 = b1;
+  GemvTask& T = h.t[0];
+  T.qs = t.qs; T.sc = t.sc; T.hm = t.hm; T.dm = t.dm; T.scale = dsc;
+  T.rows = d; T.n = n; T.local_experts = 1;
+  T.act_mode = ACT_F32; T.a_f32 = dx.as<float>();
+  T.out = dout.as<float>(); T.epilogue = EPI_STORE;
+  DSK_TRY(gemv_plan(h, 1024));
+  DevBuf dh;
+  DSK_TRY(dh.alloc(sizeof h));
+  HIP_TRY(hipMemcpyAsync(dh.p, &h, sizeof h, hipMemcpyHostToDevice, st));
+  DSK_TRY(gemv_launch(st, dh.as<GemvLaunch>(), h));
   HIP_TRY(hipMemcpyAsync(out, dout.p, (size_t)d * 4, hipMemcpyDeviceToHost, st));
   return finish(ctx);
 }
@@ -288,5 +287,81 @@ extern "C" int dsk_measure_read_bw(dsk_ctx* ctx, size_t bytes, int iters, double
   hipEventDestroy(e0);
   hipEventDestroy(e1);
   *gbps_out = best;
+  return finish(ctx);
+}
+
+// ------------------------------------------------------------------------------------
+// micro-benchmark of the GEMV kernel on device-resident synthetic weights (diagnostics; used by
+// tools/kbench.py to pick launch geometry).  kind: 0 plain, 1 GLU pair, 2 MoE accumulate.
+// Weight sets are rotated through > 512 MB so that the 256 MB Infinity Cache cannot serve them.
+// ------------------------------------------------------------------------------------
+extern "C" int dsk_bench_gemv(dsk_ctx* ctx, int quant, int rows, int n, int n_tasks, int kind, int act_mode, int force_lpr,
+                              int force_R, int force_U, int target_wgs, int iters, double* us_per_launch, double* bytes_per_launch) {
+  DSK_TRY(begin(ctx));
+  if (!us_per_launch || !bytes_per_launch || n_tasks < 1 || n_tasks > GEMV_MAX_TASKS || iters < 1) DSK_FAIL(DSK_ERR_INVALID, "bench_gemv: bad argument");
+  hipStream_t st = ctx_stream(ctx);
+  const int mats = n_tasks * (kind == 1 ? 2 : 1);
+  const double wbytes = (double)mat_bytes(quant, rows, n) * mats;
+  int copies = (int)(600e6 / wbytes) + 1;
+  if (copies > 48) copies = 48;
+  if (copies < 2) copies = 2;
+  std::vector<TensorGuard> W((size_t)copies * mats);
+  for (size_t i = 0; i < W.size(); ++i) {
+    DSK_TRY(alloc_tensor(128, 128, W[i].t, quant, 0, rows, n, 1, 0));
+    DSK_TRY(launch_fill_tensor(st, W[i].t, 1234 + i, 1.0f / sqrtf((float)n)));
+  }
+  DevBuf x, nw, out, q8, wts, plans;
+  DSK_TRY(x.alloc((size_t)n * n_tasks * 4));
+  DSK_TRY(nw.alloc((size_t)n * 4));
+  DSK_TRY(out.alloc((size_t)rows * n_tasks * 4));
+  DSK_TRY(q8.alloc((size_t)n * 2));
+  DSK_TRY(wts.alloc(64));
+  DSK_TRY(launch_fill_f32(st, x.as<float>(), (size_t)n * n_tasks, 7, 0.f, 1.f));
+  DSK_TRY(launch_fill_f32(st, nw.as<float>(), (size_t)n, 8, 1.f, 0.1f));
+  DSK_TRY(launch_fill_f32(st, wts.as<float>(), 16, 9, 1.f, 0.1f));
+  HIP_TRY(hipMemsetAsync(out.p, 0, (size_t)rows * n_tasks * 4, st));
+  int8_t* aq = q8.as<int8_t>();
+  float* ad = reinterpret_cast<float*>(aq + n);
+  int16_t* ab = reinterpret_cast<int16_t*>(aq + n + (n / 256 + 4) * 4);
+  if (is_kq(quant)) DSK_TRY(launch_quantize_q8k(st, x.as<float>(), n, aq, ad, ab));
+  std::vector<GemvLaunch> H(copies);
+  for (int c = 0; c < copies; ++c) {
+    GemvLaunch& h = H[c];
+    memset(&h, 0, sizeof h);
+    h.quant = quant; h.mode = kind == 2 ? GEMV_MODE_ACCUM : GEMV_MODE_TASKS; h.glu = kind == 1; h.act = DSK_ACT_SILU;
+    h.b0 = h.b1 = 128; h.force_lpr = force_lpr; h.force_R = force_R; h.force_U = force_U;
+    for (int i = 0; i < n_tasks; ++i) {
+      GemvTask& T = h.t[h.n_tasks++];
+      const DTensor& t = W[(size_t)c * mats + i * (kind == 1 ? 2 : 1)].t;
+      T.qs = t.qs; T.sc = t.sc; T.hm = t.hm; T.dm = t.dm; T.scale = t.scale; T.rows = rows; T.n = n; T.local_experts = 1;
+      if (kind == 1) {
+        const DTensor& t3 = W[(size_t)c * mats + i * 2 + 1].t;
+        T.qs2 = t3.qs; T.sc2 = t3.sc; T.hm2 = t3.hm; T.dm2 = t3.dm; T.scale2 = t3.scale;
+      }
+      T.act_mode = act_mode;
+      if (act_mode == ACT_Q8) { T.a_qs = aq; T.a_d = ad; T.a_bsums = ab; }
+      T.a_f32 = x.as<float>() + (kind == 2 ? (size_t)i * n : 0);
+      T.norm_w = nw.as<float>(); T.eps = 1e-6f;
+      T.out = kind == 2 ? out.as<float>() : out.as<float>() + (size_t)i * rows;
+      T.accum_w = kind == 2 ? wts.as<float>() + i : nullptr;
+    }
+    DSK_TRY(gemv_plan(h, target_wgs > 0 ? target_wgs : 1024));
+  }
+  DSK_TRY(plans.alloc(sizeof(GemvLaunch) * copies));
+  HIP_TRY(hipMemcpyAsync(plans.p, H.data(), sizeof(GemvLaunch) * copies, hipMemcpyHostToDevice, st));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  for (int c = 0; c < copies; ++c) DSK_TRY(gemv_launch(st, plans.as<GemvLaunch>() + c, H[c]));  // warm-up
+  HIP_TRY(hipEventRecord(e0, st));
+  for (int i = 0; i < iters; ++i) DSK_TRY(gemv_launch(st, plans.as<GemvLaunch>() + (i % copies), H[i % copies]));
+  HIP_TRY(hipEventRecord(e1, st));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  *us_per_launch = (double)ms * 1e3 / iters;
+  *bytes_per_launch = wbytes;
   return finish(ctx);
 }

@@ -119,6 +119,7 @@ def lib():
         L.dsk_attn_mla.argtypes = [C.c_void_p, c_f, c_f, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, c_f]
         L.dsk_measure_read_bw.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
+        L.dsk_bench_gemv.argtypes = [C.c_void_p] + [C.c_int] * 11 + [C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _lib = L
     return _lib
 
@@ -221,6 +222,13 @@ class Ctx:
         check(lib().dsk_attn_mla(self.h, _f(q_c), _f(q_rope), ckv.ctypes.data, krope.ctypes.data, n_heads, head_dim,
                                  lora, rope, kv_len, _f(out)))
         return out
+
+    def bench_gemv(self, quant, rows, n, n_tasks=1, kind=0, act_mode=0, lpr=0, R=0, U=0, target_wgs=0, iters=50):
+        """-> (us per launch, weight bytes per launch)"""
+        us, nb = C.c_double(), C.c_double()
+        check(lib().dsk_bench_gemv(self.h, quant, rows, n, n_tasks, kind, act_mode, lpr, R, U, target_wgs, iters,
+                                   C.byref(us), C.byref(nb)))
+        return us.value, nb.value
 
     def measure_read_bw(self, nbytes=8 << 30, iters=5) -> float:
         out = C.c_double()

@@ -235,6 +235,14 @@ int dsk_attn_mla(dsk_ctx* ctx, const float* q_c, const float* q_rope, const uint
  * (SURVEY 8d "measured roofline" denominator).  Best of `iters`. */
 int dsk_measure_read_bw(dsk_ctx* ctx, size_t bytes, int iters, double* gbps_out);
 
+/* Diagnostics: time the GEMV kernel on device-resident synthetic weights (rotated through > 512 MB
+ * so that the Infinity Cache cannot serve them).  kind: 0 plain, 1 GLU pair, 2 MoE accumulate over
+ * n_tasks slots; act_mode: 0 ready Q8_K, 1 f32 (quantised in the prologue), 2 f32 + RMSNorm.
+ * force_* > 0 override the launch planner (lanes per row, rows per lane group, column steps). */
+int dsk_bench_gemv(dsk_ctx* ctx, int quant, int rows, int n, int n_tasks, int kind, int act_mode,
+                   int force_lpr, int force_R, int force_U, int target_wgs, int iters,
+                   double* us_per_launch, double* bytes_per_launch);
+
 #ifdef __cplusplus
 }
 #endif
