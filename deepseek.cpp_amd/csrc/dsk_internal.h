@@ -103,6 +103,11 @@ struct GemvLaunch {
   // `bd_heads` equal (rows, n) matrices stacked along rows; head h reads activation a_f32 + h*n and
   // writes out + h*rows; bd_wgs workgroups per head
   int bd_heads, bd_wgs;
+  // MoE combine folded into a TASKS launch (tasks = routed slots in k order, then the shared expert;
+  // every task writes its own vector t[i].out): the LAST task to finish a row group (arrival counter
+  // per group) runs  x[row] += w_k * out_k[row]  in k order, then + shared (src/infer.cpp:874-877,900-903)
+  float* comb_x;
+  unsigned* comb_counter;
   size_t lds_bytes;
   double algo_bytes;          // host-side bookkeeping for the roofline report
 };
@@ -159,6 +164,7 @@ struct RouterArgs {       // F32 router GEMV (+ optional rmsnorm prologue) + moe
   int* active_experts;
   float* active_weights;
   float* scores_out;
+  int dbg;                // micro-benchmark only: 1 = skip the gate, 2 = skip the weight stream, 4 = skip the norm
 };
 int launch_router_gate(hipStream_t st, const RouterArgs& a);
 int launch_gate(hipStream_t st, const float* partial, int ksplit, const float* bias, int n_routed, int n_active,

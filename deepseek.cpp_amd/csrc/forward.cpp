@@ -242,28 +242,7 @@ int build_plans(dsk_model* m) {
       h.algo_bytes = bytes;
       DSK_TRY(add_plan(m, h, &m->lp_w13[l]));
     }
-    if (m->ctx->world == 1) {  // 9. accumulate: x += w_k * W2_k h_k (k order), then shared
-      GemvLaunch h;
-      memset(&h, 0, sizeof h);
-      h.quant = wq; h.mode = GEMV_MODE_ACCUM;
-      for (int k = 0; k < K; ++k) {
-        GemvTask& T = h.t[h.n_tasks++];
-        task_weights(T, w2);
-        task_expert(T, w2, ae, k);
-        task_act_hb(m, T, l, (size_t)k * hb_stride);
-        T.out = m->x; T.accum_w = aw + k;
-      }
-      double bytes = K * (e2 + 4.0 * mi) + 8.0 * c.dim;
-      if (c.n_shared_experts > 0) {
-        GemvTask& T = h.t[h.n_tasks++];
-        task_weights(T, L.t[DSK_ROLE_SHARED_W2]);
-        task_act_hb(m, T, l, (size_t)K * hb_stride);
-        T.out = m->x; T.accum_w = nullptr;
-        bytes += weight_bytes_2d(m, wq, c.dim, shared_n) + 4.0 * shared_n;
-      }
-      h.algo_bytes = bytes;
-      DSK_TRY(add_plan(m, h, &m->lp_w2[l]));
-    } else {  // expert-sharded: per-slot outputs -> all-reduce -> combine (bit-identical to 1 GPU)
+    {  // 9. per-slot W2 into eout[slot]; 1 GPU: the combine rides in the same launch; sharded: all-reduce first
       GemvLaunch h;
       memset(&h, 0, sizeof h);
       h.quant = wq; h.mode = GEMV_MODE_TASKS;
@@ -272,7 +251,7 @@ int build_plans(dsk_model* m) {
         task_weights(T, w2);
         task_expert(T, w2, ae, k);
         task_act_hb(m, T, l, (size_t)k * hb_stride);
-        T.out = m->eout + (size_t)k * c.dim; T.epilogue = EPI_STORE;
+        T.out = m->eout + (size_t)k * c.dim; T.epilogue = EPI_STORE; T.accum_w = aw + k;
       }
       double bytes = K * (e2 + 4.0 * mi + 4.0 * c.dim);
       if (c.n_shared_experts > 0) {
@@ -282,6 +261,7 @@ int build_plans(dsk_model* m) {
         T.out = m->eout + (size_t)K * c.dim; T.epilogue = EPI_STORE;
         bytes += weight_bytes_2d(m, wq, c.dim, shared_n) + 4.0 * shared_n + 4.0 * c.dim;
       }
+      if (m->ctx->world == 1) { h.comb_x = m->x; h.comb_counter = m->comb_counter; }
       h.algo_bytes = bytes;
       DSK_TRY(add_plan(m, h, &m->lp_w2[l]));
     }

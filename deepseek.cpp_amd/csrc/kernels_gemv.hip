@@ -666,6 +666,7 @@ template <int QT, int R, int U, bool GLU, int MODE>
 __global__ __launch_bounds__(256) void gemv_kernel(const GemvLaunch* __restrict__ Lp) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ float scratch[4];
+  __shared__ bool comb_last;
   const GemvLaunch& L = *Lp;
   constexpr bool KQ = QT == DSK_QUANT_Q2_K || QT == DSK_QUANT_Q3_K;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -724,8 +725,44 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvLaunch* __restrict_
     if (KQ) stage_q8(T, smem, reinterpret_cast<short*>(smem + T.n), reinterpret_cast<float*>(smem + T.n + (T.n >> 8) * 32), tid, scratch);
     else stage_f32(T, reinterpret_cast<float*>(smem), tid, scratch);
     __syncthreads();
+    const bool comb = !GLU && L.comb_x != nullptr;
     for (int g = wi; g < n_groups; g += nwg) {
       if (g != wi) has_rows = rows_of(g, row, valid);
+      if (comb) {
+        // ---- fused MoE combine: slot vectors go out write-through (sc1), then one arrival per task ----
+        if (has_rows) {
+          float acc[R], acc2[R];
+          rows_dot<QT, R, U, GLU>(c, false, P, T.n, L.b0, L.b1, lpr_log2, lane, row, smem, acc, acc2);
+          if (sub == 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+              if (valid[r]) __hip_atomic_store(T.out + row[r], acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+          const unsigned old = __hip_atomic_fetch_add(L.comb_counter + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          comb_last = old == (unsigned)L.n_tasks - 1;
+          if (comb_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(L.comb_counter + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+          }
+        }
+        __syncthreads();
+        if (comb_last) {  // all slots of these rows have landed: x += w_k * out_k (k order), then + shared
+          for (int rr = g * RG + tid; rr < min(T.rows, (g + 1) * RG); rr += 256) {
+            float xv = L.comb_x[rr];
+            for (int ti = 0; ti < L.n_tasks; ++ti) {
+              const float v = __hip_atomic_load(L.t[ti].out + rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (L.t[ti].accum_w) xv = fmaf(v, *L.t[ti].accum_w, xv);  // src/infer.cpp:874-877
+              else xv += v;                                             // src/infer.cpp:900-903
+            }
+            L.comb_x[rr] = xv;
+          }
+        }
+        continue;
+      }
       if (!has_rows) continue;
       float acc[R], acc2[R];
       rows_dot<QT, R, U, GLU>(c, false, P, T.n, L.b0, L.b1, lpr_log2, lane, row, smem, acc, acc2);
@@ -779,6 +816,9 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvLaunch* __restrict_
       }
     }
     __syncthreads();
+    // slots are walked one after the other with ONE register chunk (a 12-way unrolled variant that
+    // requested all slots' weights up front was 4x slower: ~100 KB of code thrashes the instruction
+    // cache); memory-level parallelism comes from the ~6 waves per SIMD this small kernel allows
     typename ChunkOf<QT, R, U, false>::type c;
     for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
       const int row0 = g * RG + wave * (RPW * R);
@@ -833,11 +873,7 @@ static int ilog2(int v) {
 template <int QT, int R, int U>
 static void launch_one(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& h) {
   dim3 grid(h.grid), block(256);
-  if (h.mode == GEMV_MODE_ACCUM) {
-    auto k = gemv_kernel<QT, R, U, false, GEMV_MODE_ACCUM>;
-    if (h.lds_bytes > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds_bytes);
-    hipLaunchKernelGGL(k, grid, block, h.lds_bytes, st, dev);
-  } else if (h.glu) {
+  if (h.glu) {
     auto k = gemv_kernel<QT, R, U, true, GEMV_MODE_TASKS>;
     if (h.lds_bytes > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds_bytes);
     hipLaunchKernelGGL(k, grid, block, h.lds_bytes, st, dev);
@@ -848,7 +884,17 @@ static void launch_one(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& 
   }
 }
 template <int QT>
+static void launch_accum(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& h) {  // always R = U = 1
+  auto k = gemv_kernel<QT, 1, 1, false, GEMV_MODE_ACCUM>;
+  if (h.lds_bytes > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds_bytes);
+  hipLaunchKernelGGL(k, dim3(h.grid), dim3(256), h.lds_bytes, st, dev);
+}
+template <int QT>
 static int launch_q(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& h) {
+  if (h.mode == GEMV_MODE_ACCUM) {
+    launch_accum<QT>(st, dev, h);
+    return DSK_OK;
+  }
   // (R, U) variants: R rows x U column steps = the 16-byte loads a lane keeps in flight
   switch (h.R * 16 + h.U) {
     case 1 * 16 + 8: launch_one<QT, 1, 8>(st, dev, h); break;
@@ -923,10 +969,12 @@ int gemv_plan(GemvLaunch& h, int target_wgs) {
   (void)rows_eff;
   if (h.force_R > 0) h.R = h.force_R;
   if (h.force_U > 0) h.U = h.force_U;
+  if (h.mode == GEMV_MODE_ACCUM) h.R = h.U = 1;
   const int RG = 4 * (64 / lpr) * h.R;
   if (h.mode == GEMV_MODE_ACCUM) {
     const int n_groups = (h.t[0].rows + RG - 1) / RG;
-    h.grid = n_groups < target_wgs ? n_groups : target_wgs;
+    int per = (n_groups + target_wgs - 1) / target_wgs;  // groups per workgroup, balanced
+    h.grid = (n_groups + per - 1) / per;
     for (int i = 0; i < h.n_tasks; ++i) { h.t[i].wg_begin = 0; h.t[i].wg_end = h.grid; }
     return DSK_OK;
   }
@@ -948,6 +996,7 @@ int gemv_plan(GemvLaunch& h, int target_wgs) {
     int share = (int)(target_wgs * ((double)T.rows * T.n * (h.glu ? 2 : 1) / total_work) + 0.5);
     if (share < 1) share = 1;
     if (share > n_groups) share = n_groups;
+    share = (n_groups + (n_groups + share - 1) / share - 1) / ((n_groups + share - 1) / share);  // equal groups per workgroup
     T.wg_begin = wg;
     wg += share;
     T.wg_end = wg;

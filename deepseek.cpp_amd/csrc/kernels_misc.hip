@@ -323,7 +323,9 @@ int launch_embed(hipStream_t st, const DTensor& t, const StepParams* sp, int tok
 // ------------------------------------------------------------------------------------
 DEV void gate_body(int e, float v, const float* __restrict__ bias, int E, int K, int norm_topk_prob, float scaling, int scoring,
                    int topk_method, int n_group, int topk_group, int* __restrict__ active_experts,
-                   float* __restrict__ active_weights, float* __restrict__ scores_out, float* s, int* surv, int* sel, float* scratch) {
+                   float* __restrict__ active_weights, float* __restrict__ scores_out, float* s, int* ci, int* sel, float* scratch) {
+  // s[256]: scores; cs (aliases scratch area passed as `s + 256`) / ci[256]: compacted candidates
+  float* cs = s + 256;
   if (e >= E) v = -INFINITY;
   if (scoring == DSK_SCORE_SOFTMAX) {  // softmax, src/infer.cpp:472-487
     const float mx = block_max(v, scratch, e, 256);
@@ -337,36 +339,66 @@ DEV void gate_body(int e, float v, const float* __restrict__ bias, int E, int K,
   if (e >= E) v = -INFINITY;
   s[e] = v;
   if (e < E && scores_out) scores_out[e] = v;
-  surv[e] = e < E ? 1 : 0;
+  cs[e] = -INFINITY;
+  ci[e] = 0x7fffffff;
   __syncthreads();
-  if (topk_method == DSK_TOPK_GROUP_LIMITED_GREEDY && e < E) {
-    const int gs = E / n_group, g0 = (e / gs) * gs;
-    int rank = 0;
-    for (int j = g0; j < g0 + gs; ++j) rank += (s[j] > v || (s[j] == v && j < e)) ? 1 : 0;
-    surv[e] = rank < topk_group ? 1 : 0;  // only s[] is read above: no hazard with this write
-  }
-  __syncthreads();
-  if (e < E && surv[e]) {
-    int rank = 0;
-#pragma unroll 4
-    for (int j0 = 0; j0 < 256; j0 += 4) {  // s/surv are padded to 256 entries (-inf / 0)
-      const f32x4 sv = *reinterpret_cast<const f32x4*>(s + j0);
-      const u32x4 mk = *reinterpret_cast<const u32x4*>(surv + j0);
-      rank += (mk.x && (sv.x > v || (sv.x == v && j0 + 0 < e))) ? 1 : 0;
-      rank += (mk.y && (sv.y > v || (sv.y == v && j0 + 1 < e))) ? 1 : 0;
-      rank += (mk.z && (sv.z > v || (sv.z == v && j0 + 2 < e))) ? 1 : 0;
-      rank += (mk.w && (sv.w > v || (sv.w == v && j0 + 3 < e))) ? 1 : 0;
+  // candidates, compacted: a wave64 VALU op takes 4 cycles, so the serial compare loops below are the
+  // critical path of the whole launch -- they must run over the candidates only, not over all E
+  int ncand = E;
+  if (topk_method == DSK_TOPK_GROUP_LIMITED_GREEDY) {
+    const int gs = E / n_group, tg = topk_group < gs ? topk_group : gs;
+    ncand = n_group * tg;
+    if (e < E) {
+      const int g = e / gs, g0 = g * gs;
+      int rank = 0;
+      for (int j = g0; j < g0 + gs; ++j) {
+        const float sj = s[j];
+        rank += (sj > v || (sj == v && j < e)) ? 1 : 0;
+      }
+      if (rank < tg) {  // survivor: (group, in-group rank) is a unique slot
+        cs[g * tg + rank] = v;
+        ci[g * tg + rank] = e;
+      }
     }
-    if (rank < K) sel[rank] = e;
+  } else if (e < E) {
+    cs[e] = v;
+    ci[e] = e;
   }
   __syncthreads();
-  if (e == 0) {
+  if (e < ncand) {
+    const float v2 = cs[e];
+    const int i2 = ci[e];
+    int rank = 0;
+    for (int j0 = 0; j0 < ncand; j0 += 4) {  // arrays are padded with (-inf, INT_MAX) up to 256
+      const f32x4 sv = *reinterpret_cast<const f32x4*>(cs + j0);
+      const u32x4 iv = *reinterpret_cast<const u32x4*>(ci + j0);
+      rank += (sv.x > v2 || (sv.x == v2 && (int)iv.x < i2)) ? 1 : 0;
+      rank += (sv.y > v2 || (sv.y == v2 && (int)iv.y < i2)) ? 1 : 0;
+      rank += (sv.z > v2 || (sv.z == v2 && (int)iv.z < i2)) ? 1 : 0;
+      rank += (sv.w > v2 || (sv.w == v2 && (int)iv.w < i2)) ? 1 : 0;
+    }
+    if (rank < K && i2 < E) sel[rank] = i2;
+  }
+  __syncthreads();
+  if (K > 64) {  // (never the case for a DeepSeek config; kept for the op-level entry point)
+    if (e == 0) {
+      float wsum = 0.f;
+      for (int k = 0; k < K; ++k) wsum += s[sel[k]];
+      if (!norm_topk_prob) wsum = 1.0f;
+      for (int k = 0; k < K; ++k) {
+        active_experts[k] = sel[k];
+        active_weights[k] = s[sel[k]] / wsum * scaling;
+      }
+    }
+  } else if (e < 64) {  // weights: x[e_k] / wsum * scaling, wsum accumulated in k order (src/infer.cpp:590-598)
+    const int ek = e < K ? sel[e] : 0;
+    const float sk = e < K ? s[ek] : 0.f;
     float wsum = 0.f;
-    for (int k = 0; k < K; ++k) wsum += s[sel[k]];
+    for (int k = 0; k < K; ++k) wsum += __shfl(sk, k);
     if (!norm_topk_prob) wsum = 1.0f;
-    for (int k = 0; k < K; ++k) {
-      active_experts[k] = sel[k];
-      active_weights[k] = s[sel[k]] / wsum * scaling;
+    if (e < K) {
+      active_experts[e] = ek;
+      active_weights[e] = sk / wsum * scaling;
     }
   }
 }
@@ -375,7 +407,7 @@ __global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ par
                                                    int E, int K, int norm_topk_prob, float scaling, int scoring, int topk_method,
                                                    int n_group, int topk_group, int* __restrict__ active_experts,
                                                    float* __restrict__ active_weights, float* __restrict__ scores_out) {
-  __shared__ __attribute__((aligned(16))) float s[256];
+  __shared__ __attribute__((aligned(16))) float s[512];
   __shared__ __attribute__((aligned(16))) int surv[256];
   __shared__ float scratch[4];
   __shared__ int sel[256];
@@ -399,7 +431,7 @@ int launch_gate(hipStream_t st, const float* partial, int ksplit, const float* b
 }
 
 __global__ __launch_bounds__(256) void router_gate_kernel(RouterArgs a) {
-  __shared__ __attribute__((aligned(16))) float s[256];
+  __shared__ __attribute__((aligned(16))) float s[512];
   __shared__ __attribute__((aligned(16))) int surv[256];
   __shared__ float scratch[4];
   __shared__ int sel[256];
@@ -408,14 +440,21 @@ __global__ __launch_bounds__(256) void router_gate_kernel(RouterArgs a) {
   const int row = blockIdx.x * 4 + (tid >> 6);
   const int c = blockIdx.y, dim = a.dim, E = a.n_routed;
   float scale = 1.0f;
-  if (a.norm_w) {  // rmsnorm of the residual stream (src/infer.cpp:839, 601-611), once per workgroup
+  if (a.norm_w && !(a.dbg & 4)) {  // rmsnorm of the residual stream (src/infer.cpp:839, 601-611), once per workgroup
     float ss = 0.f;
-    for (int i = tid * 4; i < dim; i += 1024) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + i);
-      ss = fmaf(v.x, v.x, ss);
-      ss = fmaf(v.y, v.y, ss);
-      ss = fmaf(v.z, v.z, ss);
-      ss = fmaf(v.w, v.w, ss);
+    for (int i0 = tid * 4; i0 < dim; i0 += 8 * 1024) {  // 8 loads in flight per lane
+      f32x4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (i0 + k * 1024 < dim) v[k] = *reinterpret_cast<const f32x4*>(a.x + i0 + k * 1024);
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (i0 + k * 1024 < dim) {
+          ss = fmaf(v[k].x, v[k].x, ss);
+          ss = fmaf(v[k].y, v[k].y, ss);
+          ss = fmaf(v[k].z, v[k].z, ss);
+          ss = fmaf(v[k].w, v[k].w, ss);
+        }
     }
     ss = wave_sum(ss);
     if (lane == 0) scratch[tid >> 6] = ss;
@@ -424,35 +463,43 @@ __global__ __launch_bounds__(256) void router_gate_kernel(RouterArgs a) {
     scale = 1.0f / sqrtf(total / (float)dim + a.eps);
     __syncthreads();
   }
-  if (row < E) {
+  if (row < E && !(a.dbg & 2)) {
     const int chunk = ((dim / 4 + a.ksplit - 1) / a.ksplit + 63) / 64 * 64 * 4;  // floats per K slice, multiple of 256
     const int k0 = c * chunk, k1 = min(dim, k0 + chunk);
     float acc = 0.f;
     const float* wr = a.w + (size_t)row * dim;
-    for (int i = k0 + lane * 4; i < k1; i += 256) {
-      const f32x4 wv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wr + i));
-      f32x4 xv = *reinterpret_cast<const f32x4*>(a.x + i);
-      if (a.norm_w) {
-        const f32x4 nw = *reinterpret_cast<const f32x4*>(a.norm_w + i);
-        xv.x = xv.x * scale * nw.x;
-        xv.y = xv.y * scale * nw.y;
-        xv.z = xv.z * scale * nw.z;
-        xv.w = xv.w * scale * nw.w;
+    for (int i0 = k0 + lane * 4; i0 < k1; i0 += 8 * 256) {  // 8 weight loads in flight per lane
+      f32x4 wv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (i0 + k * 256 < k1) wv[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wr + i0 + k * 256));
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int i = i0 + k * 256;
+        if (i < k1) {
+          f32x4 y = *reinterpret_cast<const f32x4*>(a.x + i);
+          if (a.norm_w) {
+            const f32x4 nw = *reinterpret_cast<const f32x4*>(a.norm_w + i);
+            y.x = y.x * scale * nw.x;
+            y.y = y.y * scale * nw.y;
+            y.z = y.z * scale * nw.z;
+            y.w = y.w * scale * nw.w;
+          }
+          acc = fmaf(wv[k].x, y.x, acc);
+          acc = fmaf(wv[k].y, y.y, acc);
+          acc = fmaf(wv[k].z, y.z, acc);
+          acc = fmaf(wv[k].w, y.w, acc);
+        }
       }
-      acc = fmaf(wv.x, xv.x, acc);
-      acc = fmaf(wv.y, xv.y, acc);
-      acc = fmaf(wv.z, xv.z, acc);
-      acc = fmaf(wv.w, xv.w, acc);
     }
     acc = wave_sum(acc);
-    if (lane == 0) a.partial[(size_t)c * E + row] = acc;
+    // write-through (sc1) store: visible across XCDs once vmcnt drains, no L2 write-back fence needed
+    if (lane == 0) __hip_atomic_store(a.partial + (size_t)c * E + row, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // ---- publish the partials; the last workgroup to arrive runs the gate ----
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned total = gridDim.x * gridDim.y;
     const unsigned old = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     is_last = old == total - 1;
@@ -460,6 +507,7 @@ __global__ __launch_bounds__(256) void router_gate_kernel(RouterArgs a) {
   }
   __syncthreads();
   if (!is_last) return;
+  if (a.dbg & 1) { if (tid == 0) *a.counter = 0; return; }
   if (tid == 0) __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
   float v = 0.f;
   if (tid < E)

@@ -292,7 +292,7 @@ extern "C" int dsk_measure_read_bw(dsk_ctx* ctx, size_t bytes, int iters, double
 
 // ------------------------------------------------------------------------------------
 // micro-benchmark of the GEMV kernel on device-resident synthetic weights (diagnostics; used by
-// tools/kbench.py to pick launch geometry).  kind: 0 plain, 1 GLU pair, 2 MoE accumulate.
+// tools/kbench.py to pick launch geometry).  kind: 0 plain, 1 GLU pair, 2 MoE accumulate kernel, 3 per-slot + fused combine.
 // Weight sets are rotated through > 512 MB so that the 256 MB Infinity Cache cannot serve them.
 // ------------------------------------------------------------------------------------
 extern "C" int dsk_bench_gemv(dsk_ctx* ctx, int quant, int rows, int n, int n_tasks, int kind, int act_mode, int force_lpr,
@@ -310,7 +310,11 @@ extern "C" int dsk_bench_gemv(dsk_ctx* ctx, int quant, int rows, int n, int n_ta
     DSK_TRY(alloc_tensor(128, 128, W[i].t, quant, 0, rows, n, 1, 0));
     DSK_TRY(launch_fill_tensor(st, W[i].t, 1234 + i, 1.0f / sqrtf((float)n)));
   }
-  DevBuf x, nw, out, q8, wts, plans;
+  DevBuf x, nw, out, q8, wts, plans, xres, cnt;
+  DSK_TRY(xres.alloc((size_t)rows * 4));
+  DSK_TRY(cnt.alloc((size_t)rows * 4));
+  HIP_TRY(hipMemsetAsync(xres.p, 0, (size_t)rows * 4, st));
+  HIP_TRY(hipMemsetAsync(cnt.p, 0, (size_t)rows * 4, st));
   DSK_TRY(x.alloc((size_t)n * n_tasks * 4));
   DSK_TRY(nw.alloc((size_t)n * 4));
   DSK_TRY(out.alloc((size_t)rows * n_tasks * 4));
@@ -340,11 +344,12 @@ extern "C" int dsk_bench_gemv(dsk_ctx* ctx, int quant, int rows, int n, int n_ta
       }
       T.act_mode = act_mode;
       if (act_mode == ACT_Q8) { T.a_qs = aq; T.a_d = ad; T.a_bsums = ab; }
-      T.a_f32 = x.as<float>() + (kind == 2 ? (size_t)i * n : 0);
+      T.a_f32 = x.as<float>() + (kind >= 2 ? (size_t)i * n : 0);
       T.norm_w = nw.as<float>(); T.eps = 1e-6f;
       T.out = kind == 2 ? out.as<float>() : out.as<float>() + (size_t)i * rows;
-      T.accum_w = kind == 2 ? wts.as<float>() + i : nullptr;
+      T.accum_w = kind >= 2 ? wts.as<float>() + i : nullptr;
     }
+    if (kind == 3) { h.comb_x = xres.as<float>(); h.comb_counter = cnt.as<unsigned>(); }
     DSK_TRY(gemv_plan(h, target_wgs > 0 ? target_wgs : 1024));
   }
   DSK_TRY(plans.alloc(sizeof(GemvLaunch) * copies));
@@ -363,5 +368,49 @@ extern "C" int dsk_bench_gemv(dsk_ctx* ctx, int quant, int rows, int n, int n_ta
   hipEventDestroy(e1);
   *us_per_launch = (double)ms * 1e3 / iters;
   *bytes_per_launch = wbytes;
+  return finish(ctx);
+}
+
+// Router + gate micro-benchmark (DeepSeek-V3: E = 256, dim = 7168).  flags: see RouterArgs::dbg.
+extern "C" int dsk_bench_router(dsk_ctx* ctx, int n_routed, int dim, int ksplit, int flags, int iters, double* us_per_launch) {
+  DSK_TRY(begin(ctx));
+  if (!us_per_launch || n_routed < 1 || n_routed > 256 || dim < 4 || ksplit < 1 || iters < 1) DSK_FAIL(DSK_ERR_INVALID, "bench_router: bad argument");
+  hipStream_t st = ctx_stream(ctx);
+  const int copies = 48;
+  DevBuf w, x, nw, partial, cnt, bias, ae, aw;
+  DSK_TRY(w.alloc((size_t)copies * n_routed * dim * 4));
+  DSK_TRY(x.alloc((size_t)dim * 4));
+  DSK_TRY(nw.alloc((size_t)dim * 4));
+  DSK_TRY(partial.alloc((size_t)ksplit * n_routed * 4));
+  DSK_TRY(cnt.alloc(64));
+  DSK_TRY(bias.alloc((size_t)n_routed * 4));
+  DSK_TRY(ae.alloc(64));
+  DSK_TRY(aw.alloc(64));
+  DSK_TRY(launch_fill_f32(st, w.as<float>(), (size_t)copies * n_routed * dim, 3, 0.f, 0.02f));
+  DSK_TRY(launch_fill_f32(st, x.as<float>(), (size_t)dim, 4, 0.f, 1.f));
+  DSK_TRY(launch_fill_f32(st, nw.as<float>(), (size_t)dim, 5, 1.f, 0.1f));
+  DSK_TRY(launch_fill_f32(st, bias.as<float>(), (size_t)n_routed, 6, 0.f, 0.01f));
+  HIP_TRY(hipMemsetAsync(cnt.p, 0, 64, st));
+  RouterArgs r;
+  memset(&r, 0, sizeof r);
+  r.x = x.as<float>(); r.norm_w = nw.as<float>(); r.eps = 1e-6f; r.n_routed = n_routed; r.dim = dim; r.ksplit = ksplit;
+  r.partial = partial.as<float>(); r.counter = cnt.as<unsigned>(); r.bias = bias.as<float>(); r.n_active = n_routed >= 8 ? 8 : 1;
+  r.norm_topk_prob = 1; r.scoring = DSK_SCORE_SIGMOID; r.topk_method = n_routed % 8 == 0 && n_routed >= 64 ? DSK_TOPK_GROUP_LIMITED_GREEDY : DSK_TOPK_GREEDY;
+  r.n_group = 8; r.topk_group = 4; r.scaling = 2.5f; r.active_experts = ae.as<int>(); r.active_weights = aw.as<float>(); r.dbg = flags;
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  for (int i = 0; i < copies + iters; ++i) {
+    if (i == copies) HIP_TRY(hipEventRecord(e0, st));
+    r.w = w.as<float>() + (size_t)(i % copies) * n_routed * dim;
+    DSK_TRY(launch_router_gate(st, r));
+  }
+  HIP_TRY(hipEventRecord(e1, st));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  *us_per_launch = (double)ms * 1e3 / iters;
   return finish(ctx);
 }

@@ -119,6 +119,7 @@ def lib():
         L.dsk_attn_mla.argtypes = [C.c_void_p, c_f, c_f, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, c_f]
         L.dsk_measure_read_bw.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
+        L.dsk_bench_router.argtypes = [C.c_void_p] + [C.c_int] * 5 + [C.POINTER(C.c_double)]
         L.dsk_bench_gemv.argtypes = [C.c_void_p] + [C.c_int] * 11 + [C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _lib = L
     return _lib
@@ -229,6 +230,11 @@ class Ctx:
         check(lib().dsk_bench_gemv(self.h, quant, rows, n, n_tasks, kind, act_mode, lpr, R, U, target_wgs, iters,
                                    C.byref(us), C.byref(nb)))
         return us.value, nb.value
+
+    def bench_router(self, n_routed=256, dim=7168, ksplit=4, flags=0, iters=50):
+        us = C.c_double()
+        check(lib().dsk_bench_router(self.h, n_routed, dim, ksplit, flags, iters, C.byref(us)))
+        return us.value
 
     def measure_read_bw(self, nbytes=8 << 30, iters=5) -> float:
         out = C.c_double()

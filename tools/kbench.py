@@ -19,7 +19,7 @@ Q2K = 3
 V3 = [
     ("lm_head 129280x7168", 129280, 7168, 1, 0, 2),
     ("experts_w13 9x(2048x7168)x2", 2048, 7168, 9, 1, 2),
-    ("experts_w2 accum 9x(7168x2048)", 7168, 2048, 9, 2, 1),
+    ("experts_w2+combine 9x(7168x2048)", 7168, 2048, 9, 3, 1),
     ("wo 7168x16384", 7168, 16384, 1, 0, 0),
     ("dense_w13 (18432x7168)x2", 18432, 7168, 1, 1, 2),
     ("dense_w2 7168x18432", 7168, 18432, 1, 0, 1),
@@ -56,7 +56,7 @@ def main():
     else:
         for name, rows, n, nt, kind, act in V3:
             us, nb = ctx.bench_gemv(Q2K, rows, n, nt, kind, act, 0, 0, 0, 0, 50)
-            us0, _ = ctx.bench_gemv(Q2K, rows, n, nt, kind, 0, 0, 0, 0, 0, 50) if kind != 2 else (float("nan"), 0)
+            us0, _ = ctx.bench_gemv(Q2K, rows, n, nt, kind, 0, 0, 0, 0, 0, 50) if kind < 2 else (float("nan"), 0)
             print(f"{name:36s} {us:8.2f} us  {nb/1e6:8.2f} MB  {nb/us/1e3:7.1f} GB/s   | ready-Q8 input: {us0:8.2f} us {nb/us0/1e3:7.1f} GB/s")
     ctx.close()
 
