@@ -48,13 +48,28 @@ DEV float act_fn(float x, int act) {
 }
 
 // ------------------------------------------------------------------------------------
-// Q2_K: one item = (block b, quarter q = 2*h + lh): bytes qs[32*h + 16*lh .. +15].
-// Word k of the item, shifted by 2*s, holds elements 128*h + 32*s + 16*lh + 4*k .. +3, i.e.
-// sub-block j = 8*h + 2*s + lh (layout: dequantize_row_q2_K, src/quant.cpp:217-247).
-// Scalar spec being computed: src/quant.cpp:746-780.
+// Activation staging layout in LDS (K-quants): one 80-byte record per item i = 4*block + quarter,
+// quarter q = 2*h + lh:
+//   [ 0..63]  the 64 int8 activations the item multiplies: 4 runs of 16 (s = 0..3), run s = elements
+//             128*h + 32*s + 16*lh .. +15 of the block (sub-block j = 8*h + 2*s + lh)
+//   [64..79]  meta.  Q2_K: int8 bsum_hi[4] | uint8 bsum_lo[4] | f32 d/16 | f32 d
+//                    Q3_K: int16 bsum[4] | f32 d | pad
+// A lane reads its record with 5 ds_read_b128 at immediate offsets; the 80-byte stride spreads 16
+// consecutive lanes over all 64 banks.  Consecutive lanes take consecutive items, and the lanes-per-row
+// count is a multiple of 4, so a lane's quarter never changes and item -> address is one add.
 // ------------------------------------------------------------------------------------
-DEV float q2k_item(u32x4 w, u32 scw, u32 dm, const u32x4 (&a)[4], u32x2 bsp, float dx, float acc) {
-  // masks keep the 2-bit fields in place (x1, x4, x16, x16): values stay < 128 for the signed dot
+#define ITEM_LDS 80
+DEV size_t kq_lds_bytes(int n) { return (size_t)(n >> 6) * ITEM_LDS; }
+
+// ------------------------------------------------------------------------------------
+// Q2_K: one item = (block b, quarter q): bytes qs[32*h + 16*lh .. +15].  Word k of the item, shifted by
+// 2*s, holds elements 128*h + 32*s + 16*lh + 4*k .. +3 (layout: dequantize_row_q2_K,
+// src/quant.cpp:217-247).  Scalar spec being computed: src/quant.cpp:746-780.
+// VALU budget: at 5.4 TB/s the chip affords ~130 wave instructions per item, so every op counts:
+// fields are masked in place (x1, x4, x16, x16), the scale products are 24-bit mads, the min term is
+// two dot4 against the split bsums, and the 1/16 is folded into the staged activation scale (exact).
+// ------------------------------------------------------------------------------------
+DEV float q2k_item(u32x4 w, u32 scw, u32 dm, const u32x4 (&a)[4], u32x4 meta, float acc) {
   int x0 = sdot4(w.x & 0x03030303u, a[0].x, 0);
   x0 = sdot4(w.y & 0x03030303u, a[0].y, x0);
   x0 = sdot4(w.z & 0x03030303u, a[0].z, x0);
@@ -72,15 +87,15 @@ DEV float q2k_item(u32x4 w, u32 scw, u32 dm, const u32x4 (&a)[4], u32x2 bsp, flo
   x3 = sdot4((w.z >> 2) & 0x30303030u, a[3].z, x3);
   x3 = sdot4((w.w >> 2) & 0x30303030u, a[3].w, x3);
   const int d0 = scw & 0xF, d1 = (scw >> 8) & 0xF, d2 = (scw >> 16) & 0xF, d3 = (scw >> 24) & 0xF;
-  const int m0 = (scw >> 4) & 0xF, m1 = (scw >> 12) & 0xF, m2 = (scw >> 20) & 0xF, m3 = scw >> 28;
-  // exact: x1 is a multiple of 4, x2/x3 of 16
-  const int isum = d0 * x0 + ((d1 * x1) >> 2) + ((d2 * x2 + d3 * x3) >> 4);
-  const int b0 = (int)(short)(bsp.x & 0xffff), b1 = (int)bsp.x >> 16;
-  const int b2 = (int)(short)(bsp.y & 0xffff), b3 = (int)bsp.y >> 16;
-  const int summs = m0 * b0 + m1 * b1 + m2 * b2 + m3 * b3;
-  const float dall = dx * h2f(dm & 0xffff);
-  const float dmin = dx * h2f(dm >> 16);
-  acc = fmaf(dall, (float)isum, acc);
+  // 16 * (sum_s d_s * true x_s): x1 carries a factor 4, x2 / x3 a factor 16; all products < 2^23
+  const int t23 = __mul24(d3, x3) + __mul24(d2, x2);
+  const int t1 = (__mul24(d1, x1) << 2) + t23;
+  const int isum16 = (__mul24(d0, x0) << 4) + t1;
+  const u32 m4 = (scw >> 4) & 0x0F0F0F0Fu;
+  const int summs = (sdot4(m4, meta.x, 0) << 8) + (int)__builtin_amdgcn_udot4(m4, meta.y, 0u, false);
+  const float dall16 = u2f(meta.z) * h2f(dm & 0xffff);
+  const float dmin = u2f(meta.w) * h2f(dm >> 16);
+  acc = fmaf(dall16, (float)isum16, acc);
   acc = fmaf(-dmin, (float)summs, acc);
   return acc;
 }
@@ -99,8 +114,8 @@ DEV int q3k_scale(u32 a0, u32 a1, u32 a2, int j) {  // j = 0..15 (src/quant.cpp:
 }
 
 DEV float q3k_item(u32x4 w, u32x4 hm, u32 s0, u32 s1, u32 s2, u32 d16, int h, int lh, const u32x4 (&a)[4],
-                   u32x2 bsp, float dx, float acc) {
-  const int bsv[4] = {(int)(short)(bsp.x & 0xffff), (int)bsp.x >> 16, (int)(short)(bsp.y & 0xffff), (int)bsp.y >> 16};
+                   u32x4 meta, float acc) {
+  const int bsv[4] = {(int)(short)(meta.x & 0xffff), (int)meta.x >> 16, (int)(short)(meta.y & 0xffff), (int)meta.y >> 16};
   int total = 0;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
@@ -114,15 +129,14 @@ DEV float q3k_item(u32x4 w, u32x4 hm, u32 s0, u32 s1, u32 s2, u32 d16, int h, in
     x = sdot4(v2, a[s].z, x);
     x = sdot4(v3, a[s].w, x);
     x -= 4 * bsv[s];  // the "- 4" of every element of the sub-block
-    total += q3k_scale(s0, s1, s2, 8 * h + 2 * s + lh) * x;
+    total += __mul24(q3k_scale(s0, s1, s2, 8 * h + 2 * s + lh), x);
   }
-  return fmaf(dx * h2f(d16), (float)total, acc);
+  return fmaf(u2f(meta.z) * h2f(d16), (float)total, acc);
 }
 
 // ------------------------------------------------------------------------------------
 // Q8_K quantisation of one 256-block by one wave (quantize_row_q8_K_ref, src/quant.cpp:616-653;
-// same arithmetic as kernels_misc.hip q8k_block) writing the LDS staging layout:
-// qs natural order, bsums in quarter order, d.
+// same arithmetic as kernels_misc.hip q8k_block) writing the item-record layout described above.
 // ------------------------------------------------------------------------------------
 // DPP lane exchanges (VALU speed; __shfl_xor lowers to ds_bpermute, ~100 cycles each)
 template <int CTRL>
@@ -154,10 +168,51 @@ DEV float bmax_value(unsigned long long key) {  // signed value of the winning e
   return u2f((u32)(key >> 32) | ((u32)(key & 1) << 31));
 }
 
-// rounding half of quantize_row_q8_K_ref given the block's signed max (src/quant.cpp:630-650)
-DEV void q8k_round_lds(const float (&v)[4], float vmax, int lane, uint8_t* qs_blk, float* d_out, short* bs_blk);
+// write one lane's share of a staged block: 4 consecutive int8 (elements 4*lane..+3), the sub-block
+// sum (lanes 4j) and the block scale (lanes 0..3, one per quarter record)
+template <bool Q2META>
+DEV void q8k_store_lds(u32 packed, int quadsum, float d, int lane, uint8_t* blk) {
+  const int h = lane >> 5, sidx = (lane >> 3) & 3, lh = (lane >> 2) & 1;
+  uint8_t* rec = blk + (2 * h + lh) * ITEM_LDS;
+  *reinterpret_cast<u32*>(rec + sidx * 16 + (lane & 3) * 4) = packed;
+  if ((lane & 3) == 0) {
+    if (Q2META) {
+      rec[64 + sidx] = (uint8_t)(quadsum >> 8);
+      rec[68 + sidx] = (uint8_t)(quadsum & 0xff);
+    } else {
+      reinterpret_cast<short*>(rec + 64)[sidx] = (short)quadsum;
+    }
+  }
+  if (lane < 4) {
+    float* m = reinterpret_cast<float*>(blk + lane * ITEM_LDS + 72);
+    if (Q2META) { m[0] = d * 0.0625f; m[1] = d; }
+    else m[0] = d;
+  }
+}
 
-DEV void q8k_block_lds(const float (&v)[4], int lane, uint8_t* qs_blk, float* d_out, short* bs_blk) {
+// rounding half of quantize_row_q8_K_ref given the block's signed max (src/quant.cpp:630-650)
+template <bool Q2META>
+DEV void q8k_round_lds(const float (&v)[4], float vmax, int lane, uint8_t* blk) {
+  int q[4] = {0, 0, 0, 0};
+  float d = 0.f;
+  if (vmax != 0.f) {
+    const float iscale = __fdiv_rn(-127.f, vmax);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = (int)rintf(__fmul_rn(iscale, v[i]));
+      q[i] = r < 127 ? r : 127;
+    }
+    d = __fmul_rn(vmax, 1.0f / -127.f);
+  }
+  const u32 packed = (u32)(q[0] & 0xff) | ((u32)(q[1] & 0xff) << 8) | ((u32)(q[2] & 0xff) << 16) | ((u32)(q[3] & 0xff) << 24);
+  int sum = q[0] + q[1] + q[2] + q[3];
+  sum += (int)dpp_u32<DPP_XOR1>((u32)sum);
+  sum += (int)dpp_u32<DPP_XOR2>((u32)sum);
+  q8k_store_lds<Q2META>(packed, sum, d, lane, blk);
+}
+
+template <bool Q2META>
+DEV void q8k_block_lds(const float (&v)[4], int lane, uint8_t* blk) {
   // max = signed value of the FIRST element with the largest |x| (src/quant.cpp:622-629)
   float amax_l = 0.f, vmax_l = 0.f;
 #pragma unroll
@@ -170,30 +225,7 @@ DEV void q8k_block_lds(const float (&v)[4], int lane, uint8_t* qs_blk, float* d_
   const unsigned long long owners = __ballot(__builtin_bit_cast(u32, amax_l) == amax_bits);
   const int owner = __ffsll((long long)owners) - 1;
   const float vmax = u2f(__builtin_amdgcn_readlane(__builtin_bit_cast(u32, vmax_l), owner));
-  q8k_round_lds(v, vmax, lane, qs_blk, d_out, bs_blk);
-}
-
-DEV void q8k_round_lds(const float (&v)[4], float vmax, int lane, uint8_t* qs_blk, float* d_out, short* bs_blk) {
-  int q[4] = {0, 0, 0, 0};
-  float d = 0.f;
-  if (vmax != 0.f) {
-    const float iscale = __fdiv_rn(-127.f, vmax);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = (int)rintf(__fmul_rn(iscale, v[i]));
-      q[i] = r < 127 ? r : 127;
-    }
-    d = __fmul_rn(vmax, 1.0f / -127.f);
-  }
-  reinterpret_cast<u32*>(qs_blk)[lane] = (u32)(q[0] & 0xff) | ((u32)(q[1] & 0xff) << 8) | ((u32)(q[2] & 0xff) << 16) | ((u32)(q[3] & 0xff) << 24);
-  int s = q[0] + q[1] + q[2] + q[3];
-  s += (int)dpp_u32<DPP_XOR1>((u32)s);
-  s += (int)dpp_u32<DPP_XOR2>((u32)s);
-  if ((lane & 3) == 0) {
-    const int j = lane >> 2, h = j >> 3, sh = (j >> 1) & 3, lh = j & 1;
-    bs_blk[(2 * h + lh) * 4 + sh] = (short)s;
-  }
-  if (lane == 0) *d_out = d;
+  q8k_round_lds<Q2META>(v, vmax, lane, blk);
 }
 
 DEV float wave_sum(float v) {  // fixed order: quads, rows of 16, then the four rows
@@ -245,22 +277,32 @@ DEV float wg_sumsq(const float* __restrict__ x, int n, int tid, float* scratch) 
   return t;
 }
 
-// Stage one activation vector of a K-quant task in LDS (qs | bsums(quarter order) | d).
-DEV void stage_q8(const GemvTask& T, uint8_t* l_qs, short* l_bs, float* l_d, int tid, float* scratch) {
+// Stage one activation vector of a K-quant task in LDS (item records, see ITEM_LDS).
+template <bool Q2META>
+DEV void stage_q8(const GemvTask& T, uint8_t* lds, int tid, float* scratch) {
   const int n = T.n, nb = n >> 8;
-  if (T.act_mode == ACT_Q8) {
-    const u32x4* src = reinterpret_cast<const u32x4*>(T.a_qs);
-    u32x4* dst = reinterpret_cast<u32x4*>(l_qs);
-    for (int i = tid; i < (n >> 4); i += 256) dst[i] = src[i];
-    for (int i = tid; i < nb * 16; i += 256) {
-      const int b = i >> 4, j = i & 15;
-      const int h = j >> 3, s = (j >> 1) & 3, lh = j & 1;
-      l_bs[b * 16 + (2 * h + lh) * 4 + s] = T.a_bsums[i];
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  if (T.act_mode == ACT_Q8) {  // ready Q8_K vector: 16-byte runs (one sub-block each) go straight to their record
+    for (int i = tid; i < (n >> 4); i += 256) {
+      const int b = i >> 4, j = i & 15, h = j >> 3, sidx = (j >> 1) & 3, lh = j & 1;
+      uint8_t* rec = lds + (size_t)(b * 4 + 2 * h + lh) * ITEM_LDS;
+      *reinterpret_cast<u32x4*>(rec + sidx * 16) = reinterpret_cast<const u32x4*>(T.a_qs)[i];
+      const int bs = T.a_bsums[i];
+      if (Q2META) {
+        rec[64 + sidx] = (uint8_t)(bs >> 8);
+        rec[68 + sidx] = (uint8_t)(bs & 0xff);
+      } else {
+        reinterpret_cast<short*>(rec + 64)[sidx] = (short)bs;
+      }
     }
-    for (int i = tid; i < nb; i += 256) l_d[i] = T.a_d[i];
+    for (int i = tid; i < nb * 4; i += 256) {
+      const float d = T.a_d[i >> 2];
+      float* m = reinterpret_cast<float*>(lds + (size_t)i * ITEM_LDS + 72);
+      if (Q2META) { m[0] = d * 0.0625f; m[1] = d; }
+      else m[0] = d;
+    }
     return;
   }
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   if (T.act_mode == ACT_F32_NORM && nb <= 32) {
     // rmsnorm (src/infer.cpp:601-611) + Q8_K in ONE memory round trip: wave w owns blocks w, w+4, ...
     // (<= 8 per wave); x and the norm weight are loaded once and stay in registers across the
@@ -295,7 +337,7 @@ DEV void stage_q8(const GemvTask& T, uint8_t* l_qs, short* l_bs, float* l_d, int
       if (b < nb) {
         float v[4] = {t[k].x * scale * wv[k].x, t[k].y * scale * wv[k].y, t[k].z * scale * wv[k].z, t[k].w * scale * wv[k].w};
         if (T.norm_out) *reinterpret_cast<f32x4*>(T.norm_out + b * 256 + lane * 4) = f32x4{v[0], v[1], v[2], v[3]};
-        q8k_block_lds(v, lane, l_qs + b * 256, l_d + b, l_bs + b * 16);
+        q8k_block_lds<Q2META>(v, lane, lds + (size_t)b * 4 * ITEM_LDS);
       }
     }
     return;
@@ -305,19 +347,22 @@ DEV void stage_q8(const GemvTask& T, uint8_t* l_qs, short* l_bs, float* l_d, int
     const float total = wg_sumsq(T.a_f32, n, tid, scratch);
     scale = 1.0f / sqrtf(total / (float)n + T.eps);
   }
-  // wave w quantises blocks w, w+4, ...; the loads of 4 blocks are issued together (one L2 latency)
-  for (int b0 = wave; b0 < nb; b0 += 16) {
-    f32x4 t[4], wv[4];
+  // wave w quantises blocks w, w+4, ...; the loads of 8 blocks are issued together, so even the
+  // longest vector (18432 = 72 blocks) costs three L2 round trips per workgroup
+  for (int b0 = wave; b0 < nb; b0 += 32) {
+    f32x4 t[8], wv[8];
+    float vm[8];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 8; ++k) {
       const int b = b0 + 4 * k;
       if (b < nb) {
         t[k] = *reinterpret_cast<const f32x4*>(T.a_f32 + b * 256 + lane * 4);
         if (T.act_mode == ACT_F32_NORM) wv[k] = *reinterpret_cast<const f32x4*>(T.norm_w + b * 256 + lane * 4);
+        if (T.act_mode == ACT_F32_BMAX) vm[k] = bmax_value(T.a_bmax[b]);
       }
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 8; ++k) {
       const int b = b0 + 4 * k;
       if (b < nb) {
         float v[4] = {t[k].x, t[k].y, t[k].z, t[k].w};
@@ -328,8 +373,8 @@ DEV void stage_q8(const GemvTask& T, uint8_t* l_qs, short* l_bs, float* l_d, int
           v[3] = v[3] * scale * wv[k].w;
           if (T.norm_out) *reinterpret_cast<f32x4*>(T.norm_out + b * 256 + lane * 4) = f32x4{v[0], v[1], v[2], v[3]};
         }
-        if (T.act_mode == ACT_F32_BMAX) q8k_round_lds(v, bmax_value(T.a_bmax[b]), lane, l_qs + b * 256, l_d + b, l_bs + b * 16);
-        else q8k_block_lds(v, lane, l_qs + b * 256, l_d + b, l_bs + b * 16);
+        if (T.act_mode == ACT_F32_BMAX) q8k_round_lds<Q2META>(v, vm[k], lane, lds + (size_t)b * 4 * ITEM_LDS);
+        else q8k_block_lds<Q2META>(v, lane, lds + (size_t)b * 4 * ITEM_LDS);
       }
     }
   }
@@ -420,88 +465,96 @@ DEV WPtr resolve(const GemvTask& T) {
 // are separate so that the first chunk can be requested from HBM BEFORE the workgroup stages its
 // activation vector (the prologue then overlaps the memory latency instead of preceding it).
 // ------------------------------------------------------------------------------------
+// K-quant planes are read through buffer descriptors: address = plane base (SGPRs) + per-lane row
+// offset (VGPR, fixed for a row group) + column-step offset (SGPR), so a load costs no VALU at all.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+DEV rsrc_t make_rsrc(const void* p) {
+  // the base is wave-uniform by construction (task pointers come from the launch descriptor); saying so
+  // keeps the compiler from wrapping every load in a waterfall loop
+  const unsigned long long v = (unsigned long long)p;
+  const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, -1, 0x00020000);
+}
+#define BUF_NT 2  // streaming data: non-temporal
+struct KQRsrc {
+  rsrc_t qs, sc, hm, dm, qs2, sc2, hm2, dm2;
+};
+template <int QT, bool GLU>
+DEV KQRsrc kq_rsrc(const WPtr& P) {
+  KQRsrc r;
+  r.qs = make_rsrc(P.qs); r.sc = make_rsrc(P.sc); r.dm = make_rsrc(P.dm);
+  r.hm = make_rsrc(QT == DSK_QUANT_Q3_K ? P.hm : P.qs);
+  r.qs2 = make_rsrc(GLU ? P.qs2 : P.qs); r.sc2 = make_rsrc(GLU ? P.sc2 : P.sc); r.dm2 = make_rsrc(GLU ? P.dm2 : P.dm);
+  r.hm2 = make_rsrc(GLU && QT == DSK_QUANT_Q3_K ? P.hm2 : P.qs);
+  return r;
+}
+
 template <int QT, int R, int U, bool GLU>
 struct ChunkKQ {
   u32x4 w[U][R], w2[U][R], hmv[U][R], hmv2[U][R];
   u32 scw[U][R], scw2[U][R], dmw[U][R], dmw2[U][R], s1w[U][R], s2w[U][R], s1w2[U][R], s2w2[U][R];
-  int itemv[U];
 };
 
+// rowblk[r] = row * nb + (sub >> 2): index of the lane's first super-block; q = sub & 3 its quarter
 template <int QT, int R, int U, bool GLU>
-DEV void load_chunk_kq(ChunkKQ<QT, R, U, GLU>& c, const WPtr& P, int nb, int lpr_log2, int lane, const int (&row)[R], int it0) {
-  const int LPR = 1 << lpr_log2;
-  const int sub = lane & (LPR - 1);
-  const int items = nb * 4;
-  const int its = (items + LPR - 1) >> lpr_log2;
+DEV void load_chunk_kq(ChunkKQ<QT, R, U, GLU>& c, const KQRsrc& B, int its, int lpr_log2, int q, const int (&rowblk)[R], int it0) {
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int it = it0 + u;
     if (it >= its) break;  // wave-uniform: the trailing steps of the last chunk do no work at all
-    int item = sub + (it << lpr_log2);
-    const bool live = item < items;
-    if (!live) item = items - 1;
-    c.itemv[u] = item;
-    const int b = item >> 2, lh = item & 1;
+    const int sblk = (it << lpr_log2) >> 2;  // super-blocks advanced by this column step (scalar)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const size_t roff = (size_t)row[r] * nb;
-      c.w[u][r] = ldg_nt(reinterpret_cast<const u32x4*>(P.qs + roff * 64 + (size_t)item * 16));
+      const int vb = rowblk[r];
+      c.w[u][r] = __builtin_amdgcn_raw_buffer_load_b128(B.qs, vb * 64 + q * 16, sblk * 64, BUF_NT);
       if (QT == DSK_QUANT_Q2_K) {
-        c.scw[u][r] = ldg_nt(reinterpret_cast<const u32*>(P.sc + roff * 16 + (size_t)item * 4));
-        c.dmw[u][r] = ldg_nt(reinterpret_cast<const u32*>(P.dm + (roff + b) * 4));
+        c.scw[u][r] = __builtin_amdgcn_raw_buffer_load_b32(B.sc, vb * 16 + q * 4, sblk * 16, BUF_NT);
+        c.dmw[u][r] = __builtin_amdgcn_raw_buffer_load_b32(B.dm, vb * 4, sblk * 4, BUF_NT);
       } else {
-        c.hmv[u][r] = ldg_nt(reinterpret_cast<const u32x4*>(P.hm + (roff + b) * 32 + lh * 16));
-        const u32* sp = reinterpret_cast<const u32*>(P.sc + (roff + b) * 12);
-        c.scw[u][r] = ldg_nt(sp);
-        c.s1w[u][r] = ldg_nt(sp + 1);
-        c.s2w[u][r] = ldg_nt(sp + 2);
-        c.dmw[u][r] = ldg_nt(reinterpret_cast<const unsigned short*>(P.dm + (roff + b) * 2));
+        c.hmv[u][r] = __builtin_amdgcn_raw_buffer_load_b128(B.hm, vb * 32 + (q & 1) * 16, sblk * 32, BUF_NT);
+        c.scw[u][r] = __builtin_amdgcn_raw_buffer_load_b32(B.sc, vb * 12, sblk * 12, BUF_NT);
+        c.s1w[u][r] = __builtin_amdgcn_raw_buffer_load_b32(B.sc, vb * 12 + 4, sblk * 12, BUF_NT);
+        c.s2w[u][r] = __builtin_amdgcn_raw_buffer_load_b32(B.sc, vb * 12 + 8, sblk * 12, BUF_NT);
+        c.dmw[u][r] = (u32)__builtin_amdgcn_raw_buffer_load_b16(B.dm, vb * 2, sblk * 2, BUF_NT);
       }
       if (GLU) {
-        c.w2[u][r] = ldg_nt(reinterpret_cast<const u32x4*>(P.qs2 + roff * 64 + (size_t)item * 16));
+        c.w2[u][r] = __builtin_amdgcn_raw_buffer_load_b128(B.qs2, vb * 64 + q * 16, sblk * 64, BUF_NT);
         if (QT == DSK_QUANT_Q2_K) {
-          c.scw2[u][r] = ldg_nt(reinterpret_cast<const u32*>(P.sc2 + roff * 16 + (size_t)item * 4));
-          c.dmw2[u][r] = ldg_nt(reinterpret_cast<const u32*>(P.dm2 + (roff + b) * 4));
+          c.scw2[u][r] = __builtin_amdgcn_raw_buffer_load_b32(B.sc2, vb * 16 + q * 4, sblk * 16, BUF_NT);
+          c.dmw2[u][r] = __builtin_amdgcn_raw_buffer_load_b32(B.dm2, vb * 4, sblk * 4, BUF_NT);
         } else {
-          c.hmv2[u][r] = ldg_nt(reinterpret_cast<const u32x4*>(P.hm2 + (roff + b) * 32 + lh * 16));
-          const u32* sp = reinterpret_cast<const u32*>(P.sc2 + (roff + b) * 12);
-          c.scw2[u][r] = ldg_nt(sp);
-          c.s1w2[u][r] = ldg_nt(sp + 1);
-          c.s2w2[u][r] = ldg_nt(sp + 2);
-          c.dmw2[u][r] = ldg_nt(reinterpret_cast<const unsigned short*>(P.dm2 + (roff + b) * 2));
+          c.hmv2[u][r] = __builtin_amdgcn_raw_buffer_load_b128(B.hm2, vb * 32 + (q & 1) * 16, sblk * 32, BUF_NT);
+          c.scw2[u][r] = __builtin_amdgcn_raw_buffer_load_b32(B.sc2, vb * 12, sblk * 12, BUF_NT);
+          c.s1w2[u][r] = __builtin_amdgcn_raw_buffer_load_b32(B.sc2, vb * 12 + 4, sblk * 12, BUF_NT);
+          c.s2w2[u][r] = __builtin_amdgcn_raw_buffer_load_b32(B.sc2, vb * 12 + 8, sblk * 12, BUF_NT);
+          c.dmw2[u][r] = (u32)__builtin_amdgcn_raw_buffer_load_b16(B.dm2, vb * 2, sblk * 2, BUF_NT);
         }
-      }
-      if (!live) {  // a zero super-block scale removes the (finite) contribution
-        c.dmw[u][r] = 0;
-        if (GLU) c.dmw2[u][r] = 0;
       }
     }
   }
 }
 
+// lds_lane = staged vector + sub * ITEM_LDS (the lane's record of column step 0)
 template <int QT, int R, int U, bool GLU>
-DEV void compute_chunk_kq(const ChunkKQ<QT, R, U, GLU>& c, int nb, int lpr_log2, int it0, const uint8_t* l_qs, const short* l_bs,
-                          const float* l_d, float (&acc)[R], float (&acc2)[R]) {
-  const int its = (nb * 4 + (1 << lpr_log2) - 1) >> lpr_log2;
+DEV void compute_chunk_kq(const ChunkKQ<QT, R, U, GLU>& c, int its, int lpr_log2, int q, int it0, const uint8_t* lds_lane,
+                          float (&acc)[R], float (&acc2)[R]) {
+  const int h = q >> 1, lh = q & 1;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     if (it0 + u >= its) break;
-    const int item = c.itemv[u];
-    const int b = item >> 2, q = item & 3, h = q >> 1, lh = q & 1;
+    const uint8_t* rec = lds_lane + (size_t)((it0 + u) << lpr_log2) * ITEM_LDS;
     u32x4 a[4];
-    const uint8_t* ap = l_qs + b * 256 + h * 128 + lh * 16;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) a[s] = *reinterpret_cast<const u32x4*>(ap + s * 32);
-    const u32x2 bsp = *reinterpret_cast<const u32x2*>(l_bs + b * 16 + q * 4);
-    const float dx = l_d[b];
+    for (int s = 0; s < 4; ++s) a[s] = *reinterpret_cast<const u32x4*>(rec + s * 16);
+    const u32x4 meta = *reinterpret_cast<const u32x4*>(rec + 64);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       if (QT == DSK_QUANT_Q2_K) {
-        acc[r] = q2k_item(c.w[u][r], c.scw[u][r], c.dmw[u][r], a, bsp, dx, acc[r]);
-        if (GLU) acc2[r] = q2k_item(c.w2[u][r], c.scw2[u][r], c.dmw2[u][r], a, bsp, dx, acc2[r]);
+        acc[r] = q2k_item(c.w[u][r], c.scw[u][r], c.dmw[u][r], a, meta, acc[r]);
+        if (GLU) acc2[r] = q2k_item(c.w2[u][r], c.scw2[u][r], c.dmw2[u][r], a, meta, acc2[r]);
       } else {
-        acc[r] = q3k_item(c.w[u][r], c.hmv[u][r], c.scw[u][r], c.s1w[u][r], c.s2w[u][r], c.dmw[u][r], h, lh, a, bsp, dx, acc[r]);
-        if (GLU) acc2[r] = q3k_item(c.w2[u][r], c.hmv2[u][r], c.scw2[u][r], c.s1w2[u][r], c.s2w2[u][r], c.dmw2[u][r], h, lh, a, bsp, dx, acc2[r]);
+        acc[r] = q3k_item(c.w[u][r], c.hmv[u][r], c.scw[u][r], c.s1w[u][r], c.s2w[u][r], c.dmw[u][r], h, lh, a, meta, acc[r]);
+        if (GLU) acc2[r] = q3k_item(c.w2[u][r], c.hmv2[u][r], c.scw2[u][r], c.s1w2[u][r], c.s2w2[u][r], c.dmw2[u][r], h, lh, a, meta, acc2[r]);
       }
     }
   }
@@ -580,24 +633,15 @@ DEV void compute_chunk_f(const ChunkF<QT, R, U, GLU>& c, int n, int lpr_log2, in
 
 // dot products of R rows (x 64/LPR rows per wave) with a staged activation vector.
 // `pre`: the first chunk was already requested by the caller (prefetch across the prologue).
-template <int QT, int R, int U, bool GLU, typename Chunk>
-DEV void rows_dot(Chunk& c, bool pre, const WPtr& P, int n, int b0, int b1, int lpr_log2, int lane, const int (&row)[R],
-                  const uint8_t* lds, float (&acc)[R], float (&acc2)[R]) {
-  constexpr bool KQ = QT == DSK_QUANT_Q2_K || QT == DSK_QUANT_Q3_K;
-  const int nb = n >> 8;
-  const int items = KQ ? nb * 4 : n / FTraits<QT>::EPI;
-  const int its = (items + (1 << lpr_log2) - 1) >> lpr_log2;
+template <int QT, int R, int U, bool GLU>
+DEV void rows_dot_kq(const KQRsrc& B, int its, int lpr_log2, int q, const int (&rowblk)[R], const uint8_t* lds_lane,
+                     float (&acc)[R], float (&acc2)[R]) {
+  ChunkKQ<QT, R, U, GLU> c;
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = acc2[r] = 0.f;
   for (int it0 = 0; it0 < its; it0 += U) {
-    if constexpr (KQ) {
-      if (!(pre && it0 == 0)) load_chunk_kq<QT, R, U, GLU>(c, P, nb, lpr_log2, lane, row, it0);
-      compute_chunk_kq<QT, R, U, GLU>(c, nb, lpr_log2, it0, lds, reinterpret_cast<const short*>(lds + n),
-                                      reinterpret_cast<const float*>(lds + n + nb * 32), acc, acc2);
-    } else {
-      if (!(pre && it0 == 0)) load_chunk_f<QT, R, U, GLU>(c, P, n, b0, b1, lpr_log2, lane, row, it0);
-      compute_chunk_f<QT, R, U, GLU>(c, n, lpr_log2, it0, reinterpret_cast<const float*>(lds), acc, acc2);
-    }
+    load_chunk_kq<QT, R, U, GLU>(c, B, its, lpr_log2, q, rowblk, it0);
+    compute_chunk_kq<QT, R, U, GLU>(c, its, lpr_log2, q, it0, lds_lane, acc, acc2);
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -607,62 +651,28 @@ DEV void rows_dot(Chunk& c, bool pre, const WPtr& P, int n, int b0, int b1, int 
 }
 
 template <int QT, int R, int U, bool GLU>
-struct ChunkOf {
-  using type = typename std::conditional<(QT == DSK_QUANT_Q2_K || QT == DSK_QUANT_Q3_K), ChunkKQ<QT, R, U, GLU>, ChunkF<QT, R, U, GLU>>::type;
-};
-
-// Stage the activation vectors of ALL tasks of an accumulate launch (K-quants): the 256-blocks of
-// every slot form one list that the four waves walk together, 4 loads in flight per lane.
-DEV void stage_accum_q8(const GemvLaunch& L, uint8_t* smem, int tid) {
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  int NB = 0;
-  for (int ti = 0; ti < L.n_tasks; ++ti) NB += L.t[ti].n >> 8;
-  for (int g0 = wave; g0 < NB; g0 += 16) {
-    f32x4 t[4];
-    float vm[4];
-    int dst_off[4], bidx[4];
-    bool hasmax[4];
+DEV void rows_dot_f(const WPtr& P, int n, int b0, int b1, int lpr_log2, int lane, const int (&row)[R], const uint8_t* lds,
+                    float (&acc)[R], float (&acc2)[R]) {
+  ChunkF<QT, R, U, GLU> c;
+  const int items = n / FTraits<QT>::EPI;
+  const int its = (items + (1 << lpr_log2) - 1) >> lpr_log2;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int gb = g0 + 4 * k;
-      if (gb < NB) {
-        int ti = 0, b = gb;
-        size_t off = 0;
-        while (b >= (L.t[ti].n >> 8)) {  // wave-uniform scan: which slot owns block gb
-          b -= L.t[ti].n >> 8;
-          off += ((size_t)L.t[ti].n + (size_t)(L.t[ti].n >> 8) * 36 + 15) & ~(size_t)15;
-          ++ti;
-        }
-        const GemvTask& T = L.t[ti];
-        t[k] = *reinterpret_cast<const f32x4*>(T.a_f32 + b * 256 + lane * 4);
-        hasmax[k] = T.act_mode == ACT_F32_BMAX;
-        vm[k] = hasmax[k] ? bmax_value(T.a_bmax[b]) : 0.f;
-        dst_off[k] = (int)off;
-        bidx[k] = b | (T.n << 8);  // block index and the slot's n (for the bsums / d sub-offsets)
-      }
-    }
+  for (int r = 0; r < R; ++r) acc[r] = acc2[r] = 0.f;
+  for (int it0 = 0; it0 < its; it0 += U) {
+    load_chunk_f<QT, R, U, GLU>(c, P, n, b0, b1, lpr_log2, lane, row, it0);
+    compute_chunk_f<QT, R, U, GLU>(c, n, lpr_log2, it0, reinterpret_cast<const float*>(lds), acc, acc2);
+  }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int gb = g0 + 4 * k;
-      if (gb < NB) {
-        const int b = bidx[k] & 255, n = bidx[k] >> 8;
-        uint8_t* base = smem + dst_off[k];
-        float v[4] = {t[k].x, t[k].y, t[k].z, t[k].w};
-        uint8_t* qs = base + b * 256;
-        float* dd = reinterpret_cast<float*>(base + n + (n >> 8) * 32) + b;
-        short* bs = reinterpret_cast<short*>(base + n) + b * 16;
-        if (hasmax[k]) q8k_round_lds(v, vm[k], lane, qs, dd, bs);
-        else q8k_block_lds(v, lane, qs, dd, bs);
-      }
-    }
+  for (int r = 0; r < R; ++r) {
+    acc[r] = lanes_sum(acc[r], lpr_log2);
+    if (GLU) acc2[r] = lanes_sum(acc2[r], lpr_log2);
   }
 }
 
 // ------------------------------------------------------------------------------------
-// the kernel.  GEMV_MODE_TASKS: every workgroup serves one task.  GEMV_MODE_ACCUM: every workgroup
-// serves a row range of ALL tasks (the MoE combine: tasks = routed slots in k order, then shared).
+// the kernel: every workgroup serves one task (persistent over that task's row groups).
 // ------------------------------------------------------------------------------------
-template <int QT, int R, int U, bool GLU, int MODE>
+template <int QT, int R, int U, bool GLU>
 __global__ __launch_bounds__(256) void gemv_kernel(const GemvLaunch* __restrict__ Lp) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ float scratch[4];
@@ -675,188 +685,137 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvLaunch* __restrict_
   const int rloc = lane >> lpr_log2, sub = lane & ((1 << lpr_log2) - 1);
   const int RG = 4 * RPW * R;  // rows per workgroup step
 
-  if (MODE == GEMV_MODE_TASKS) {
-    GemvTask T;
-    int wi, nwg;
-    if (L.bd_heads > 0) {  // block-diagonal stack: workgroup -> head
-      const int head = blockIdx.x / L.bd_wgs;
-      wi = blockIdx.x - head * L.bd_wgs;
-      nwg = L.bd_wgs;
-      T = L.t[0];
-      const size_t per = (size_t)T.rows * T.n;
-      if (QT == DSK_QUANT_Q2_K) {
-        T.qs += head * (per / 256 * 64); T.sc += head * (per / 256 * 16); T.dm += head * (per / 256 * 4);
-      } else if (QT == DSK_QUANT_Q3_K) {
-        T.qs += head * (per / 256 * 64); T.hm += head * (per / 256 * 32); T.sc += head * (per / 256 * 12); T.dm += head * (per / 256 * 2);
-      } else {
-        T.qs += head * per * FTraits<QT>::ESZ;
-        // reference indexing: expert_index * cdiv(d,b0)*cdiv(n,b1) (src/infer.cpp:437-438)
-        if (T.scale) T.scale += (size_t)head * ((T.rows + L.b0 - 1) / L.b0) * ((T.n + L.b1 - 1) / L.b1);
-      }
-      T.a_f32 += (size_t)head * T.n;
-      T.out += (size_t)head * T.rows;
+  GemvTask T;
+  int wi, nwg;
+  if (L.bd_heads > 0) {  // block-diagonal stack: workgroup -> head
+    const int head = blockIdx.x / L.bd_wgs;
+    wi = blockIdx.x - head * L.bd_wgs;
+    nwg = L.bd_wgs;
+    T = L.t[0];
+    const size_t per = (size_t)T.rows * T.n;
+    if (QT == DSK_QUANT_Q2_K) {
+      T.qs += head * (per / 256 * 64); T.sc += head * (per / 256 * 16); T.dm += head * (per / 256 * 4);
+    } else if (QT == DSK_QUANT_Q3_K) {
+      T.qs += head * (per / 256 * 64); T.hm += head * (per / 256 * 32); T.sc += head * (per / 256 * 12); T.dm += head * (per / 256 * 2);
     } else {
-      int ti = 0;
-      while (ti + 1 < L.n_tasks && (int)blockIdx.x >= L.t[ti].wg_end) ++ti;
-      T = L.t[ti];
-      wi = blockIdx.x - T.wg_begin;
-      nwg = T.wg_end - T.wg_begin;
+      T.qs += head * per * FTraits<QT>::ESZ;
+      // reference indexing: expert_index * cdiv(d,b0)*cdiv(n,b1) (src/infer.cpp:437-438)
+      if (T.scale) T.scale += (size_t)head * ((T.rows + L.b0 - 1) / L.b0) * ((T.n + L.b1 - 1) / L.b1);
     }
-    const WPtr P = resolve(T);
-    if (!P.present) return;
-    const int n_groups = (T.rows + RG - 1) / RG;
-    if (wi >= n_groups) return;
-
-    auto row0_of = [&](int g) { return g * RG + wave * (RPW * R); };
-    auto rows_of = [&](int g, int (&row)[R], bool (&valid)[R]) {
-      const int row0 = g * RG + wave * (RPW * R);
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int rr = row0 + r * RPW + rloc;
-        valid[r] = rr < T.rows;
-        row[r] = valid[r] ? rr : T.rows - 1;
-      }
-      return row0 < T.rows;
-    };
-    typename ChunkOf<QT, R, U, GLU>::type c;
-    int row[R];
-    bool valid[R];
-    bool has_rows = rows_of(wi, row, valid);
-    if (KQ) stage_q8(T, smem, reinterpret_cast<short*>(smem + T.n), reinterpret_cast<float*>(smem + T.n + (T.n >> 8) * 32), tid, scratch);
-    else stage_f32(T, reinterpret_cast<float*>(smem), tid, scratch);
-    __syncthreads();
-    const bool comb = !GLU && L.comb_x != nullptr;
-    for (int g = wi; g < n_groups; g += nwg) {
-      if (g != wi) has_rows = rows_of(g, row, valid);
-      if (comb) {
-        // ---- fused MoE combine: slot vectors go out write-through (sc1), then one arrival per task ----
-        if (has_rows) {
-          float acc[R], acc2[R];
-          rows_dot<QT, R, U, GLU>(c, false, P, T.n, L.b0, L.b1, lpr_log2, lane, row, smem, acc, acc2);
-          if (sub == 0) {
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-              if (valid[r]) __hip_atomic_store(T.out + row[r], acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-          const unsigned old = __hip_atomic_fetch_add(L.comb_counter + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          comb_last = old == (unsigned)L.n_tasks - 1;
-          if (comb_last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __hip_atomic_store(L.comb_counter + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
-          }
-        }
-        __syncthreads();
-        if (comb_last) {  // all slots of these rows have landed: x += w_k * out_k (k order), then + shared
-          for (int rr = g * RG + tid; rr < min(T.rows, (g + 1) * RG); rr += 256) {
-            float xv = L.comb_x[rr];
-            for (int ti = 0; ti < L.n_tasks; ++ti) {
-              const float v = __hip_atomic_load(L.t[ti].out + rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if (L.t[ti].accum_w) xv = fmaf(v, *L.t[ti].accum_w, xv);  // src/infer.cpp:874-877
-              else xv += v;                                             // src/infer.cpp:900-903
-            }
-            L.comb_x[rr] = xv;
-          }
-        }
-        continue;
-      }
-      if (!has_rows) continue;
-      float acc[R], acc2[R];
-      rows_dot<QT, R, U, GLU>(c, false, P, T.n, L.b0, L.b1, lpr_log2, lane, row, smem, acc, acc2);
-      unsigned long long mykey = 0;
-      int myblk = -1;
-      if (sub == 0) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          if (!valid[r]) continue;
-          float* o = T.out + row[r];
-          if (GLU) {
-            const float hv = act_fn(acc[r], L.act) * acc2[r];  // src/infer.cpp:859-872
-            *o = hv;
-            if (T.bmax_out) {
-              const unsigned long long key = bmax_key(hv, row[r] & 255);
-              if (key > mykey) { mykey = key; myblk = row[r] >> 8; }
-            }
-          } else if (T.epilogue == EPI_ADD) {
-            *o += acc[r];  // residual add, src/infer.cpp:832-834,928-930
-          } else {
-            *o = acc[r];
-          }
-        }
-      }
-      if (GLU && T.bmax_out) {
-        // the rows of one wave are consecutive and (RPW*R divides 256) share a 256-block: reduce the
-        // key over the wave, then ONE atomic per wave (contended L2 atomics serialise at ~0.2 us each)
-        u32 hi = (u32)(mykey >> 32), lo = (u32)mykey;
-        const u32 hmax = wave_max_bits(hi);
-        if (hi != hmax) lo = 0;
-        const u32 lmax = wave_max_bits(lo);
-        const int blk = __builtin_amdgcn_readfirstlane((row0_of(g)) >> 8);
-        if (lane == 0 && (hmax | lmax)) atomicMax(T.bmax_out + blk, ((unsigned long long)hmax << 32) | lmax);
-        (void)myblk;
-      }
-    }
+    T.a_f32 += (size_t)head * T.n;
+    T.out += (size_t)head * T.rows;
   } else {
-    // ---- MoE combine: x[row] += sum_k w_k * (W2_{e_k}[row] . h_k) in k order, then + shared ----
-    const int nt = L.n_tasks;
-    const int rows = L.t[0].rows;
-    const int n_groups = (rows + RG - 1) / RG;
-    if ((int)blockIdx.x >= n_groups) return;
-    // stage every slot's activation once per (persistent) workgroup
-    if (KQ) {
-      stage_accum_q8(L, smem, tid);
-    } else {
-      size_t off = 0;
-      for (int ti = 0; ti < nt; ++ti) {
-        stage_f32(L.t[ti], reinterpret_cast<float*>(smem + off), tid, scratch);
-        off += ((size_t)L.t[ti].n * 4 + 15) & ~(size_t)15;
-      }
+    int ti = 0;
+    while (ti + 1 < L.n_tasks && (int)blockIdx.x >= L.t[ti].wg_end) ++ti;
+    T = L.t[ti];
+    wi = blockIdx.x - T.wg_begin;
+    nwg = T.wg_end - T.wg_begin;
+  }
+  const WPtr P = resolve(T);
+  if (!P.present) return;
+  const int n_groups = (T.rows + RG - 1) / RG;
+  if (wi >= n_groups) return;
+
+  auto row0_of = [&](int g) { return g * RG + wave * (RPW * R); };
+  auto rows_of = [&](int g, int (&row)[R], bool (&valid)[R]) {
+    const int row0 = g * RG + wave * (RPW * R);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int rr = row0 + r * RPW + rloc;
+      valid[r] = rr < T.rows;
+      row[r] = valid[r] ? rr : T.rows - 1;
     }
-    __syncthreads();
-    // slots are walked one after the other with ONE register chunk (a 12-way unrolled variant that
-    // requested all slots' weights up front was 4x slower: ~100 KB of code thrashes the instruction
-    // cache); memory-level parallelism comes from the ~6 waves per SIMD this small kernel allows
-    typename ChunkOf<QT, R, U, false>::type c;
-    for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
-      const int row0 = g * RG + wave * (RPW * R);
-      if (row0 >= rows) continue;
-      int row[R];
-      bool valid[R];
-      float xacc[R];
+    return row0 < T.rows;
+  };
+  int row[R];
+  bool valid[R];
+  bool has_rows = rows_of(wi, row, valid);
+  if (KQ) stage_q8<QT == DSK_QUANT_Q2_K>(T, smem, tid, scratch);
+  else stage_f32(T, reinterpret_cast<float*>(smem), tid, scratch);
+  __syncthreads();
+  const KQRsrc B = kq_rsrc<QT, GLU>(P);
+  const int nb = T.n >> 8, its = (nb * 4) >> lpr_log2, q = sub & 3;
+  const uint8_t* lds_lane = smem + sub * ITEM_LDS;
+  auto dot = [&](float (&acc)[R], float (&acc2)[R]) {
+    if constexpr (KQ) {
+      int rowblk[R];
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int rr = row0 + r * RPW + rloc;
-        valid[r] = rr < rows;
-        row[r] = valid[r] ? rr : rows - 1;
-        xacc[r] = L.t[0].out[row[r]];
-      }
-      size_t off = 0;
-      for (int ti = 0; ti < nt; ++ti) {
-        const GemvTask& T = L.t[ti];
-        const WPtr P = resolve(T);
+      for (int r = 0; r < R; ++r) rowblk[r] = row[r] * nb + (sub >> 2);
+      rows_dot_kq<QT, R, U, GLU>(B, its, lpr_log2, q, rowblk, lds_lane, acc, acc2);
+    } else {
+      rows_dot_f<QT, R, U, GLU>(P, T.n, L.b0, L.b1, lpr_log2, lane, row, smem, acc, acc2);
+    }
+  };
+  const bool comb = !GLU && L.comb_x != nullptr;
+  for (int g = wi; g < n_groups; g += nwg) {
+    if (g != wi) has_rows = rows_of(g, row, valid);
+    if (comb) {
+      // ---- fused MoE combine: slot vectors go out write-through (sc1), then one arrival per task ----
+      if (has_rows) {
         float acc[R], acc2[R];
+        dot(acc, acc2);
+        if (sub == 0) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = acc2[r] = 0.f;
-        if (P.present) rows_dot<QT, R, U, false>(c, false, P, T.n, L.b0, L.b1, lpr_log2, lane, row, smem + off, acc, acc2);
-        off += KQ ? (((size_t)T.n + (size_t)(T.n >> 8) * 36 + 15) & ~(size_t)15) : (((size_t)T.n * 4 + 15) & ~(size_t)15);
-        if (!P.present) continue;
-        if (T.accum_w) {
-          const float wk = *T.accum_w;  // src/infer.cpp:874-877
-#pragma unroll
-          for (int r = 0; r < R; ++r) xacc[r] = fmaf(acc[r], wk, xacc[r]);
-        } else {
-#pragma unroll
-          for (int r = 0; r < R; ++r) xacc[r] += acc[r];  // shared expert, src/infer.cpp:900-903
+          for (int r = 0; r < R; ++r)
+            if (valid[r]) __hip_atomic_store(T.out + row[r], acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
-      if (sub == 0) {
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-          if (valid[r]) L.t[0].out[row[r]] = xacc[r];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(L.comb_counter + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        comb_last = old == (unsigned)L.n_tasks - 1;
+        if (comb_last) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          __hip_atomic_store(L.comb_counter + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+        }
       }
+      __syncthreads();
+      if (comb_last) {  // all slots of these rows have landed: x += w_k * out_k (k order), then + shared
+        for (int rr = g * RG + tid; rr < min(T.rows, (g + 1) * RG); rr += 256) {
+          float xv = L.comb_x[rr];
+          for (int ti = 0; ti < L.n_tasks; ++ti) {
+            const float v = __hip_atomic_load(L.t[ti].out + rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (L.t[ti].accum_w) xv = fmaf(v, *L.t[ti].accum_w, xv);  // src/infer.cpp:874-877
+            else xv += v;                                             // src/infer.cpp:900-903
+          }
+          L.comb_x[rr] = xv;
+        }
+      }
+      continue;
+    }
+    if (!has_rows) continue;
+    float acc[R], acc2[R];
+    dot(acc, acc2);
+    unsigned long long mykey = 0;
+    if (sub == 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (!valid[r]) continue;
+        float* o = T.out + row[r];
+        if (GLU) {
+          const float hv = act_fn(acc[r], L.act) * acc2[r];  // src/infer.cpp:859-872
+          *o = hv;
+          if (T.bmax_out) {
+            const unsigned long long key = bmax_key(hv, row[r] & 255);
+            if (key > mykey) mykey = key;
+          }
+        } else if (T.epilogue == EPI_ADD) {
+          *o += acc[r];  // residual add, src/infer.cpp:832-834,928-930
+        } else {
+          *o = acc[r];
+        }
+      }
+    }
+    if (GLU && T.bmax_out) {
+      // the rows of one wave are consecutive and (RPW*R divides 256) share a 256-block: reduce the
+      // key over the wave, then ONE atomic per wave (contended L2 atomics serialise at ~0.2 us each)
+      u32 hi = (u32)(mykey >> 32), lo = (u32)mykey;
+      const u32 hmax = wave_max_bits(hi);
+      if (hi != hmax) lo = 0;
+      const u32 lmax = wave_max_bits(lo);
+      const int blk = __builtin_amdgcn_readfirstlane((row0_of(g)) >> 8);
+      if (lane == 0 && (hmax | lmax)) atomicMax(T.bmax_out + blk, ((unsigned long long)hmax << 32) | lmax);
     }
   }
 }
@@ -874,27 +833,17 @@ template <int QT, int R, int U>
 static void launch_one(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& h) {
   dim3 grid(h.grid), block(256);
   if (h.glu) {
-    auto k = gemv_kernel<QT, R, U, true, GEMV_MODE_TASKS>;
+    auto k = gemv_kernel<QT, R, U, true>;
     if (h.lds_bytes > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds_bytes);
     hipLaunchKernelGGL(k, grid, block, h.lds_bytes, st, dev);
   } else {
-    auto k = gemv_kernel<QT, R, U, false, GEMV_MODE_TASKS>;
+    auto k = gemv_kernel<QT, R, U, false>;
     if (h.lds_bytes > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds_bytes);
     hipLaunchKernelGGL(k, grid, block, h.lds_bytes, st, dev);
   }
 }
 template <int QT>
-static void launch_accum(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& h) {  // always R = U = 1
-  auto k = gemv_kernel<QT, 1, 1, false, GEMV_MODE_ACCUM>;
-  if (h.lds_bytes > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds_bytes);
-  hipLaunchKernelGGL(k, dim3(h.grid), dim3(256), h.lds_bytes, st, dev);
-}
-template <int QT>
 static int launch_q(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& h) {
-  if (h.mode == GEMV_MODE_ACCUM) {
-    launch_accum<QT>(st, dev, h);
-    return DSK_OK;
-  }
   // (R, U) variants: R rows x U column steps = the 16-byte loads a lane keeps in flight
   switch (h.R * 16 + h.U) {
     case 1 * 16 + 8: launch_one<QT, 1, 8>(st, dev, h); break;
@@ -936,15 +885,16 @@ int gemv_plan(GemvLaunch& h, int target_wgs) {
     if (T.rows <= 0 || T.n <= 0) DSK_FAIL(DSK_ERR_INVALID, "gemv: empty shape %d x %d", T.rows, T.n);
     if (kq && T.n % QK_K) DSK_FAIL(DSK_ERR_INVALID, "k-quant gemv: n=%d is not a multiple of 256 (quantizer.cpp:8)", T.n);
     if (!kq && T.n % epi) DSK_FAIL(DSK_ERR_INVALID, "gemv: n=%d is not a multiple of %d (src/infer.cpp:169,246)", T.n, epi);
-    const size_t lds = kq ? (size_t)T.n + (size_t)(T.n / 256) * 36 : (size_t)T.n * 4;
+    const size_t lds = kq ? (size_t)(T.n / 64) * ITEM_LDS : (size_t)T.n * 4;
     lds_max = lds > lds_max ? lds : lds_max;
     lds_sum += (lds + 15) & ~(size_t)15;
     total_rows += T.rows;
     total_work += (double)T.rows * T.n * (h.glu ? 2 : 1);
     min_items = T.n / epi < min_items ? T.n / epi : min_items;
-    if (h.mode == GEMV_MODE_ACCUM && T.rows != h.t[0].rows) DSK_FAIL(DSK_ERR_INVALID, "gemv accumulate: tasks must share the row count");
+    if (h.comb_x && T.rows != h.t[0].rows) DSK_FAIL(DSK_ERR_INVALID, "gemv combine: tasks must share the row count");
   }
-  h.lds_bytes = h.mode == GEMV_MODE_ACCUM ? lds_sum : lds_max;
+  h.lds_bytes = lds_max;
+  (void)lds_sum;
   if (h.lds_bytes > 150 * 1024) DSK_FAIL(DSK_ERR_UNSUPPORTED, "gemv: activation vector(s) need %zu B of LDS", h.lds_bytes);
   if (h.b0 < 1) h.b0 = 1;
   if (h.b1 < 1) h.b1 = 1;
@@ -956,28 +906,31 @@ int gemv_plan(GemvLaunch& h, int target_wgs) {
     if (ok) break;
     lpr >>= 1;
   }
-  if (h.force_lpr > 0) lpr = h.force_lpr;
-  const long rows_eff = h.mode == GEMV_MODE_ACCUM ? h.t[0].rows : (h.bd_heads > 0 ? (long)h.t[0].rows * h.bd_heads : total_rows);
+  if (h.force_lpr > 0) {
+    for (int i = 0; i < h.n_tasks; ++i)
+      if ((h.t[i].n / epi) % h.force_lpr || (kq && h.force_lpr < 4)) DSK_FAIL(DSK_ERR_INVALID, "gemv: lanes-per-row %d does not divide the row", h.force_lpr);
+    lpr = h.force_lpr;
+  }
+  const long rows_eff = h.bd_heads > 0 ? (long)h.t[0].rows * h.bd_heads : total_rows;
   h.lpr_log2 = ilog2(lpr);
-  // (R, U) variant.  Measured on MI355X (tools/kbench.py): occupancy beats per-wave unrolling --
-  // the GLU pair and the MoE accumulate are fastest at R = U = 1 (few VGPRs, 8 waves/SIMD), a plain
-  // GEMV gains a little from U = 4 (plain 32768x7168: 4.18 vs 3.97 TB/s).
+  // (R, U) variant and grid, from the sweeps of tools/kbench.py on MI355X (DeepSeek-V3 shapes): the
+  // geometry moves a launch by < 10 % -- U = 4 column steps in flight is right for plain and GLU
+  // launches alike, big launches (> 64 MB) want ~8 workgroups per CU.  The fused MoE combine pays one
+  // arrival (barrier + atomic round trip) per row group, so it wants FEW, tall groups: 8 lanes per row,
+  // 2 row sets => 64 rows per group (experts_w2: 16.7 us vs 46 us at 32 lanes per row).
+  if (h.comb_x && h.force_lpr <= 0) {
+    while (lpr > 8) lpr >>= 1;
+    h.lpr_log2 = ilog2(lpr);
+  }
   const int its = (min_items + lpr - 1) / lpr;
-  h.R = 1;
-  h.U = 1;
-  if (!h.glu && h.mode != GEMV_MODE_ACCUM) h.U = its >= 4 ? 4 : (its >= 2 ? 2 : 1);
+  h.R = h.comb_x ? 2 : 1;
+  h.U = its >= 4 ? 4 : (its >= 2 ? 2 : 1);
+  if (h.comb_x && h.U > 2) h.U = 2;
+  if (total_work >= 256e6 && target_wgs < 2048) target_wgs = 2048;
   (void)rows_eff;
   if (h.force_R > 0) h.R = h.force_R;
   if (h.force_U > 0) h.U = h.force_U;
-  if (h.mode == GEMV_MODE_ACCUM) h.R = h.U = 1;
   const int RG = 4 * (64 / lpr) * h.R;
-  if (h.mode == GEMV_MODE_ACCUM) {
-    const int n_groups = (h.t[0].rows + RG - 1) / RG;
-    int per = (n_groups + target_wgs - 1) / target_wgs;  // groups per workgroup, balanced
-    h.grid = (n_groups + per - 1) / per;
-    for (int i = 0; i < h.n_tasks; ++i) { h.t[i].wg_begin = 0; h.t[i].wg_end = h.grid; }
-    return DSK_OK;
-  }
   if (h.bd_heads > 0) {
     const int n_groups = (h.t[0].rows + RG - 1) / RG;
     int per_head = target_wgs / h.bd_heads;

@@ -292,7 +292,7 @@ extern "C" int dsk_measure_read_bw(dsk_ctx* ctx, size_t bytes, int iters, double
 
 // ------------------------------------------------------------------------------------
 // micro-benchmark of the GEMV kernel on device-resident synthetic weights (diagnostics; used by
-// tools/kbench.py to pick launch geometry).  kind: 0 plain, 1 GLU pair, 2 MoE accumulate kernel, 3 per-slot + fused combine.
+// tools/kbench.py to pick launch geometry).  kind: 0 plain, 1 GLU pair, 2 or 3 per-slot MoE W2 + fused combine.
 // Weight sets are rotated through > 512 MB so that the 256 MB Infinity Cache cannot serve them.
 // ------------------------------------------------------------------------------------
 extern "C" int dsk_bench_gemv(dsk_ctx* ctx, int quant, int rows, int n, int n_tasks, int kind, int act_mode, int force_lpr,
@@ -332,7 +332,7 @@ extern "C" int dsk_bench_gemv(dsk_ctx* ctx, int quant, int rows, int n, int n_ta
   for (int c = 0; c < copies; ++c) {
     GemvLaunch& h = H[c];
     memset(&h, 0, sizeof h);
-    h.quant = quant; h.mode = kind == 2 ? GEMV_MODE_ACCUM : GEMV_MODE_TASKS; h.glu = kind == 1; h.act = DSK_ACT_SILU;
+    h.quant = quant; h.mode = GEMV_MODE_TASKS; h.glu = kind == 1; h.act = DSK_ACT_SILU;
     h.b0 = h.b1 = 128; h.force_lpr = force_lpr; h.force_R = force_R; h.force_U = force_U;
     for (int i = 0; i < n_tasks; ++i) {
       GemvTask& T = h.t[h.n_tasks++];
@@ -346,10 +346,10 @@ extern "C" int dsk_bench_gemv(dsk_ctx* ctx, int quant, int rows, int n, int n_ta
       if (act_mode == ACT_Q8) { T.a_qs = aq; T.a_d = ad; T.a_bsums = ab; }
       T.a_f32 = x.as<float>() + (kind >= 2 ? (size_t)i * n : 0);
       T.norm_w = nw.as<float>(); T.eps = 1e-6f;
-      T.out = kind == 2 ? out.as<float>() : out.as<float>() + (size_t)i * rows;
+      T.out = out.as<float>() + (size_t)i * rows;
       T.accum_w = kind >= 2 ? wts.as<float>() + i : nullptr;
     }
-    if (kind == 3) { h.comb_x = xres.as<float>(); h.comb_counter = cnt.as<unsigned>(); }
+    if (kind >= 2) { h.comb_x = xres.as<float>(); h.comb_counter = cnt.as<unsigned>(); }
     DSK_TRY(gemv_plan(h, target_wgs > 0 ? target_wgs : 1024));
   }
   DSK_TRY(plans.alloc(sizeof(GemvLaunch) * copies));
