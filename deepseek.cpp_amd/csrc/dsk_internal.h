@@ -178,9 +178,15 @@ struct AttnMhaArgs {
   uint16_t* value_cache;
   float* out;           // (H, v)
   int n_heads, head_dim, nope, rope, v_dim, lora, is_v3;
+  // fused launch only: Q8_K copy of `out` for the wo GEMV (null: none); one arrival counter per 256-block
+  int8_t* q_qs;
+  float* q_d;
+  int16_t* q_bsums;
+  unsigned* q_counter;
 };
 int launch_rope_kv_mha(hipStream_t st, const AttnMhaArgs& a, const StepParams* sp);
 int launch_attn_mha(hipStream_t st, const AttnMhaArgs& a, const StepParams* sp, int kv_len_override, int max_kv);
+int launch_attn_mha_fused(hipStream_t st, const AttnMhaArgs& a, const StepParams* sp, int max_kv);
 struct AttnMlaArgs {
   float* q_rope;         // (H, rope)
   const float* q_c;      // (H, lora)

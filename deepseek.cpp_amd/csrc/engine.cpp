@@ -483,6 +483,8 @@ extern "C" int dsk_model_finalize(dsk_model* m) {
   memset(m->sp_host, 0, sizeof(StepParams));
   HIP_TRY(hipMalloc((void**)&m->router_counter, 64));
   HIP_TRY(hipMemset(m->router_counter, 0, 64));
+  HIP_TRY(hipMalloc((void**)&m->att_counter, ((size_t)c.n_heads * c.v_head_dim / 256 + 2) * 4));
+  HIP_TRY(hipMemset(m->att_counter, 0, ((size_t)c.n_heads * c.v_head_dim / 256 + 2) * 4));
   HIP_TRY(hipMalloc((void**)&m->comb_counter, (size_t)c.dim * 4));
   HIP_TRY(hipMemset(m->comb_counter, 0, (size_t)c.dim * 4));
   m->bmax_per_layer = (hb_n + 255) / 256;
@@ -524,6 +526,7 @@ extern "C" int dsk_model_destroy(dsk_model* m) {
   free_plans(m);
   if (m->router_counter) hipFree(m->router_counter);
   if (m->comb_counter) hipFree(m->comb_counter);
+  if (m->att_counter) hipFree(m->att_counter);
   if (m->bmax) hipFree(m->bmax);
   free_q8(m->a_xb); free_q8(m->a_qa); free_q8(m->a_kva); free_q8(m->a_att); free_q8(m->a_hb);
   if (m->sp_host) hipHostFree(m->sp_host);

@@ -73,6 +73,7 @@ struct dsk_model {
   std::vector<int> lp_qkv_a, lp_qkv_b, lp_wv_b, lp_wo, lp_w13, lp_w2, lp_w2_shared;  // per-layer indices into plans (-1: none)
   int lp_head = -1;
   unsigned* router_counter = nullptr;
+  unsigned* att_counter = nullptr;   // one arrival counter per 256-block of the attention output
   unsigned* comb_counter = nullptr;  // one arrival counter per row group of the fused MoE combine
   unsigned long long* bmax = nullptr;  // [n_layers][bmax_per_layer] block-max keys of the hidden vectors (zeroed per token)
   size_t bmax_per_layer = 0;

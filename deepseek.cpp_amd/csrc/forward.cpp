@@ -340,9 +340,11 @@ static int attention_mha(dsk_model* m, int l, int max_kv) {
   a.q = m->q; a.kv_b = m->kv_b; a.kv_a = m->kv_a; a.key_cache = L.key_cache; a.value_cache = L.value_cache; a.out = m->att_out;
   a.n_heads = H; a.head_dim = hd; a.nope = c.qk_nope_head_dim; a.rope = c.qk_rope_head_dim; a.v_dim = c.v_head_dim;
   a.lora = c.kv_lora_rank; a.is_v3 = c.has_moegate_bias;
-  PROFILED("rope_kv", (double)H * (hd * 6 + c.v_head_dim * 6), launch_rope_kv_mha(st, a, m->sp_dev));
-  PROFILED("attn_mha", (double)m->sp_host->kv_len * H * (hd + c.v_head_dim) * 2, launch_attn_mha(st, a, m->sp_dev, 0, max_kv));
-  DSK_TRY(run_quant(m, m->att_out, H * c.v_head_dim, m->a_att));
+  a.q_qs = nullptr; a.q_d = nullptr; a.q_bsums = nullptr; a.q_counter = m->att_counter;
+  if (is_kq(c.weight_quant)) { a.q_qs = m->a_att.qs; a.q_d = m->a_att.d; a.q_bsums = m->a_att.bsums; }
+  // rope + cache write + attention + Q8_K of the head outputs: one launch
+  PROFILED("attn_mha", (double)m->sp_host->kv_len * H * (hd + c.v_head_dim) * 2 + (double)H * (hd * 6 + c.v_head_dim * 11),
+           launch_attn_mha_fused(st, a, m->sp_dev, max_kv));
   DSK_TRY(run_plan(m, "gemv_wo", m->lp_wo[l]));  // residual: src/infer.cpp:832-834
   return DSK_OK;
 }

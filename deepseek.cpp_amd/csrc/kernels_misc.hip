@@ -530,8 +530,7 @@ int launch_router_gate(hipStream_t st, const RouterArgs& a) {
 // MHA path: RoPE on q, assemble k/v, f16 cache write, attention-sink rotation.
 // BlockMHA::_attention_impl, src/infer.cpp:956-1020.  One workgroup per head.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rope_kv_mha_kernel(AttnMhaArgs a, const StepParams* __restrict__ sp) {
-  const int h = blockIdx.x, tid = threadIdx.x;
+DEV void rope_kv_mha_body(const AttnMhaArgs& a, const StepParams* __restrict__ sp, int h, int tid) {
   const int hd = a.head_dim, nope = a.nope, rope = a.rope, vd = a.v_dim;
   const int kv_pos = sp->kv_pos, kv_sink = sp->kv_sink;
   // q rope, in place
@@ -579,6 +578,9 @@ __global__ __launch_bounds__(256) void rope_kv_mha_kernel(AttnMhaArgs a, const S
     __syncthreads();
   }
 }
+__global__ __launch_bounds__(256) void rope_kv_mha_kernel(AttnMhaArgs a, const StepParams* __restrict__ sp) {
+  rope_kv_mha_body(a, sp, blockIdx.x, threadIdx.x);
+}
 int launch_rope_kv_mha(hipStream_t st, const AttnMhaArgs& a, const StepParams* sp) {
   if (a.rope > 128 || (a.rope & 1)) DSK_FAIL(DSK_ERR_UNSUPPORTED, "rope dim %d (max 128, even)", a.rope);
   hipLaunchKernelGGL(rope_kv_mha_kernel, dim3(a.n_heads), dim3(256), 0, st, a, sp);
@@ -589,33 +591,50 @@ int launch_rope_kv_mha(hipStream_t st, const AttnMhaArgs& a, const StepParams* s
 // attn (per head), src/infer.cpp:728-762: scores = q.k / sqrt(head_dim), softmax, sum att*v.
 // One workgroup per head; scores live in LDS (kv_len floats).
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_mha_kernel(AttnMhaArgs a, const StepParams* __restrict__ sp, int kv_len_override) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  __shared__ float scratch[4];
-  __shared__ float part[256];
-  float* att = reinterpret_cast<float*>(smem);
-  const int h = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+// sum over the 16 lanes of a DPP row (every lane gets the total; VALU speed, no ds_bpermute)
+DEV float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));  // row_mirror
+  return v;
+}
+
+// returns this thread's output element (valid for tid < v_dim).  part: 256 / (v_dim / 4) * v_dim floats.
+// Scores: 16 lanes per cached position (4 positions per wave step, 128-byte coalesced f16 reads);
+// values: 4 output dims per thread, v_dim / 4 threads per position.
+DEV float attn_mha_body(const AttnMhaArgs& a, int kv_len, int h, int tid, float* att, float* scratch, float* part) {
+  const int wave = tid >> 6, lane = tid & 63, grp = lane >> 4, sl = lane & 15;
   const int hd = a.head_dim, vd = a.v_dim, H = a.n_heads;
-  const int kv_len = kv_len_override > 0 ? kv_len_override : sp->kv_len;
   const float* q = a.q + (size_t)h * hd;
-  float qv[4] = {0.f, 0.f, 0.f, 0.f};
-  const bool act = lane * 4 < hd;
-  if (act) {
+  float qv[4][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) qv[i] = q[lane * 4 + i];
+  for (int j = 0; j < 4; ++j) {
+    const int d0 = 64 * j + sl * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qv[j][i] = d0 < hd ? q[d0 + i] : 0.f;
   }
   const float inv = sqrtf((float)hd);
-  for (int t = wave; t < kv_len; t += 4) {
+  for (int t0 = wave * 4; t0 < kv_len; t0 += 16) {
+    const int t = t0 + grp;
     float p = 0.f;
-    if (act) {
-      const f16x4 k = *reinterpret_cast<const f16x4*>(a.key_cache + ((size_t)t * H + h) * hd + lane * 4);
-      p = fmaf(qv[0], (float)k.x, p);
-      p = fmaf(qv[1], (float)k.y, p);
-      p = fmaf(qv[2], (float)k.z, p);
-      p = fmaf(qv[3], (float)k.w, p);
+    if (t < kv_len) {
+      const uint16_t* kr = a.key_cache + ((size_t)t * H + h) * hd;
+      f16x4 k[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (64 * j + sl * 4 < hd) k[j] = *reinterpret_cast<const f16x4*>(kr + 64 * j + sl * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (64 * j + sl * 4 < hd) {
+          p = fmaf(qv[j][0], (float)k[j].x, p);
+          p = fmaf(qv[j][1], (float)k[j].y, p);
+          p = fmaf(qv[j][2], (float)k[j].z, p);
+          p = fmaf(qv[j][3], (float)k[j].w, p);
+        }
     }
-    p = wave_sum(p);
-    if (lane == 0) att[t] = p / inv;
+    p = row16_sum(p);
+    if (sl == 0 && t < kv_len) att[t] = p / inv;
   }
   __syncthreads();
   // softmax, src/infer.cpp:472-487
@@ -631,23 +650,90 @@ __global__ __launch_bounds__(256) void attn_mha_kernel(AttnMhaArgs a, const Step
   sum = block_sum(sum, scratch, tid, 256);
   for (int t = tid; t < kv_len; t += 256) att[t] = att[t] / sum;
   __syncthreads();
-  // mix values: thread (g, i) sums t = g, g+G, ... for output i; groups are added in order
-  const int G = 256 / vd > 0 ? 256 / vd : 1;
-  const int g = tid / vd, i = tid % vd;
-  float acc = 0.f;
-  if (g < G) {
-    for (int t = g; t < kv_len; t += G) acc = fmaf(att[t], h2f(a.value_cache[((size_t)t * H + h) * vd + i]), acc);
+  // mix values: thread (g, i4) sums positions g, g+TG, ... for outputs 4*i4..4*i4+3; groups are added in order
+  const int tpp = vd >> 2;        // threads per position
+  const int TG = 256 / tpp;       // positions in flight
+  const int g = tid / tpp, i4 = tid - g * tpp;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (g < TG) {
+    for (int t = g; t < kv_len; t += TG) {
+      const float w = att[t];
+      const f16x4 v = *reinterpret_cast<const f16x4*>(a.value_cache + ((size_t)t * H + h) * vd + i4 * 4);
+      acc[0] = fmaf(w, (float)v.x, acc[0]);
+      acc[1] = fmaf(w, (float)v.y, acc[1]);
+      acc[2] = fmaf(w, (float)v.z, acc[2]);
+      acc[3] = fmaf(w, (float)v.w, acc[3]);
+    }
+    *reinterpret_cast<f32x4*>(part + (size_t)g * vd + i4 * 4) = f32x4{acc[0], acc[1], acc[2], acc[3]};
   }
-  part[tid] = acc;
   __syncthreads();
-  if (tid < vd) {
-    float o = 0.f;
-    for (int gg = 0; gg < G; ++gg) o += part[gg * vd + tid];
-    a.out[(size_t)h * vd + tid] = o;
+  float o = 0.f;
+  if (tid < vd)
+    for (int gg = 0; gg < TG; ++gg) o += part[gg * vd + tid];
+  return o;
+}
+__global__ __launch_bounds__(256) void attn_mha_kernel(AttnMhaArgs a, const StepParams* __restrict__ sp, int kv_len_override) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ float scratch[4];
+  __shared__ __attribute__((aligned(16))) float part[1024];
+  const int h = blockIdx.x, tid = threadIdx.x;
+  const float o = attn_mha_body(a, kv_len_override > 0 ? kv_len_override : sp->kv_len, h, tid, reinterpret_cast<float*>(smem), scratch, part);
+  if (tid < a.v_dim) a.out[(size_t)h * a.v_dim + tid] = o;
+}
+
+// The whole per-head attention step in ONE launch: RoPE + cache write + sink rotation
+// (src/infer.cpp:956-1020), attention (:728-762), and the Q8_K quantisation of the concatenated head
+// outputs that the wo GEMV consumes (src/quant.cpp:616-653): a 256-block spans 256 / v_dim heads, the
+// LAST of them to arrive (write-through stores, one counter per block) quantises the block.
+__global__ __launch_bounds__(256) void attn_mha_fused_kernel(AttnMhaArgs a, const StepParams* __restrict__ sp) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ float scratch[4];
+  __shared__ __attribute__((aligned(16))) float part[1024];
+  __shared__ int last_flag;
+  const int h = blockIdx.x, tid = threadIdx.x, vd = a.v_dim;
+  rope_kv_mha_body(a, sp, h, tid);
+  __syncthreads();  // q (rotated in place) and this position's k / v are re-read below by other threads
+  const float o = attn_mha_body(a, sp->kv_len, h, tid, reinterpret_cast<float*>(smem), scratch, part);
+  if (!a.q_qs) {
+    if (tid < vd) a.out[(size_t)h * vd + tid] = o;
+    return;
+  }
+  if (tid < vd) __hip_atomic_store(a.out + (size_t)h * vd + tid, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int b_first = (h * vd) >> 8, b_last = ((h + 1) * vd - 1) >> 8;
+  for (int b = b_first; b <= b_last; ++b) {
+    if (tid == 0) {
+      const int h0 = (b * 256) / vd, h1 = min((b * 256 + 255) / vd, a.n_heads - 1);
+      const unsigned old = __hip_atomic_fetch_add(a.q_counter + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last_flag = old == (unsigned)(h1 - h0);
+      if (last_flag) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(a.q_counter + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();
+    if (last_flag && tid < 64) {
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = __hip_atomic_load(a.out + (size_t)b * 256 + tid * 4 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      q8k_block(v, tid, a.q_qs + (size_t)b * 256, a.q_d + b, a.q_bsums + (size_t)b * 16);
+    }
+    __syncthreads();
   }
 }
+int launch_attn_mha_fused(hipStream_t st, const AttnMhaArgs& a, const StepParams* sp, int max_kv) {
+  if (a.rope > 128 || (a.rope & 1)) DSK_FAIL(DSK_ERR_UNSUPPORTED, "rope dim %d (max 128, even)", a.rope);
+  if (a.head_dim > 256 || a.head_dim % 4 || a.v_dim > 256 || a.v_dim % 4) DSK_FAIL(DSK_ERR_UNSUPPORTED, "attn: head_dim %d / v_head_dim %d", a.head_dim, a.v_dim);
+  if (a.q_qs && (a.n_heads * a.v_dim) % 256) DSK_FAIL(DSK_ERR_INVALID, "attn: n_heads * v_head_dim = %d is not a multiple of 256", a.n_heads * a.v_dim);
+  const size_t lds = (size_t)max_kv * 4;
+  if (lds > 150 * 1024) DSK_FAIL(DSK_ERR_UNSUPPORTED, "attn: kv_len %d does not fit LDS", max_kv);
+  if (lds > 64 * 1024) hipFuncSetAttribute((const void*)attn_mha_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(attn_mha_fused_kernel, dim3(a.n_heads), dim3(256), lds, st, a, sp);
+  return DSK_OK;
+}
 int launch_attn_mha(hipStream_t st, const AttnMhaArgs& a, const StepParams* sp, int kv_len_override, int max_kv) {
-  if (a.head_dim > 256 || a.head_dim % 4 || a.v_dim > 256) DSK_FAIL(DSK_ERR_UNSUPPORTED, "attn: head_dim %d / v_head_dim %d", a.head_dim, a.v_dim);
+  if (a.head_dim > 256 || a.head_dim % 4 || a.v_dim > 256 || a.v_dim % 4) DSK_FAIL(DSK_ERR_UNSUPPORTED, "attn: head_dim %d / v_head_dim %d", a.head_dim, a.v_dim);
   const size_t lds = (size_t)max_kv * 4;
   if (lds > 150 * 1024) DSK_FAIL(DSK_ERR_UNSUPPORTED, "attn: kv_len %d does not fit LDS", max_kv);
   if (lds > 64 * 1024) hipFuncSetAttribute((const void*)attn_mha_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

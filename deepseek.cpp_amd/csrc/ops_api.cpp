@@ -231,6 +231,7 @@ extern "C" int dsk_attn_mha(dsk_ctx* ctx, const float* q, const uint16_t* kb, co
   HIP_TRY(hipMemcpyAsync(dv.p, vb, vb_n * 2, hipMemcpyHostToDevice, st));
   AttnMhaArgs a;
   memset(&a, 0, sizeof a);
+  memset(&a, 0, sizeof a);
   a.q = dq.as<float>(); a.key_cache = dk.as<uint16_t>(); a.value_cache = dv.as<uint16_t>(); a.out = dout.as<float>();
   a.n_heads = n_heads; a.head_dim = head_dim; a.v_dim = v_head_dim;
   DSK_TRY(launch_attn_mha(st, a, nullptr, kv_len, kv_len));
