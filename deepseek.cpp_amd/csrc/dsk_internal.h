@@ -58,7 +58,7 @@ struct DTensor {
 // A launch descriptor lives in device memory (built once per layer at finalize time: every
 // pointer in it is fixed for the life of the model, so a captured graph can replay it).
 enum { EPI_STORE = 0, EPI_ADD = 1 };
-enum { ACT_Q8 = 0, ACT_F32 = 1, ACT_F32_NORM = 2, ACT_F32_BMAX = 3 };
+enum { ACT_Q8 = 0, ACT_F32 = 1, ACT_F32_NORM = 2 };
 enum { GEMV_MODE_TASKS = 0, GEMV_MODE_ACCUM = 1 };
 #define GEMV_MAX_TASKS 12
 
@@ -81,23 +81,31 @@ struct GemvTask {
   const float* norm_w;     // rmsnorm weight
   float eps;
   float* norm_out;         // optional: workgroup 0 of the task also stores the normed f32 vector
-  // ACT_F32_BMAX: the producer already found, per 256-block, the first element of largest magnitude
-  // (64-bit key, see bmax_key() in kernels_gemv.hip); the prologue only rounds.
-  const unsigned long long* a_bmax;
-  unsigned long long* bmax_out;  // producer side: GLU epilogue atomically maxes its output's block keys
   // output
   float* out;
   int epilogue;            // EPI_*
   const float* accum_w;    // GEMV_MODE_ACCUM: device pointer to this slot's mixing weight (null: 1)
-  int wg_begin, wg_end;    // workgroup range of this task
+  // Consecutive tasks reading the SAME activation vector form an activation group: they share one
+  // workgroup range and their rows are concatenated into one virtual row space that the group's
+  // workgroups split evenly (so 8 routed experts + the shared expert balance like one dense matrix)
+  int wg_begin, wg_end;      // workgroup range of the task's activation group
+  int vrow_begin, vrow_end;  // this task's rows inside the group's virtual row space
 };
 
 struct GemvLaunch {
+  // activation-group table, first so that ONE scalar load brings it in (walking the tasks to find a
+  // workgroup's group cost a dependent scalar load per task: 3 us in front of a 9-task launch)
+  int n_groups;
+  int grp_wg_end[GEMV_MAX_TASKS];   // exclusive workgroup end of group g
+  int grp_t0[GEMV_MAX_TASKS + 1];   // first task of group g (grp_t0[n_groups] = n_tasks)
+  int pad_[6];
   GemvTask t[GEMV_MAX_TASKS];
   int n_tasks;
   int quant, mode, glu, act;  // act = DSK_ACT_* of the GLU epilogue
   int lpr_log2, R, U, grid;
-  int force_lpr, force_R, force_U;  // > 0: override the planner (micro-benchmarks)
+  int NW;                     // waves per workgroup (4 or 16)
+  int part_unit;              // rows are dealt to workgroups in multiples of this
+  int force_lpr, force_R, force_U, force_NW;  // > 0: override the planner (micro-benchmarks)
   int b0, b1;                 // F8 block-scale geometry
   // block-diagonal stack (MLA per-head wv_b, src/infer.cpp:1134-1137): t[0] describes head 0 of
   // `bd_heads` equal (rows, n) matrices stacked along rows; head h reads activation a_f32 + h*n and
@@ -108,6 +116,9 @@ struct GemvLaunch {
   // per group) runs  x[row] += w_k * out_k[row]  in k order, then + shared (src/infer.cpp:874-877,900-903)
   float* comb_x;
   unsigned* comb_counter;
+  // debug (DSK_TIMELINE=1 with dsk_bench_gemv): 4 wall-clock stamps per workgroup (entry, staged, first
+  // row group done, exit), 100 MHz s_memrealtime ticks
+  unsigned long long* timeline;
   size_t lds_bytes;
   double algo_bytes;          // host-side bookkeeping for the roofline report
 };

@@ -487,9 +487,6 @@ extern "C" int dsk_model_finalize(dsk_model* m) {
   HIP_TRY(hipMemset(m->att_counter, 0, ((size_t)c.n_heads * c.v_head_dim / 256 + 2) * 4));
   HIP_TRY(hipMalloc((void**)&m->comb_counter, (size_t)c.dim * 4));
   HIP_TRY(hipMemset(m->comb_counter, 0, (size_t)c.dim * 4));
-  m->bmax_per_layer = (hb_n + 255) / 256;
-  HIP_TRY(hipMalloc((void**)&m->bmax, (size_t)c.n_layers * m->bmax_per_layer * 8));
-  HIP_TRY(hipMemset(m->bmax, 0, (size_t)c.n_layers * m->bmax_per_layer * 8));
   DSK_TRY(build_plans(m));
   HIP_TRY(hipDeviceSynchronize());
   m->finalized = true;
@@ -527,7 +524,6 @@ extern "C" int dsk_model_destroy(dsk_model* m) {
   if (m->router_counter) hipFree(m->router_counter);
   if (m->comb_counter) hipFree(m->comb_counter);
   if (m->att_counter) hipFree(m->att_counter);
-  if (m->bmax) hipFree(m->bmax);
   free_q8(m->a_xb); free_q8(m->a_qa); free_q8(m->a_kva); free_q8(m->a_att); free_q8(m->a_hb);
   if (m->sp_host) hipHostFree(m->sp_host);
   if (m->logits_host) hipHostFree(m->logits_host);

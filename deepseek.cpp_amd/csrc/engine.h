@@ -75,8 +75,6 @@ struct dsk_model {
   unsigned* router_counter = nullptr;
   unsigned* att_counter = nullptr;   // one arrival counter per 256-block of the attention output
   unsigned* comb_counter = nullptr;  // one arrival counter per row group of the fused MoE combine
-  unsigned long long* bmax = nullptr;  // [n_layers][bmax_per_layer] block-max keys of the hidden vectors (zeroed per token)
-  size_t bmax_per_layer = 0;
   int target_wgs = 1024;
   // profiling
   bool profiling = false;

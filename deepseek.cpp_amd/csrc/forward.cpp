@@ -89,15 +89,16 @@ static void task_act_norm(GemvTask& T, const float* x, const DTensor& norm, floa
   T.act_mode = ACT_F32_NORM; T.a_f32 = x; T.norm_w = reinterpret_cast<const float*>(norm.qs); T.eps = eps;
 }
 static void task_act_f32(GemvTask& T, const float* x) { T.act_mode = ACT_F32; T.a_f32 = x; }
-// hidden vector produced by a GLU launch that also recorded its per-256-block maxima (K-quants)
+// hidden vector of a GLU launch; its consumer quantises it in the prologue.  (Recording per-block maxima
+// in the producer's epilogue with atomics was measured: +7 us on experts_w13, nothing gained in W2.)
 static void task_act_hb(const dsk_model* m, GemvTask& T, int layer, size_t off) {
+  (void)layer;
   T.a_f32 = m->hb + off;
-  if (is_kq(m->c.weight_quant)) { T.act_mode = ACT_F32_BMAX; T.a_bmax = m->bmax + (size_t)layer * m->bmax_per_layer + off / 256; }
-  else T.act_mode = ACT_F32;
+  T.act_mode = ACT_F32;
 }
 static void task_out_hb(const dsk_model* m, GemvTask& T, int layer, size_t off) {
+  (void)layer;
   T.out = m->hb + off;
-  if (is_kq(m->c.weight_quant)) T.bmax_out = m->bmax + (size_t)layer * m->bmax_per_layer + off / 256;
 }
 static void task_act_q8(GemvTask& T, const Q8Buf& q) { T.act_mode = ACT_Q8; T.a_qs = q.qs; T.a_d = q.d; T.a_bsums = q.bsums; }
 
@@ -422,7 +423,6 @@ static int enqueue_forward(dsk_model* m, int mode, int max_kv) {
   const dsk_config& c = m->c;
   hipStream_t st = m->ctx->stream;
   HIP_TRY(hipMemcpyAsync(m->sp_dev, m->sp_host, sizeof(StepParams), hipMemcpyHostToDevice, st));
-  if (m->bmax) HIP_TRY(hipMemsetAsync(m->bmax, 0, (size_t)c.n_layers * m->bmax_per_layer * 8, st));
   PROFILED("embed", (double)mat_bytes(c.weight_quant, 1, c.dim), launch_embed(st, m->g[DSK_ROLE_EMBED], m->sp_dev, -1, std::max(1, c.block_size[0]),
                                                                               std::max(1, c.block_size[1]), m->x));
   for (int l = 0; l < c.n_layers; ++l) {

@@ -158,16 +158,6 @@ DEV u32 wave_max_bits(u32 v) {
   return max(max(a, b), max(c, d));
 }
 
-// 64-bit key whose maximum over a 256-block identifies "the first element with the largest |x|"
-// (src/quant.cpp:622-629): |x| bits | inverted index | sign.  Producers atomicMax it per block.
-DEV unsigned long long bmax_key(float x, int idx) {
-  const u32 bits = __builtin_bit_cast(u32, x);
-  return ((unsigned long long)(bits & 0x7fffffffu) << 32) | ((unsigned long long)(0x7fffffffu - (u32)idx) << 1) | (bits >> 31);
-}
-DEV float bmax_value(unsigned long long key) {  // signed value of the winning element
-  return u2f((u32)(key >> 32) | ((u32)(key & 1) << 31));
-}
-
 // write one lane's share of a staged block: 4 consecutive int8 (elements 4*lane..+3), the sub-block
 // sum (lanes 4j) and the block scale (lanes 0..3, one per quarter record)
 template <bool Q2META>
@@ -252,17 +242,28 @@ DEV float lanes_sum(float v, int lpr_log2) {
   return v;
 }
 
-// sum of squares of x[0..n) over the whole workgroup (256 threads), deterministic order
+// fixed-order sum of the per-wave partials
+template <int NW>
+DEV float scratch_total(const float* scratch) {
+  if (NW == 4) return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < NW; i += 4) t += (scratch[i] + scratch[i + 1]) + (scratch[i + 2] + scratch[i + 3]);
+  return t;
+}
+
+// sum of squares of x[0..n) over the whole workgroup (NW waves), deterministic order
+template <int NW>
 DEV float wg_sumsq(const float* __restrict__ x, int n, int tid, float* scratch) {
   float ss = 0.f;
-  for (int i0 = tid * 4; i0 < n; i0 += 8 * 1024) {
+  for (int i0 = tid * 4; i0 < n; i0 += 8 * NW * 256) {
     f32x4 v[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k)
-      if (i0 + k * 1024 < n) v[k] = *reinterpret_cast<const f32x4*>(x + i0 + k * 1024);
+      if (i0 + k * NW * 256 < n) v[k] = *reinterpret_cast<const f32x4*>(x + i0 + k * NW * 256);
 #pragma unroll
     for (int k = 0; k < 8; ++k)
-      if (i0 + k * 1024 < n) {
+      if (i0 + k * NW * 256 < n) {
         ss = fmaf(v[k].x, v[k].x, ss);
         ss = fmaf(v[k].y, v[k].y, ss);
         ss = fmaf(v[k].z, v[k].z, ss);
@@ -272,18 +273,20 @@ DEV float wg_sumsq(const float* __restrict__ x, int n, int tid, float* scratch) 
   ss = wave_sum(ss);
   if ((tid & 63) == 0) scratch[tid >> 6] = ss;
   __syncthreads();
-  const float t = (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+  const float t = scratch_total<NW>(scratch);
   __syncthreads();
   return t;
 }
 
-// Stage one activation vector of a K-quant task in LDS (item records, see ITEM_LDS).
-template <bool Q2META>
-DEV void stage_q8(const GemvTask& T, uint8_t* lds, int tid, float* scratch) {
+// Stage one activation vector of a K-quant task in LDS (item records, see ITEM_LDS).  The VALU work of
+// the quantisation (~90 wave instructions per 256-block) is the serial part of every launch, which is
+// why big launches run 16-wave workgroups: 4x fewer blocks per wave, 4x fewer redundant prologues.
+template <bool Q2META, int NW>
+DEV void stage_q8(const GemvTask& T, uint8_t* lds, int tid, float* scratch, unsigned long long* tl = nullptr) {
   const int n = T.n, nb = n >> 8;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   if (T.act_mode == ACT_Q8) {  // ready Q8_K vector: 16-byte runs (one sub-block each) go straight to their record
-    for (int i = tid; i < (n >> 4); i += 256) {
+    for (int i = tid; i < (n >> 4); i += NW * 64) {
       const int b = i >> 4, j = i & 15, h = j >> 3, sidx = (j >> 1) & 3, lh = j & 1;
       uint8_t* rec = lds + (size_t)(b * 4 + 2 * h + lh) * ITEM_LDS;
       *reinterpret_cast<u32x4*>(rec + sidx * 16) = reinterpret_cast<const u32x4*>(T.a_qs)[i];
@@ -295,7 +298,7 @@ DEV void stage_q8(const GemvTask& T, uint8_t* lds, int tid, float* scratch) {
         reinterpret_cast<short*>(rec + 64)[sidx] = (short)bs;
       }
     }
-    for (int i = tid; i < nb * 4; i += 256) {
+    for (int i = tid; i < nb * 4; i += NW * 64) {
       const float d = T.a_d[i >> 2];
       float* m = reinterpret_cast<float*>(lds + (size_t)i * ITEM_LDS + 72);
       if (Q2META) { m[0] = d * 0.0625f; m[1] = d; }
@@ -303,14 +306,14 @@ DEV void stage_q8(const GemvTask& T, uint8_t* lds, int tid, float* scratch) {
     }
     return;
   }
+  constexpr int KB1 = 32 / NW;  // blocks per wave of the single-pass path
   if (T.act_mode == ACT_F32_NORM && nb <= 32) {
-    // rmsnorm (src/infer.cpp:601-611) + Q8_K in ONE memory round trip: wave w owns blocks w, w+4, ...
-    // (<= 8 per wave); x and the norm weight are loaded once and stay in registers across the
-    // sum-of-squares reduction.
-    f32x4 t[8], wv[8];
+    // rmsnorm (src/infer.cpp:601-611) + Q8_K in ONE memory round trip: wave w owns blocks w, w+NW, ...;
+    // x and the norm weight are loaded once and stay in registers across the sum-of-squares reduction.
+    f32x4 t[KB1], wv[KB1];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int b = wave + 4 * k;
+    for (int k = 0; k < KB1; ++k) {
+      const int b = wave + NW * k;
       if (b < nb) {
         t[k] = *reinterpret_cast<const f32x4*>(T.a_f32 + b * 256 + lane * 4);
         wv[k] = *reinterpret_cast<const f32x4*>(T.norm_w + b * 256 + lane * 4);
@@ -318,8 +321,8 @@ DEV void stage_q8(const GemvTask& T, uint8_t* lds, int tid, float* scratch) {
     }
     float ss = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      if (wave + 4 * k < nb) {
+    for (int k = 0; k < KB1; ++k) {
+      if (wave + NW * k < nb) {
         ss = fmaf(t[k].x, t[k].x, ss);
         ss = fmaf(t[k].y, t[k].y, ss);
         ss = fmaf(t[k].z, t[k].z, ss);
@@ -327,13 +330,15 @@ DEV void stage_q8(const GemvTask& T, uint8_t* lds, int tid, float* scratch) {
       }
     }
     ss = wave_sum(ss);
+    if (tl && tid == 0) tl[4] = wall_clock64();
     if (lane == 0) scratch[wave] = ss;
     __syncthreads();
-    const float total = (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+    const float total = scratch_total<NW>(scratch);
     const float scale = 1.0f / sqrtf(total / (float)n + T.eps);
+    if (tl && tid == 0) tl[5] = wall_clock64();
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int b = wave + 4 * k;
+    for (int k = 0; k < KB1; ++k) {
+      const int b = wave + NW * k;
       if (b < nb) {
         float v[4] = {t[k].x * scale * wv[k].x, t[k].y * scale * wv[k].y, t[k].z * scale * wv[k].z, t[k].w * scale * wv[k].w};
         if (T.norm_out) *reinterpret_cast<f32x4*>(T.norm_out + b * 256 + lane * 4) = f32x4{v[0], v[1], v[2], v[3]};
@@ -344,26 +349,24 @@ DEV void stage_q8(const GemvTask& T, uint8_t* lds, int tid, float* scratch) {
   }
   float scale = 1.0f;
   if (T.act_mode == ACT_F32_NORM) {  // long vectors: two passes
-    const float total = wg_sumsq(T.a_f32, n, tid, scratch);
+    const float total = wg_sumsq<NW>(T.a_f32, n, tid, scratch);
     scale = 1.0f / sqrtf(total / (float)n + T.eps);
   }
-  // wave w quantises blocks w, w+4, ...; the loads of 8 blocks are issued together, so even the
-  // longest vector (18432 = 72 blocks) costs three L2 round trips per workgroup
-  for (int b0 = wave; b0 < nb; b0 += 32) {
-    f32x4 t[8], wv[8];
-    float vm[8];
+  // wave w quantises blocks w, w+NW, ...; the loads of KB blocks are issued together
+  constexpr int KB = NW == 4 ? 8 : 5;
+  for (int b0 = wave; b0 < nb; b0 += KB * NW) {
+    f32x4 t[KB], wv[KB];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int b = b0 + 4 * k;
+    for (int k = 0; k < KB; ++k) {
+      const int b = b0 + NW * k;
       if (b < nb) {
         t[k] = *reinterpret_cast<const f32x4*>(T.a_f32 + b * 256 + lane * 4);
         if (T.act_mode == ACT_F32_NORM) wv[k] = *reinterpret_cast<const f32x4*>(T.norm_w + b * 256 + lane * 4);
-        if (T.act_mode == ACT_F32_BMAX) vm[k] = bmax_value(T.a_bmax[b]);
       }
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int b = b0 + 4 * k;
+    for (int k = 0; k < KB; ++k) {
+      const int b = b0 + NW * k;
       if (b < nb) {
         float v[4] = {t[k].x, t[k].y, t[k].z, t[k].w};
         if (T.act_mode == ACT_F32_NORM) {
@@ -373,20 +376,20 @@ DEV void stage_q8(const GemvTask& T, uint8_t* lds, int tid, float* scratch) {
           v[3] = v[3] * scale * wv[k].w;
           if (T.norm_out) *reinterpret_cast<f32x4*>(T.norm_out + b * 256 + lane * 4) = f32x4{v[0], v[1], v[2], v[3]};
         }
-        if (T.act_mode == ACT_F32_BMAX) q8k_round_lds<Q2META>(v, vm[k], lane, lds + (size_t)b * 4 * ITEM_LDS);
-        else q8k_block_lds<Q2META>(v, lane, lds + (size_t)b * 4 * ITEM_LDS);
+        q8k_block_lds<Q2META>(v, lane, lds + (size_t)b * 4 * ITEM_LDS);
       }
     }
   }
 }
 
 // Stage an f32 activation vector (F8 / F16 / F32 weights)
+template <int NW>
 DEV void stage_f32(const GemvTask& T, float* l_x, int tid, float* scratch) {
   const int n = T.n;
   if (T.act_mode == ACT_F32_NORM) {
-    const float total = wg_sumsq(T.a_f32, n, tid, scratch);
+    const float total = wg_sumsq<NW>(T.a_f32, n, tid, scratch);
     const float scale = 1.0f / sqrtf(total / (float)n + T.eps);
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += NW * 64) {
       const float y = T.a_f32[i] * scale * T.norm_w[i];
       l_x[i] = y;
       if (T.norm_out) T.norm_out[i] = y;
@@ -394,8 +397,8 @@ DEV void stage_f32(const GemvTask& T, float* l_x, int tid, float* scratch) {
   } else {
     const f32x4* src = reinterpret_cast<const f32x4*>(T.a_f32);
     f32x4* dst = reinterpret_cast<f32x4*>(l_x);
-    for (int i = tid; i < (n >> 2); i += 256) dst[i] = src[i];
-    for (int i = (n & ~3) + tid; i < n; i += 256) l_x[i] = T.a_f32[i];
+    for (int i = tid; i < (n >> 2); i += NW * 64) dst[i] = src[i];
+    for (int i = (n & ~3) + tid; i < n; i += NW * 64) l_x[i] = T.a_f32[i];
   }
 }
 
@@ -636,6 +639,8 @@ DEV void compute_chunk_f(const ChunkF<QT, R, U, GLU>& c, int n, int lpr_log2, in
 template <int QT, int R, int U, bool GLU>
 DEV void rows_dot_kq(const KQRsrc& B, int its, int lpr_log2, int q, const int (&rowblk)[R], const uint8_t* lds_lane,
                      float (&acc)[R], float (&acc2)[R]) {
+  // (requesting the first weight chunk before the staging prologue was measured and is slower: loads
+  // return in order, so the prologue's L2 reads queue behind the HBM reads, and the chunk costs registers)
   ChunkKQ<QT, R, U, GLU> c;
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = acc2[r] = 0.f;
@@ -670,12 +675,13 @@ DEV void rows_dot_f(const WPtr& P, int n, int b0, int b1, int lpr_log2, int lane
 }
 
 // ------------------------------------------------------------------------------------
-// the kernel: every workgroup serves one task (persistent over that task's row groups).
+// the kernel.  A workgroup belongs to one activation group (tasks sharing an input vector), stages that
+// vector once, and walks its even share of the group's concatenated rows.
 // ------------------------------------------------------------------------------------
-template <int QT, int R, int U, bool GLU>
-__global__ __launch_bounds__(256) void gemv_kernel(const GemvLaunch* __restrict__ Lp) {
+template <int QT, int R, int U, bool GLU, int NW>
+__global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvLaunch* __restrict__ Lp) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  __shared__ float scratch[4];
+  __shared__ float scratch[16];
   __shared__ bool comb_last;
   const GemvLaunch& L = *Lp;
   constexpr bool KQ = QT == DSK_QUANT_Q2_K || QT == DSK_QUANT_Q3_K;
@@ -683,141 +689,145 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvLaunch* __restrict_
   const int lpr_log2 = L.lpr_log2;
   const int RPW = 64 >> lpr_log2;
   const int rloc = lane >> lpr_log2, sub = lane & ((1 << lpr_log2) - 1);
-  const int RG = 4 * RPW * R;  // rows per workgroup step
+  const int RG = NW * RPW * R;  // rows per workgroup step
+  unsigned long long* tl = L.timeline ? L.timeline + (size_t)blockIdx.x * 8 : nullptr;
+  if (tl && tid == 0) tl[0] = wall_clock64();
 
-  GemvTask T;
-  int wi, nwg;
-  if (L.bd_heads > 0) {  // block-diagonal stack: workgroup -> head
-    const int head = blockIdx.x / L.bd_wgs;
+  int t0 = 0, t1 = 1, wi, nwg, head = 0;
+  const bool bd = L.bd_heads > 0;
+  if (bd) {  // block-diagonal stack: workgroup -> head
+    head = blockIdx.x / L.bd_wgs;
     wi = blockIdx.x - head * L.bd_wgs;
     nwg = L.bd_wgs;
-    T = L.t[0];
-    const size_t per = (size_t)T.rows * T.n;
-    if (QT == DSK_QUANT_Q2_K) {
-      T.qs += head * (per / 256 * 64); T.sc += head * (per / 256 * 16); T.dm += head * (per / 256 * 4);
-    } else if (QT == DSK_QUANT_Q3_K) {
-      T.qs += head * (per / 256 * 64); T.hm += head * (per / 256 * 32); T.sc += head * (per / 256 * 12); T.dm += head * (per / 256 * 2);
-    } else {
-      T.qs += head * per * FTraits<QT>::ESZ;
-      // reference indexing: expert_index * cdiv(d,b0)*cdiv(n,b1) (src/infer.cpp:437-438)
-      if (T.scale) T.scale += (size_t)head * ((T.rows + L.b0 - 1) / L.b0) * ((T.n + L.b1 - 1) / L.b1);
-    }
-    T.a_f32 += (size_t)head * T.n;
-    T.out += (size_t)head * T.rows;
   } else {
-    int ti = 0;
-    while (ti + 1 < L.n_tasks && (int)blockIdx.x >= L.t[ti].wg_end) ++ti;
-    T = L.t[ti];
-    wi = blockIdx.x - T.wg_begin;
-    nwg = T.wg_end - T.wg_begin;
+    int g = 0, wg0 = 0;
+#pragma unroll
+    for (int k = 0; k < GEMV_MAX_TASKS - 1; ++k)
+      if (k + 1 < L.n_groups && (int)blockIdx.x >= L.grp_wg_end[k]) { g = k + 1; wg0 = L.grp_wg_end[k]; }
+    t0 = L.grp_t0[g];
+    t1 = L.grp_t0[g + 1];
+    wi = blockIdx.x - wg0;
+    nwg = L.grp_wg_end[g] - wg0;
   }
-  const WPtr P = resolve(T);
-  if (!P.present) return;
-  const int n_groups = (T.rows + RG - 1) / RG;
-  if (wi >= n_groups) return;
-
-  auto row0_of = [&](int g) { return g * RG + wave * (RPW * R); };
-  auto rows_of = [&](int g, int (&row)[R], bool (&valid)[R]) {
-    const int row0 = g * RG + wave * (RPW * R);
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int rr = row0 + r * RPW + rloc;
-      valid[r] = rr < T.rows;
-      row[r] = valid[r] ? rr : T.rows - 1;
+  auto task_of = [&](int ti) {
+    GemvTask T = L.t[ti];
+    if (bd) {  // re-base the one task to this workgroup's head
+      const size_t per = (size_t)T.rows * T.n;
+      if (QT == DSK_QUANT_Q2_K) {
+        T.qs += head * (per / 256 * 64); T.sc += head * (per / 256 * 16); T.dm += head * (per / 256 * 4);
+      } else if (QT == DSK_QUANT_Q3_K) {
+        T.qs += head * (per / 256 * 64); T.hm += head * (per / 256 * 32); T.sc += head * (per / 256 * 12); T.dm += head * (per / 256 * 2);
+      } else {
+        T.qs += head * per * FTraits<QT>::ESZ;
+        // reference indexing: expert_index * cdiv(d,b0)*cdiv(n,b1) (src/infer.cpp:437-438)
+        if (T.scale) T.scale += (size_t)head * ((T.rows + L.b0 - 1) / L.b0) * ((T.n + L.b1 - 1) / L.b1);
+      }
+      T.a_f32 += (size_t)head * T.n;
+      T.out += (size_t)head * T.rows;
+      T.vrow_begin = 0;
+      T.vrow_end = T.rows;
     }
-    return row0 < T.rows;
+    return T;
   };
-  int row[R];
-  bool valid[R];
-  bool has_rows = rows_of(wi, row, valid);
-  if (KQ) stage_q8<QT == DSK_QUANT_Q2_K>(T, smem, tid, scratch);
-  else stage_f32(T, reinterpret_cast<float*>(smem), tid, scratch);
+  {
+    const GemvTask Ta = task_of(t0);
+    if (tl && tid == 0) tl[6] = wall_clock64();
+    if (KQ) stage_q8<QT == DSK_QUANT_Q2_K, NW>(Ta, smem, tid, scratch, tl);
+    else stage_f32<NW>(Ta, reinterpret_cast<float*>(smem), tid, scratch);
+  }
+  if (tl && tid == 0) tl[7] = wall_clock64();
   __syncthreads();
-  const KQRsrc B = kq_rsrc<QT, GLU>(P);
-  const int nb = T.n >> 8, its = (nb * 4) >> lpr_log2, q = sub & 3;
-  const uint8_t* lds_lane = smem + sub * ITEM_LDS;
-  auto dot = [&](float (&acc)[R], float (&acc2)[R]) {
-    if constexpr (KQ) {
-      int rowblk[R];
-#pragma unroll
-      for (int r = 0; r < R; ++r) rowblk[r] = row[r] * nb + (sub >> 2);
-      rows_dot_kq<QT, R, U, GLU>(B, its, lpr_log2, q, rowblk, lds_lane, acc, acc2);
-    } else {
-      rows_dot_f<QT, R, U, GLU>(P, T.n, L.b0, L.b1, lpr_log2, lane, row, smem, acc, acc2);
-    }
-  };
+  if (tl && tid == 0) tl[1] = wall_clock64();
+
+  // this workgroup's share of the group's virtual rows, in multiples of part_unit
+  const int vtotal = bd ? L.t[0].rows : L.t[t1 - 1].vrow_end;
+  const int unit = L.part_unit;
+  const long long units = (vtotal + unit - 1) / unit;
+  const int r_lo = (int)(units * wi / nwg) * unit;
+  int r_hi = (int)(units * (wi + 1) / nwg) * unit;
+  if (r_hi > vtotal) r_hi = vtotal;
   const bool comb = !GLU && L.comb_x != nullptr;
-  for (int g = wi; g < n_groups; g += nwg) {
-    if (g != wi) has_rows = rows_of(g, row, valid);
-    if (comb) {
-      // ---- fused MoE combine: slot vectors go out write-through (sc1), then one arrival per task ----
+  const uint8_t* lds_lane = smem + sub * ITEM_LDS;
+  const int q = sub & 3;
+  bool first = true;
+
+  for (int ti = t0; ti < t1; ++ti) {
+    const GemvTask T = task_of(ti);
+    const int vb = T.vrow_begin, ve = T.vrow_end;
+    const int lo = (r_lo > vb ? r_lo : vb) - vb, hi = (r_hi < ve ? r_hi : ve) - vb;
+    if (lo >= hi) continue;
+    const WPtr P = resolve(T);
+    if (!P.present) continue;
+    const KQRsrc B = kq_rsrc<QT, GLU>(P);
+    const int nb = T.n >> 8, its = (nb * 4) >> lpr_log2;
+    for (int base = lo; base < hi; base += RG) {
+      int row[R];
+      bool valid[R];
+      const int row0 = base + wave * (RPW * R);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int rr = row0 + r * RPW + rloc;
+        valid[r] = rr < hi;
+        row[r] = valid[r] ? rr : hi - 1;
+      }
+      const bool has_rows = row0 < hi;
+      float acc[R], acc2[R];
       if (has_rows) {
-        float acc[R], acc2[R];
-        dot(acc, acc2);
-        if (sub == 0) {
+        if constexpr (KQ) {
+          int rowblk[R];
+#pragma unroll
+          for (int r = 0; r < R; ++r) rowblk[r] = row[r] * nb + (sub >> 2);
+          rows_dot_kq<QT, R, U, GLU>(B, its, lpr_log2, q, rowblk, lds_lane, acc, acc2);
+        } else {
+          rows_dot_f<QT, R, U, GLU>(P, T.n, L.b0, L.b1, lpr_log2, lane, row, smem, acc, acc2);
+        }
+      }
+      if (tl && tid == 0 && first) tl[2] = wall_clock64();
+      first = false;
+      if (comb) {
+        // ---- fused MoE combine: slot vectors go out write-through (sc1), then one arrival per task ----
+        const int g = base / RG;  // part_unit == RG: a row group is computed by exactly one workgroup per task
+        if (has_rows && sub == 0) {
 #pragma unroll
           for (int r = 0; r < R; ++r)
             if (valid[r]) __hip_atomic_store(T.out + row[r], acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) {
-        const unsigned old = __hip_atomic_fetch_add(L.comb_counter + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        comb_last = old == (unsigned)L.n_tasks - 1;
-        if (comb_last) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          __hip_atomic_store(L.comb_counter + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
-        }
-      }
-      __syncthreads();
-      if (comb_last) {  // all slots of these rows have landed: x += w_k * out_k (k order), then + shared
-        for (int rr = g * RG + tid; rr < min(T.rows, (g + 1) * RG); rr += 256) {
-          float xv = L.comb_x[rr];
-          for (int ti = 0; ti < L.n_tasks; ++ti) {
-            const float v = __hip_atomic_load(L.t[ti].out + rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (L.t[ti].accum_w) xv = fmaf(v, *L.t[ti].accum_w, xv);  // src/infer.cpp:874-877
-            else xv += v;                                             // src/infer.cpp:900-903
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+          const unsigned old = __hip_atomic_fetch_add(L.comb_counter + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          comb_last = old == (unsigned)L.n_tasks - 1;
+          if (comb_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(L.comb_counter + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
           }
-          L.comb_x[rr] = xv;
         }
+        __syncthreads();
+        if (comb_last) {  // all slots of these rows have landed: x += w_k * out_k (k order), then + shared
+          for (int rr = base + tid; rr < min(T.rows, base + RG); rr += NW * 64) {
+            float xv = L.comb_x[rr];
+            for (int tj = 0; tj < L.n_tasks; ++tj) {
+              const float v = __hip_atomic_load(L.t[tj].out + rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (L.t[tj].accum_w) xv = fmaf(v, *L.t[tj].accum_w, xv);  // src/infer.cpp:874-877
+              else xv += v;                                             // src/infer.cpp:900-903
+            }
+            L.comb_x[rr] = xv;
+          }
+        }
+        continue;
       }
-      continue;
-    }
-    if (!has_rows) continue;
-    float acc[R], acc2[R];
-    dot(acc, acc2);
-    unsigned long long mykey = 0;
-    if (sub == 0) {
+      if (!has_rows || sub != 0) continue;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         if (!valid[r]) continue;
         float* o = T.out + row[r];
-        if (GLU) {
-          const float hv = act_fn(acc[r], L.act) * acc2[r];  // src/infer.cpp:859-872
-          *o = hv;
-          if (T.bmax_out) {
-            const unsigned long long key = bmax_key(hv, row[r] & 255);
-            if (key > mykey) mykey = key;
-          }
-        } else if (T.epilogue == EPI_ADD) {
-          *o += acc[r];  // residual add, src/infer.cpp:832-834,928-930
-        } else {
-          *o = acc[r];
-        }
+        if (GLU) *o = act_fn(acc[r], L.act) * acc2[r];  // src/infer.cpp:859-872
+        else if (T.epilogue == EPI_ADD) *o += acc[r];   // residual add, src/infer.cpp:832-834,928-930
+        else *o = acc[r];
       }
     }
-    if (GLU && T.bmax_out) {
-      // the rows of one wave are consecutive and (RPW*R divides 256) share a 256-block: reduce the
-      // key over the wave, then ONE atomic per wave (contended L2 atomics serialise at ~0.2 us each)
-      u32 hi = (u32)(mykey >> 32), lo = (u32)mykey;
-      const u32 hmax = wave_max_bits(hi);
-      if (hi != hmax) lo = 0;
-      const u32 lmax = wave_max_bits(lo);
-      const int blk = __builtin_amdgcn_readfirstlane((row0_of(g)) >> 8);
-      if (lane == 0 && (hmax | lmax)) atomicMax(T.bmax_out + blk, ((unsigned long long)hmax << 32) | lmax);
-    }
   }
+  if (tl && tid == 0) tl[3] = wall_clock64();
 }
 
 // ------------------------------------------------------------------------------------
@@ -829,44 +839,45 @@ static int ilog2(int v) {
   return l;
 }
 
-template <int QT, int R, int U>
+template <int QT, int R, int U, int NW>
 static void launch_one(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& h) {
-  dim3 grid(h.grid), block(256);
+  dim3 grid(h.grid), block(NW * 64);
   if (h.glu) {
-    auto k = gemv_kernel<QT, R, U, true>;
+    auto k = gemv_kernel<QT, R, U, true, NW>;
     if (h.lds_bytes > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds_bytes);
     hipLaunchKernelGGL(k, grid, block, h.lds_bytes, st, dev);
   } else {
-    auto k = gemv_kernel<QT, R, U, false>;
+    auto k = gemv_kernel<QT, R, U, false, NW>;
     if (h.lds_bytes > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds_bytes);
     hipLaunchKernelGGL(k, grid, block, h.lds_bytes, st, dev);
   }
 }
-template <int QT>
+template <int QT, int NW>
 static int launch_q(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& h) {
   // (R, U) variants: R rows x U column steps = the 16-byte loads a lane keeps in flight
   switch (h.R * 16 + h.U) {
-    case 1 * 16 + 8: launch_one<QT, 1, 8>(st, dev, h); break;
-    case 1 * 16 + 4: launch_one<QT, 1, 4>(st, dev, h); break;
-    case 1 * 16 + 2: launch_one<QT, 1, 2>(st, dev, h); break;
-    case 1 * 16 + 1: launch_one<QT, 1, 1>(st, dev, h); break;
-    case 2 * 16 + 4: launch_one<QT, 2, 4>(st, dev, h); break;
-    case 2 * 16 + 2: launch_one<QT, 2, 2>(st, dev, h); break;
-    case 2 * 16 + 1: launch_one<QT, 2, 1>(st, dev, h); break;
-    case 4 * 16 + 2: launch_one<QT, 4, 2>(st, dev, h); break;
-    case 4 * 16 + 1: launch_one<QT, 4, 1>(st, dev, h); break;
+    case 1 * 16 + 4: launch_one<QT, 1, 4, NW>(st, dev, h); break;
+    case 1 * 16 + 2: launch_one<QT, 1, 2, NW>(st, dev, h); break;
+    case 1 * 16 + 1: launch_one<QT, 1, 1, NW>(st, dev, h); break;
+    case 2 * 16 + 4: launch_one<QT, 2, 4, NW>(st, dev, h); break;
+    case 2 * 16 + 2: launch_one<QT, 2, 2, NW>(st, dev, h); break;
+    case 2 * 16 + 1: launch_one<QT, 2, 1, NW>(st, dev, h); break;
     default: DSK_FAIL(DSK_ERR_INVALID, "gemv: no kernel variant R=%d U=%d", h.R, h.U);
   }
   return DSK_OK;
 }
+template <int QT>
+static int launch_nw(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& h) {
+  return h.NW == 16 ? launch_q<QT, 16>(st, dev, h) : launch_q<QT, 4>(st, dev, h);
+}
 
 int gemv_launch(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& h) {
   switch (h.quant) {
-    case DSK_QUANT_F32: return launch_q<DSK_QUANT_F32>(st, dev, h);
-    case DSK_QUANT_F16: return launch_q<DSK_QUANT_F16>(st, dev, h);
-    case DSK_QUANT_F8E5M2: return launch_q<DSK_QUANT_F8E5M2>(st, dev, h);
-    case DSK_QUANT_Q2_K: return launch_q<DSK_QUANT_Q2_K>(st, dev, h);
-    case DSK_QUANT_Q3_K: return launch_q<DSK_QUANT_Q3_K>(st, dev, h);
+    case DSK_QUANT_F32: return launch_nw<DSK_QUANT_F32>(st, dev, h);
+    case DSK_QUANT_F16: return launch_nw<DSK_QUANT_F16>(st, dev, h);
+    case DSK_QUANT_F8E5M2: return launch_nw<DSK_QUANT_F8E5M2>(st, dev, h);
+    case DSK_QUANT_Q2_K: return launch_nw<DSK_QUANT_Q2_K>(st, dev, h);
+    case DSK_QUANT_Q3_K: return launch_nw<DSK_QUANT_Q3_K>(st, dev, h);
   }
   DSK_FAIL(DSK_ERR_INVALID, "gemv: bad quant %d", h.quant);
 }
@@ -926,11 +937,20 @@ int gemv_plan(GemvLaunch& h, int target_wgs) {
   h.R = h.comb_x ? 2 : 1;
   h.U = its >= 4 ? 4 : (its >= 2 ? 2 : 1);
   if (h.comb_x && h.U > 2) h.U = 2;
-  if (total_work >= 256e6 && target_wgs < 2048) target_wgs = 2048;
   (void)rows_eff;
   if (h.force_R > 0) h.R = h.force_R;
   if (h.force_U > 0) h.U = h.force_U;
-  const int RG = 4 * (64 / lpr) * h.R;
+  const int RPW = 64 / lpr;
+  // Workgroup size.  The per-workgroup prologue (staging + quantising the activation vector) is serial
+  // work in front of every launch: ~4 us for rmsnorm + Q8_K of 7168 values on 4 waves.  Launches with
+  // enough rows to give each of the 256 CUs a full 16-wave row group run 16-wave workgroups, one per CU:
+  // a quarter of the blocks per wave and a quarter of the redundant prologues.
+  h.NW = 4;
+  if (!h.comb_x && h.bd_heads <= 0 && total_rows >= 192L * 16 * RPW * h.R) h.NW = 16;
+  if (h.force_NW == 4 || h.force_NW == 16) h.NW = h.force_NW;
+  if (h.NW == 16 && h.glu && h.quant == DSK_QUANT_Q3_K && h.U > 2 && h.force_U <= 0) h.U = 2;  // 128 VGPRs per lane at 16 waves
+  const int RG = h.NW * RPW * h.R;
+  h.part_unit = h.comb_x ? RG : 1;
   if (h.bd_heads > 0) {
     const int n_groups = (h.t[0].rows + RG - 1) / RG;
     int per_head = target_wgs / h.bd_heads;
@@ -940,20 +960,44 @@ int gemv_plan(GemvLaunch& h, int target_wgs) {
     h.grid = per_head * h.bd_heads;
     h.t[0].wg_begin = 0;
     h.t[0].wg_end = h.grid;
+    h.t[0].vrow_begin = 0;
+    h.t[0].vrow_end = h.t[0].rows;
+    h.n_groups = 1; h.grp_wg_end[0] = h.grid; h.grp_t0[0] = 0; h.grp_t0[1] = 1;
     return DSK_OK;
   }
+  // activation groups: consecutive tasks that read the same vector (the fused combine keeps one task per
+  // group: its arrival counters are per task)
+  const int W = h.NW == 16 ? 256 : target_wgs;
   int wg = 0;
-  for (int i = 0; i < h.n_tasks; ++i) {
-    GemvTask& T = h.t[i];
-    const int n_groups = (T.rows + RG - 1) / RG;
-    int share = (int)(target_wgs * ((double)T.rows * T.n * (h.glu ? 2 : 1) / total_work) + 0.5);
+  h.n_groups = 0;
+  for (int i = 0; i < h.n_tasks;) {
+    int j = i + 1;
+    while (!h.comb_x && j < h.n_tasks && h.t[j].act_mode == h.t[i].act_mode && h.t[j].a_f32 == h.t[i].a_f32 &&
+           h.t[j].a_qs == h.t[i].a_qs && h.t[j].norm_w == h.t[i].norm_w && h.t[j].n == h.t[i].n)
+      ++j;
+    long rows_g = 0;
+    double work_g = 0;
+    for (int k = i; k < j; ++k) {
+      h.t[k].vrow_begin = (int)rows_g;
+      rows_g += h.t[k].rows;
+      h.t[k].vrow_end = (int)rows_g;
+      work_g += (double)h.t[k].rows * h.t[k].n * (h.glu ? 2 : 1);
+    }
+    int share = (int)(W * (work_g / total_work) + 0.5);
+    const long units = (rows_g + h.part_unit - 1) / h.part_unit;
+    // no more workgroups than half-filled row groups (combine: than whole groups, evenly dealt)
+    long cap = h.comb_x ? units : (2 * rows_g + RG - 1) / RG;
+    if (share > cap) share = (int)cap;
     if (share < 1) share = 1;
-    if (share > n_groups) share = n_groups;
-    share = (n_groups + (n_groups + share - 1) / share - 1) / ((n_groups + share - 1) / share);  // equal groups per workgroup
-    T.wg_begin = wg;
+    if (h.comb_x) share = (int)((units + (units + share - 1) / share - 1) / ((units + share - 1) / share));
+    for (int k = i; k < j; ++k) { h.t[k].wg_begin = wg; h.t[k].wg_end = wg + share; }
     wg += share;
-    T.wg_end = wg;
+    h.grp_t0[h.n_groups] = i;
+    h.grp_wg_end[h.n_groups] = wg;
+    ++h.n_groups;
+    i = j;
   }
+  h.grp_t0[h.n_groups] = h.n_tasks;
   h.grid = wg;
   return DSK_OK;
 }

@@ -335,6 +335,7 @@ extern "C" int dsk_bench_gemv(dsk_ctx* ctx, int quant, int rows, int n, int n_ta
     memset(&h, 0, sizeof h);
     h.quant = quant; h.mode = GEMV_MODE_TASKS; h.glu = kind == 1; h.act = DSK_ACT_SILU;
     h.b0 = h.b1 = 128; h.force_lpr = force_lpr; h.force_R = force_R; h.force_U = force_U;
+    if (getenv("DSK_FORCE_NW")) h.force_NW = atoi(getenv("DSK_FORCE_NW"));  // tuning knob of tools/kbench.py
     for (int i = 0; i < n_tasks; ++i) {
       GemvTask& T = h.t[h.n_tasks++];
       const DTensor& t = W[(size_t)c * mats + i * (kind == 1 ? 2 : 1)].t;
@@ -369,6 +370,34 @@ extern "C" int dsk_bench_gemv(dsk_ctx* ctx, int quant, int rows, int n, int n_ta
   hipEventDestroy(e1);
   *us_per_launch = (double)ms * 1e3 / iters;
   *bytes_per_launch = wbytes;
+  if (getenv("DSK_TIMELINE")) {  // one more launch with per-workgroup wall-clock stamps, summarised on stderr
+    DevBuf tlb;
+    const int grid = H[0].grid;
+    DSK_TRY(tlb.alloc((size_t)grid * 64));
+    HIP_TRY(hipMemsetAsync(tlb.p, 0, (size_t)grid * 64, st));
+    H[0].timeline = tlb.as<unsigned long long>();
+    HIP_TRY(hipMemcpyAsync(plans.p, H.data(), sizeof(GemvLaunch), hipMemcpyHostToDevice, st));
+    DSK_TRY(gemv_launch(st, plans.as<GemvLaunch>() + 1, H[1]));  // a neighbour first, as in a stream of launches
+    DSK_TRY(gemv_launch(st, plans.as<GemvLaunch>(), H[0]));
+    std::vector<unsigned long long> tl((size_t)grid * 8);
+    HIP_TRY(hipMemcpyAsync(tl.data(), tlb.p, (size_t)grid * 64, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    unsigned long long t00 = ~0ull;
+    for (int i = 0; i < grid; ++i) if (tl[i * 8] && tl[i * 8] < t00) t00 = tl[i * 8];
+    double mx[8] = {0}, av[8] = {0}, mn[8] = {1e30, 1e30, 1e30, 1e30, 1e30, 1e30, 1e30, 1e30};
+    int cnt = 0;
+    for (int i = 0; i < grid; ++i) {
+      if (!tl[i * 8 + 3]) continue;
+      ++cnt;
+      for (int k = 0; k < 8; ++k) {
+        const double v = tl[i * 8 + k] ? (double)(tl[i * 8 + k] - t00) * 0.01 : 0;  // us
+        mx[k] = v > mx[k] ? v : mx[k]; mn[k] = v < mn[k] ? v : mn[k]; av[k] += v;
+      }
+    }
+    fprintf(stderr, "timeline grid=%d (NW=%d R=%d U=%d lpr=%d) us since first entry [min avg max]: entry %.2f %.2f %.2f | staged %.2f %.2f %.2f | first group %.2f %.2f %.2f | exit %.2f %.2f %.2f\n",
+            grid, H[0].NW, H[0].R, H[0].U, 1 << H[0].lpr_log2, mn[0], av[0] / cnt, mx[0], mn[1], av[1] / cnt, mx[1], mn[2], av[2] / cnt, mx[2], mn[3], av[3] / cnt, mx[3]);
+    fprintf(stderr, "   prologue avg: descriptor read %.2f | x loaded + sumsq %.2f | barrier + scale %.2f | quantised %.2f | all waves %.2f\n", av[6] / cnt, av[4] / cnt, av[5] / cnt, av[7] / cnt, av[1] / cnt);
+  }
   return finish(ctx);
 }
 
