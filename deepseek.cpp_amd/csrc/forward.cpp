@@ -26,10 +26,16 @@ static int cdiv(int a, int b) { return (a + b - 1) / b; }
 struct Prof {
   dsk_model* m;
   int idx = -1;
+  bool skip = false;
   hipEvent_t e0 = nullptr, e1 = nullptr;
 };
 static int prof_begin(dsk_model* m, const char* name, double bytes, Prof* p) {
   p->m = m;
+  if (m->class_filter) {  // dsk_time_kernel_class: only the launches of one class are enqueued
+    p->skip = strcmp(name, m->class_filter) != 0;
+    if (!p->skip) { m->class_launches++; m->class_bytes += bytes; }
+    return DSK_OK;
+  }
   if (!m->profiling) return DSK_OK;
   auto it = m->kindex.find(name);
   if (it == m->kindex.end()) {
@@ -49,7 +55,7 @@ static int prof_begin(dsk_model* m, const char* name, double bytes, Prof* p) {
   return DSK_OK;
 }
 static int prof_end(Prof* p) {
-  if (!p->m->profiling) return DSK_OK;
+  if (!p->m->profiling || p->m->class_filter) return DSK_OK;
   HIP_TRY(hipEventRecord(p->e1, p->m->ctx->stream));
   p->m->ktimes[p->idx].ev.push_back({p->e0, p->e1});
   return DSK_OK;
@@ -58,7 +64,7 @@ static int prof_end(Prof* p) {
   do {                                                  \
     Prof _p;                                            \
     DSK_TRY(prof_begin(m, name, (double)(bytes), &_p)); \
-    DSK_TRY(call);                                      \
+    if (!_p.skip) DSK_TRY(call);                        \
     DSK_TRY(prof_end(&_p));                             \
   } while (0)
 
@@ -422,7 +428,7 @@ static int ffn(dsk_model* m, int l) {
 static int enqueue_forward(dsk_model* m, int mode, int max_kv) {
   const dsk_config& c = m->c;
   hipStream_t st = m->ctx->stream;
-  HIP_TRY(hipMemcpyAsync(m->sp_dev, m->sp_host, sizeof(StepParams), hipMemcpyHostToDevice, st));
+  if (!m->class_filter) HIP_TRY(hipMemcpyAsync(m->sp_dev, m->sp_host, sizeof(StepParams), hipMemcpyHostToDevice, st));
   PROFILED("embed", (double)mat_bytes(c.weight_quant, 1, c.dim), launch_embed(st, m->g[DSK_ROLE_EMBED], m->sp_dev, -1, std::max(1, c.block_size[0]),
                                                                               std::max(1, c.block_size[1]), m->x));
   for (int l = 0; l < c.n_layers; ++l) {
@@ -433,7 +439,7 @@ static int enqueue_forward(dsk_model* m, int mode, int max_kv) {
   }
   if (mode == DSK_MODE_HYDRATE_KV_CACHE) return DSK_OK;  // src/infer.cpp:1284-1287
   DSK_TRY(run_plan(m, "gemv_lm_head", m->lp_head));
-  HIP_TRY(hipMemcpyAsync(m->logits_host, m->logits, (size_t)c.vocab_size * 4, hipMemcpyDeviceToHost, st));
+  if (!m->class_filter) HIP_TRY(hipMemcpyAsync(m->logits_host, m->logits, (size_t)c.vocab_size * 4, hipMemcpyDeviceToHost, st));
   return DSK_OK;
 }
 
@@ -540,5 +546,44 @@ extern "C" int dsk_profile_forward(dsk_model* m, int token, int pos, dsk_kernel_
     }
   }
   *n_classes = n;
+  return DSK_OK;
+}
+
+// Duration of ONE kernel class inside the model: the class's launches of a whole token (every layer's own
+// weights, so the stream of launches reads fresh HBM exactly as in a decode step) are enqueued back to
+// back `reps` times between two HIP events on the engine stream.  Unlike dsk_profile_forward there is no
+// event between launches, so the figure is what rocprofv3 --kernel-trace reports plus the ~1.5 us
+// same-stream kernel boundary.  Leaves the activations / KV slot of `pos` in an undefined state.
+extern "C" int dsk_time_kernel_class(dsk_model* m, const char* name, int pos, int reps, double* us_per_launch,
+                                     double* bytes_per_launch, int* launches_per_token) {
+  DSK_TRY(check_forward_args(m, 0, pos, DSK_MODE_OUTPUT_LOGITS, m ? m->logits_host : nullptr));
+  if (!name || reps < 1 || !us_per_launch || !bytes_per_launch || !launches_per_token) DSK_FAIL(DSK_ERR_INVALID, "time_kernel_class: bad argument");
+  HIP_TRY(hipSetDevice(m->ctx->device));
+  hipStream_t st = m->ctx->stream;
+  DSK_TRY(fill_step_params(m, 0, pos));
+  HIP_TRY(hipMemcpyAsync(m->sp_dev, m->sp_host, sizeof(StepParams), hipMemcpyHostToDevice, st));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  m->class_filter = name;
+  m->class_launches = 0;
+  m->class_bytes = 0;
+  int r = enqueue_forward(m, DSK_MODE_OUTPUT_LOGITS, m->c.max_seq_len);  // warm-up pass (also counts the launches)
+  const int per_token = m->class_launches;
+  const double bytes = m->class_bytes;
+  if (r == DSK_OK) r = hipEventRecord(e0, st) == hipSuccess ? DSK_OK : DSK_ERR_HIP;
+  for (int i = 0; i < reps && r == DSK_OK; ++i) r = enqueue_forward(m, DSK_MODE_OUTPUT_LOGITS, m->c.max_seq_len);
+  m->class_filter = nullptr;
+  if (r == DSK_OK) r = hipEventRecord(e1, st) == hipSuccess ? DSK_OK : DSK_ERR_HIP;
+  if (r == DSK_OK) r = hipEventSynchronize(e1) == hipSuccess ? DSK_OK : DSK_ERR_HIP;
+  float ms = 0.f;
+  if (r == DSK_OK) hipEventElapsedTime(&ms, e0, e1);
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  if (r != DSK_OK) { hipStreamSynchronize(st); if (r == DSK_ERR_HIP) dsk_set_error(r, "time_kernel_class: HIP event failure"); return r; }
+  if (per_token == 0) DSK_FAIL(DSK_ERR_INVALID, "time_kernel_class: no launch of class '%s' in a token", name);
+  *us_per_launch = (double)ms * 1e3 / ((double)reps * per_token);
+  *bytes_per_launch = bytes / per_token;
+  *launches_per_token = per_token;
   return DSK_OK;
 }

@@ -119,6 +119,7 @@ def lib():
         L.dsk_attn_mla.argtypes = [C.c_void_p, c_f, c_f, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, c_f]
         L.dsk_measure_read_bw.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
+        L.dsk_time_kernel_class.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.dsk_bench_router.argtypes = [C.c_void_p] + [C.c_int] * 5 + [C.POINTER(C.c_double)]
         L.dsk_bench_gemv.argtypes = [C.c_void_p] + [C.c_int] * 11 + [C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _lib = L
@@ -296,6 +297,12 @@ class Model:
         check(lib().dsk_profile_forward(self.h, token, pos, arr, 64, C.byref(n)))
         return [dict(name=arr[i].name.decode(), launches=arr[i].launches, total_ms=arr[i].total_ms,
                      algo_bytes=arr[i].algo_bytes) for i in range(n.value)]
+
+    def time_kernel_class(self, name: str, pos: int, reps: int = 8):
+        """-> (us per launch, algorithmic bytes per launch, launches per token)"""
+        us, nb, n = C.c_double(), C.c_double(), C.c_int()
+        check(lib().dsk_time_kernel_class(self.h, name.encode(), pos, reps, C.byref(us), C.byref(nb), C.byref(n)))
+        return us.value, nb.value, n.value
 
     def active_bytes(self, pos: int) -> float:
         return lib().dsk_model_active_bytes(self.h, pos)

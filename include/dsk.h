@@ -235,6 +235,13 @@ int dsk_attn_mla(dsk_ctx* ctx, const float* q_c, const float* q_rope, const uint
  * (SURVEY 8d "measured roofline" denominator).  Best of `iters`. */
 int dsk_measure_read_bw(dsk_ctx* ctx, size_t bytes, int iters, double* gbps_out);
 
+/* Duration of one kernel class (a name reported by dsk_profile_forward, e.g. "gemv_experts_w13") inside
+   the model: its launches of a whole token are enqueued back to back `reps` times between two HIP events
+   on the engine stream -- no events between launches, so the figure matches rocprofv3 --kernel-trace plus
+   the same-stream kernel boundary.  The activations / KV slot of `pos` are left undefined. */
+int dsk_time_kernel_class(dsk_model* m, const char* name, int pos, int reps, double* us_per_launch,
+                          double* bytes_per_launch, int* launches_per_token);
+
 /* Diagnostics: time the GEMV kernel on device-resident synthetic weights (rotated through > 512 MB
  * so that the Infinity Cache cannot serve them).  kind: 0 plain, 1 GLU pair, 2 MoE accumulate over
  * n_tasks slots; act_mode: 0 ready Q8_K, 1 f32 (quantised in the prologue), 2 f32 + RMSNorm.
