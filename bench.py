@@ -83,62 +83,7 @@ def cpu_baseline(cfg_full, seconds: float):
         c.n_routed_experts = 32
         c.n_group = min(c.n_group, 8)
     c.max_seq_len = 1024  # >= the tokens the thread sweep decodes (5 settings x <= 64)
-    rng = np.random.default_rng(0)
-
-    def rand_tensor(shape):  # valid random blocks, like dsk_model_synthesize
-        rows = int(np.prod(shape[:-1]))
-        n = shape[-1]
-        if c.quant == "q2_k":
-            b = rng.integers(0, 256, (rows * (n // 256), 84), dtype=np.uint8)
-            d = (rng.uniform(0.5, 1.5, rows * (n // 256)) / np.sqrt(n) / 13.9).astype(np.float16)
-            b[:, 80:82] = d.view(np.uint8).reshape(-1, 2)
-            b[:, 82:84] = (1.5 * d.astype(np.float32)).astype(np.float16).view(np.uint8).reshape(-1, 2)
-            return synth.Tens(b.reshape(*shape[:-1], -1), tuple(shape), synth.QUANT_IDS["q2_k"])
-        w = (rng.standard_normal(shape, dtype=np.float32) / np.sqrt(n)).astype(np.float32)
-        return synth._encode(w, c.quant, c.block_size)
-
-    T = {}
-    F32 = synth.QUANT_IDS["fp32"]
-    H, hd = c.n_heads, c.head_dim
-    T["model.embed.weight"] = rand_tensor((c.vocab_size, c.dim))
-    T["model.output.weight"] = rand_tensor((c.vocab_size, c.dim))
-    T["model.norm.weight"] = synth.Tens(np.ones(c.dim, np.float32), (c.dim,), F32)
-    for l in range(c.n_layers):
-        p = f"model.layers.{l}."
-        for nm, n in (("attn.norm", c.dim), ("mlp.norm", c.dim), ("attn.kv_a_norm", c.kv_lora_rank)):
-            T[p + nm + ".weight"] = synth.Tens(np.ones(n, np.float32), (n,), F32)
-        if c.q_lora_rank > 0:
-            T[p + "attn.q_a_norm.weight"] = synth.Tens(np.ones(c.q_lora_rank, np.float32), (c.q_lora_rank,), F32)
-            T[p + "attn.wq_a.weight"] = rand_tensor((c.q_lora_rank, c.dim))
-        T[p + "attn.wkv_a.weight"] = rand_tensor((c.kv_lora_rank + c.qk_rope_head_dim, c.dim))
-        T[p + "attn.wo.weight"] = rand_tensor((c.dim, H * c.v_head_dim))
-        if c.use_mla:
-            T[p + "attn.wc.weight"] = rand_tensor((H * c.kv_lora_rank, c.q_lora_rank))
-            T[p + "attn.wq_rope_b.weight"] = rand_tensor((H * c.qk_rope_head_dim, c.q_lora_rank))
-            T[p + "attn.wv_b.weight"] = rand_tensor((H * c.v_head_dim, c.kv_lora_rank))
-        else:
-            if c.q_lora_rank > 0:
-                T[p + "attn.wq_b.weight"] = rand_tensor((H * hd, c.q_lora_rank))
-            else:
-                T[p + "attn.wq.weight"] = rand_tensor((H * hd, c.dim))
-            T[p + "attn.wkv_b.weight"] = rand_tensor((H * (c.qk_nope_head_dim + c.v_head_dim), c.kv_lora_rank))
-        if l >= c.first_k_dense_replace:
-            E, mi = c.n_routed_experts, c.moe_intermediate_size
-            T[p + "mlp.w1.weight"] = rand_tensor((E, mi, c.dim))
-            T[p + "mlp.w2.weight"] = rand_tensor((E, c.dim, mi))
-            T[p + "mlp.w3.weight"] = rand_tensor((E, mi, c.dim))
-            if c.n_shared_experts:
-                T[p + "shared_mlp.w1.weight"] = rand_tensor((c.n_shared_experts * mi, c.dim))
-                T[p + "shared_mlp.w2.weight"] = rand_tensor((c.dim, c.n_shared_experts * mi))
-                T[p + "shared_mlp.w3.weight"] = rand_tensor((c.n_shared_experts * mi, c.dim))
-            g = (rng.standard_normal((E, c.dim), dtype=np.float32) / np.sqrt(c.dim)).astype(np.float32)
-            T[p + "moegate.weight"] = synth.Tens(g, g.shape, F32)
-            if c.has_moegate_bias:
-                T[p + "moegate.bias"] = synth.Tens(np.zeros(E, np.float32), (E,), F32)
-        else:
-            T[p + "mlp.w1.weight"] = rand_tensor((c.hidden_dim, c.dim))
-            T[p + "mlp.w2.weight"] = rand_tensor((c.dim, c.hidden_dim))
-            T[p + "mlp.w3.weight"] = rand_tensor((c.hidden_dim, c.dim))
+    T = synth.random_block_model(c, seed=0)
     d = tempfile.mkdtemp(prefix="dsk_cpu_baseline_")
     try:
         synth.write_dseek(d, c, T)

@@ -265,14 +265,21 @@ static int tensor_slot(dsk_model* m, int role, int layer, DTensor** out) {
   return DSK_OK;
 }
 
+// Expert e of a routed stack lives on rank e / ceil(E / world): contiguous blocks, so that with the
+// reference's group-limited routing (<= topk_group survivors per group of E / n_group experts) the
+// per-rank load is bounded.  Pure host arithmetic (callable without a GPU; tests/test_dist_cpu.py).
+extern "C" int dsk_expert_shard(int n_experts, int world, int rank, int* base, int* count) {
+  if (n_experts < 0 || world < 1 || rank < 0 || rank >= world || !base || !count) DSK_FAIL(DSK_ERR_INVALID, "expert_shard: bad argument");
+  const int per = cdiv(n_experts, world);
+  *base = std::min(n_experts, rank * per);
+  *count = std::max(0, std::min(per, n_experts - *base));
+  return DSK_OK;
+}
+
 static void shard_range(const dsk_model* m, int role, int e, int* base, int* local) {
   *base = 0;
   *local = e;
-  if (e > 0 && is_routed_role(role) && m->ctx->world > 1) {
-    const int per = cdiv(e, m->ctx->world);
-    *base = std::min(e, m->ctx->rank * per);
-    *local = std::max(0, std::min(per, e - *base));
-  }
+  if (e > 0 && is_routed_role(role) && m->ctx->world > 1) dsk_expert_shard(e, m->ctx->world, m->ctx->rank, base, local);
 }
 
 extern "C" int dsk_model_bind(dsk_model* m, int role, int layer, int quant, const int32_t shape[4], const void* host_ptr, size_t bytes) {

@@ -120,6 +120,7 @@ def lib():
                                    C.c_int, c_f]
         L.dsk_measure_read_bw.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
         L.dsk_time_kernel_class.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.dsk_expert_shard.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.dsk_bench_router.argtypes = [C.c_void_p] + [C.c_int] * 5 + [C.POINTER(C.c_double)]
         L.dsk_bench_gemv.argtypes = [C.c_void_p] + [C.c_int] * 11 + [C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _lib = L

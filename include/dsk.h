@@ -146,6 +146,9 @@ int dsk_abi_version(void);
  * by rank 0 with dsk_comm_unique_id() and broadcast by the launcher. */
 int dsk_comm_unique_id(void* uid128);
 int dsk_comm_init(dsk_ctx* ctx, const void* uid128, int rank, int world);
+/* Which experts of an E-expert routed stack rank `rank` of `world` owns: [*base, *base + *count).
+   Host arithmetic only (no GPU needed). */
+int dsk_expert_shard(int n_experts, int world, int rank, int* base, int* count);
 
 /* ---- model life-cycle (replaces Model::Model binding, src/model.cpp:756-872) */
 int dsk_model_create(dsk_ctx* ctx, const dsk_config* cfg, dsk_model** out);
