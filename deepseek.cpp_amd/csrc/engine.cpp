@@ -468,7 +468,8 @@ extern "C" int dsk_model_finalize(dsk_model* m) {
   DSK_TRY(alloc_f(m, &m->q_c, (size_t)H * std::max(1, c.kv_lora_rank)));
   DSK_TRY(alloc_f(m, &m->q_rope, (size_t)H * std::max(1, c.qk_rope_head_dim)));
   DSK_TRY(alloc_f(m, &m->vb_out, (size_t)H * c.v_head_dim));
-  m->router_ksplit = c.n_routed_experts > 0 ? std::max(1, std::min(8, 1024 / std::max(1, c.n_routed_experts))) : 1;
+  // column slices per router row: 8 (2 rows per 16-wave workgroup) unless the rows are short
+  m->router_ksplit = c.n_routed_experts > 0 ? 8 : 1;
   while (m->router_ksplit > 1 && c.dim / m->router_ksplit < 256) m->router_ksplit /= 2;
   DSK_TRY(alloc_f(m, &m->router_partial, (size_t)m->router_ksplit * std::max(1, c.n_routed_experts)));
   DSK_TRY(alloc_f(m, &m->gate_scores, (size_t)c.n_layers * std::max(1, c.n_routed_experts)));

@@ -323,24 +323,28 @@ int launch_embed(hipStream_t st, const DTensor& t, const StepParams* sp, int tok
 // ------------------------------------------------------------------------------------
 DEV void gate_body(int e, float v, const float* __restrict__ bias, int E, int K, int norm_topk_prob, float scaling, int scoring,
                    int topk_method, int n_group, int topk_group, int* __restrict__ active_experts,
-                   float* __restrict__ active_weights, float* __restrict__ scores_out, float* s, int* ci, int* sel, float* scratch) {
-  // s[256]: scores; cs (aliases scratch area passed as `s + 256`) / ci[256]: compacted candidates
+                   float* __restrict__ active_weights, float* __restrict__ scores_out, float* s, int* ci, int* sel, float* scratch,
+                   int nthreads = 256) {
+  // s[256]: scores; cs (aliases scratch area passed as `s + 256`) / ci[256]: compacted candidates.
+  // Called by every thread of the workgroup (barriers inside); threads >= 256 only take part in those.
   float* cs = s + 256;
   if (e >= E) v = -INFINITY;
   if (scoring == DSK_SCORE_SOFTMAX) {  // softmax, src/infer.cpp:472-487
-    const float mx = block_max(v, scratch, e, 256);
+    const float mx = block_max(v, scratch, e, nthreads);
     const float ex = e < E ? expf(v - mx) : 0.f;
-    const float sum = block_sum(ex, scratch, e, 256);
+    const float sum = block_sum(ex, scratch, e, nthreads);
     v = ex / sum;
   } else {
     v = 1.0f / (1.0f + expf(-v));  // sigmoid, src/infer.cpp:489-491
   }
   if (bias && e < E) v += bias[e];
   if (e >= E) v = -INFINITY;
-  s[e] = v;
+  if (e < 256) {
+    s[e] = v;
+    cs[e] = -INFINITY;
+    ci[e] = 0x7fffffff;
+  }
   if (e < E && scores_out) scores_out[e] = v;
-  cs[e] = -INFINITY;
-  ci[e] = 0x7fffffff;
   __syncthreads();
   // candidates, compacted: a wave64 VALU op takes 4 cycles, so the serial compare loops below are the
   // critical path of the whole launch -- they must run over the candidates only, not over all E
@@ -430,43 +434,70 @@ int launch_gate(hipStream_t st, const float* partial, int ksplit, const float* b
   return DSK_OK;
 }
 
-__global__ __launch_bounds__(256) void router_gate_kernel(RouterArgs a) {
+// sum over the 16 lanes of a DPP row (every lane gets the total; VALU speed, no ds_bpermute)
+DEV float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));  // row_mirror
+  return v;
+}
+
+// full-wave sum, fixed order: DPP inside the 16-lane rows, then the four rows
+DEV float wave_sum_dpp(float v) {
+  v = row16_sum(v);
+  const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return (a + b) + (c + d);
+}
+
+// 16-wave workgroups: RW rows x (16 / RW) column slices each, slices summed in LDS in slice order, so
+// one launch is E / RW workgroups = E / RW arrivals on the counter (256 arrivals on one address cost 2 us)
+template <int RW>
+__global__ __launch_bounds__(1024) void router_gate_kernel(RouterArgs a) {
+  constexpr int SL = 16 / RW;
   __shared__ __attribute__((aligned(16))) float s[512];
   __shared__ __attribute__((aligned(16))) int surv[256];
-  __shared__ float scratch[4];
+  __shared__ float scratch[16];
+  __shared__ float part[16];
   __shared__ int sel[256];
   __shared__ int is_last;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int row = blockIdx.x * 4 + (tid >> 6);
-  const int c = blockIdx.y, dim = a.dim, E = a.n_routed;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = wave % RW, sl = wave / RW;
+  const int row = blockIdx.x * RW + r;
+  const int dim = a.dim, E = a.n_routed;
   float scale = 1.0f;
   if (a.norm_w && !(a.dbg & 4)) {  // rmsnorm of the residual stream (src/infer.cpp:839, 601-611), once per workgroup
     float ss = 0.f;
-    for (int i0 = tid * 4; i0 < dim; i0 += 8 * 1024) {  // 8 loads in flight per lane
-      f32x4 v[8];
+    for (int i0 = tid * 4; i0 < dim; i0 += 4 * 4096) {
+      f32x4 v[4];
 #pragma unroll
-      for (int k = 0; k < 8; ++k)
-        if (i0 + k * 1024 < dim) v[k] = *reinterpret_cast<const f32x4*>(a.x + i0 + k * 1024);
+      for (int k = 0; k < 4; ++k)
+        if (i0 + k * 4096 < dim) v[k] = *reinterpret_cast<const f32x4*>(a.x + i0 + k * 4096);
 #pragma unroll
-      for (int k = 0; k < 8; ++k)
-        if (i0 + k * 1024 < dim) {
+      for (int k = 0; k < 4; ++k)
+        if (i0 + k * 4096 < dim) {
           ss = fmaf(v[k].x, v[k].x, ss);
           ss = fmaf(v[k].y, v[k].y, ss);
           ss = fmaf(v[k].z, v[k].z, ss);
           ss = fmaf(v[k].w, v[k].w, ss);
         }
     }
-    ss = wave_sum(ss);
-    if (lane == 0) scratch[tid >> 6] = ss;
+    ss = wave_sum_dpp(ss);
+    if (lane == 0) scratch[wave] = ss;
     __syncthreads();
-    const float total = (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+    float total = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i += 4) total += (scratch[i] + scratch[i + 1]) + (scratch[i + 2] + scratch[i + 3]);
     scale = 1.0f / sqrtf(total / (float)dim + a.eps);
     __syncthreads();
   }
+  float acc = 0.f;
   if (row < E && !(a.dbg & 2)) {
-    const int chunk = ((dim / 4 + a.ksplit - 1) / a.ksplit + 63) / 64 * 64 * 4;  // floats per K slice, multiple of 256
-    const int k0 = c * chunk, k1 = min(dim, k0 + chunk);
-    float acc = 0.f;
+    const int chunk = ((dim / 4 + SL - 1) / SL + 63) / 64 * 64 * 4;  // floats per column slice, multiple of 256
+    const int k0 = sl * chunk, k1 = min(dim, k0 + chunk);
     const float* wr = a.w + (size_t)row * dim;
     for (int i0 = k0 + lane * 4; i0 < k1; i0 += 8 * 256) {  // 8 weight loads in flight per lane
       f32x4 wv[8];
@@ -492,17 +523,23 @@ __global__ __launch_bounds__(256) void router_gate_kernel(RouterArgs a) {
         }
       }
     }
-    acc = wave_sum(acc);
-    // write-through (sc1) store: visible across XCDs once vmcnt drains, no L2 write-back fence needed
-    if (lane == 0) __hip_atomic_store(a.partial + (size_t)c * E + row, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    acc = wave_sum_dpp(acc);
   }
-  // ---- publish the partials; the last workgroup to arrive runs the gate ----
+  if (lane == 0) part[wave] = acc;
+  __syncthreads();
+  if (tid < RW && blockIdx.x * RW + tid < E) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < SL; ++k) v += part[k * RW + tid];  // slice order: deterministic
+    // write-through (sc1) store: visible across XCDs once vmcnt drains, no L2 write-back fence needed
+    __hip_atomic_store(a.partial + blockIdx.x * RW + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // ---- publish the scores; the last workgroup to arrive runs the gate ----
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    const unsigned total = gridDim.x * gridDim.y;
     const unsigned old = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = old == total - 1;
+    is_last = old == gridDim.x - 1;
     if (is_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
@@ -510,11 +547,9 @@ __global__ __launch_bounds__(256) void router_gate_kernel(RouterArgs a) {
   if (a.dbg & 1) { if (tid == 0) *a.counter = 0; return; }
   if (tid == 0) __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
   float v = 0.f;
-  if (tid < E)
-    for (int cc = 0; cc < a.ksplit; ++cc)
-      v += __hip_atomic_load(a.partial + (size_t)cc * E + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid < E) v = __hip_atomic_load(a.partial + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   gate_body(tid, v, a.bias, E, a.n_active, a.norm_topk_prob, a.scaling, a.scoring, a.topk_method, a.n_group, a.topk_group,
-            a.active_experts, a.active_weights, a.scores_out, s, surv, sel, scratch);
+            a.active_experts, a.active_weights, a.scores_out, s, surv, sel, scratch, 1024);
 }
 int launch_router_gate(hipStream_t st, const RouterArgs& a) {
   if (a.dim % 4) DSK_FAIL(DSK_ERR_INVALID, "router: dim %% 4 != 0");
@@ -522,7 +557,9 @@ int launch_router_gate(hipStream_t st, const RouterArgs& a) {
   if (a.n_active > a.n_routed) DSK_FAIL(DSK_ERR_INVALID, "moe_gate: n_active > n_routed");
   if (a.topk_method == DSK_TOPK_GROUP_LIMITED_GREEDY && (a.n_group <= 0 || a.n_routed % a.n_group || a.topk_group * a.n_group < a.n_active))
     DSK_FAIL(DSK_ERR_INVALID, "moe_gate: bad group config (E=%d, n_group=%d, topk_group=%d, k=%d)", a.n_routed, a.n_group, a.topk_group, a.n_active);
-  hipLaunchKernelGGL(router_gate_kernel, dim3((a.n_routed + 3) / 4, a.ksplit), dim3(256), 0, st, a);
+  // ksplit = column slices per row: 4 -> 4 rows per workgroup, 8 -> 2 rows per workgroup
+  if (a.ksplit >= 8) hipLaunchKernelGGL(router_gate_kernel<2>, dim3((a.n_routed + 1) / 2), dim3(1024), 0, st, a);
+  else hipLaunchKernelGGL(router_gate_kernel<4>, dim3((a.n_routed + 3) / 4), dim3(1024), 0, st, a);
   return DSK_OK;
 }
 
@@ -591,15 +628,6 @@ int launch_rope_kv_mha(hipStream_t st, const AttnMhaArgs& a, const StepParams* s
 // attn (per head), src/infer.cpp:728-762: scores = q.k / sqrt(head_dim), softmax, sum att*v.
 // One workgroup per head; scores live in LDS (kv_len floats).
 // ------------------------------------------------------------------------------------
-// sum over the 16 lanes of a DPP row (every lane gets the total; VALU speed, no ds_bpermute)
-DEV float row16_sum(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));  // row_mirror
-  return v;
-}
-
 // returns this thread's output element (valid for tid < v_dim).  part: 256 / (v_dim / 4) * v_dim floats.
 // Scores: 16 lanes per cached position (4 positions per wave step, 128-byte coalesced f16 reads);
 // values: 4 output dims per thread, v_dim / 4 threads per position.
