@@ -856,6 +856,7 @@ template <int QT, int NW>
 static int launch_q(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& h) {
   // (R, U) variants: R rows x U column steps = the 16-byte loads a lane keeps in flight
   switch (h.R * 16 + h.U) {
+    case 1 * 16 + 8: launch_one<QT, 1, 8, NW>(st, dev, h); break;
     case 1 * 16 + 4: launch_one<QT, 1, 4, NW>(st, dev, h); break;
     case 1 * 16 + 2: launch_one<QT, 1, 2, NW>(st, dev, h); break;
     case 1 * 16 + 1: launch_one<QT, 1, 1, NW>(st, dev, h); break;
@@ -935,8 +936,12 @@ int gemv_plan(GemvLaunch& h, int target_wgs) {
   }
   const int its = (min_items + lpr - 1) / lpr;
   h.R = h.comb_x ? 2 : 1;
-  h.U = its >= 4 ? 4 : (its >= 2 ? 2 : 1);
-  if (h.comb_x && h.U > 2) h.U = 2;
+  // one HBM round trip per row group when the row fits: U = column steps of a row, rounded up to a power
+  // of two (<= 8; the GLU pair holds two matrices per step: <= 4); longer rows take chunks of 4
+  h.U = 1;
+  while (h.U < its && h.U < (h.glu ? 4 : 8)) h.U *= 2;
+  if (its > h.U) h.U = 4;
+  if (h.R > 1 && h.U > 4) h.U = 4;
   (void)rows_eff;
   if (h.force_R > 0) h.R = h.force_R;
   if (h.force_U > 0) h.U = h.force_U;

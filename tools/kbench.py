@@ -40,10 +40,10 @@ def main():
             print("==", name)
             res = []
             for lpr in (0, 8, 16, 32, 64):
-                for R, U in ((1, 8), (2, 4), (4, 2), (1, 4), (2, 2), (4, 1), (1, 2), (2, 1), (1, 1)):
+                for R, U in ((1, 8), (2, 4), (1, 4), (2, 2), (1, 2), (2, 1), (1, 1)):
                     if kind == 1 and R > 2:
                         continue
-                    for wgs in (256, 512, 1024, 2048):
+                    for wgs in (512, 1024, 2048):
                         try:
                             us, nb = ctx.bench_gemv(Q2K, rows, n, nt, kind, act, lpr, R, U, wgs, 20)
                         except dsk.DskError:
