@@ -116,6 +116,8 @@ struct GemvLaunch {
   // per group) runs  x[row] += w_k * out_k[row]  in k order, then + shared (src/infer.cpp:874-877,900-903)
   float* comb_x;
   unsigned* comb_counter;
+  int comb_geometry;  // plan exactly like a fused-combine launch (the expert-sharded W2 launch: same
+                      // summation trees as on one GPU => bit-identical slot outputs)
   // debug (DSK_TIMELINE=1 with dsk_bench_gemv): 4 wall-clock stamps per workgroup (entry, staged, first
   // row group done, exit), 100 MHz s_memrealtime ticks
   unsigned long long* timeline;

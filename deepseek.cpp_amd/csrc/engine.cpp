@@ -83,6 +83,7 @@ extern "C" int dsk_comm_init(dsk_ctx* c, const void* uid128, int rank, int world
   c->rank = rank;
   c->world = world;
   if (world == 1) return DSK_OK;
+  if (!uid128) return DSK_OK;  // dry run of one shard: no communicator, the all-reduce is skipped
   HIP_TRY(hipSetDevice(c->device));
   ncclUniqueId id;
   memcpy(&id, uid128, 128);

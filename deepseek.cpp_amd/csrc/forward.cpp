@@ -269,6 +269,7 @@ int build_plans(dsk_model* m) {
         bytes += weight_bytes_2d(m, wq, c.dim, shared_n) + 4.0 * shared_n + 4.0 * c.dim;
       }
       if (m->ctx->world == 1) { h.comb_x = m->x; h.comb_counter = m->comb_counter; }
+      else h.comb_geometry = 1;
       h.algo_bytes = bytes;
       DSK_TRY(add_plan(m, h, &m->lp_w2[l]));
     }
@@ -412,8 +413,10 @@ static int ffn(dsk_model* m, int l) {
   DSK_TRY(run_plan(m, "gemv_experts_w2", m->lp_w2[l]));
   if (m->ctx->world > 1) {
     // every routed slot is non-zero on exactly one rank: a sum all-reduce is exact and order-independent
-    ncclResult_t rr = ncclAllReduce(m->eout, m->eout, (size_t)K * c.dim, ncclFloat, ncclSum, m->ctx->comm, st);
-    if (rr != ncclSuccess) DSK_FAIL(DSK_ERR_COMM, "ncclAllReduce: %s", ncclGetErrorString(rr));
+    if (m->ctx->comm) {  // (null only in a single-rank dry run of a shard, dsk_comm_init with uid = NULL)
+      ncclResult_t rr = ncclAllReduce(m->eout, m->eout, (size_t)K * c.dim, ncclFloat, ncclSum, m->ctx->comm, st);
+      if (rr != ncclSuccess) DSK_FAIL(DSK_ERR_COMM, "ncclAllReduce: %s", ncclGetErrorString(rr));
+    }
     NormJob j;  // combine in k order, then the shared expert (src/infer.cpp:874-877, 900-903)
     memset(&j, 0, sizeof j);
     j.x = m->x; j.n = c.dim; j.eps = c.norm_eps;
@@ -511,6 +514,14 @@ extern "C" int dsk_model_get_routing(dsk_model* m, int32_t* experts, float* weig
   for (int l = 0; l < m->c.n_layers; ++l)
     if (!m->L[l].is_moe)
       for (int k = 0; k < K; ++k) { experts[(size_t)l * K + k] = -1; weights[(size_t)l * K + k] = 0.f; }
+  return DSK_OK;
+}
+
+extern "C" int dsk_model_get_slot_outputs(dsk_model* m, float* out) {
+  if (!m || !m->finalized || !out) DSK_FAIL(DSK_ERR_INVALID, "get_slot_outputs: bad argument");
+  if (m->n_slots <= 0) DSK_FAIL(DSK_ERR_STATE, "get_slot_outputs: the model has no MoE layer");
+  HIP_TRY(hipSetDevice(m->ctx->device));
+  HIP_TRY(hipMemcpy(out, m->eout, (size_t)m->n_slots * m->c.dim * 4, hipMemcpyDeviceToHost));
   return DSK_OK;
 }
 

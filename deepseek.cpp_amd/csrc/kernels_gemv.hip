@@ -885,6 +885,7 @@ int gemv_launch(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& h) {
 
 // Decide lanes-per-row, rows-per-wave, grid and workgroup ranges.  `target_wgs` ~ a few per CU.
 int gemv_plan(GemvLaunch& h, int target_wgs) {
+  const bool cg = h.comb_x != nullptr || h.comb_geometry != 0;  // fused-combine geometry
   if (h.n_tasks < 1 || h.n_tasks > GEMV_MAX_TASKS) DSK_FAIL(DSK_ERR_INVALID, "gemv: %d tasks", h.n_tasks);
   const bool kq = h.quant == DSK_QUANT_Q2_K || h.quant == DSK_QUANT_Q3_K;
   const int epi = kq ? 64 : (h.quant == DSK_QUANT_F32 ? 4 : (h.quant == DSK_QUANT_F16 ? 8 : 16));
@@ -903,7 +904,7 @@ int gemv_plan(GemvLaunch& h, int target_wgs) {
     total_rows += T.rows;
     total_work += (double)T.rows * T.n * (h.glu ? 2 : 1);
     min_items = T.n / epi < min_items ? T.n / epi : min_items;
-    if (h.comb_x && T.rows != h.t[0].rows) DSK_FAIL(DSK_ERR_INVALID, "gemv combine: tasks must share the row count");
+    if (cg && T.rows != h.t[0].rows) DSK_FAIL(DSK_ERR_INVALID, "gemv combine: tasks must share the row count");
   }
   h.lds_bytes = lds_max;
   (void)lds_sum;
@@ -930,12 +931,12 @@ int gemv_plan(GemvLaunch& h, int target_wgs) {
   // launches alike, big launches (> 64 MB) want ~8 workgroups per CU.  The fused MoE combine pays one
   // arrival (barrier + atomic round trip) per row group, so it wants FEW, tall groups: 8 lanes per row,
   // 2 row sets => 64 rows per group (experts_w2: 16.7 us vs 46 us at 32 lanes per row).
-  if (h.comb_x && h.force_lpr <= 0) {
+  if (cg && h.force_lpr <= 0) {
     while (lpr > 8) lpr >>= 1;
     h.lpr_log2 = ilog2(lpr);
   }
   const int its = (min_items + lpr - 1) / lpr;
-  h.R = h.comb_x ? 2 : 1;
+  h.R = cg ? 2 : 1;
   // one HBM round trip per row group when the row fits: U = column steps of a row, rounded up to a power
   // of two (<= 8; the GLU pair holds two matrices per step: <= 4); longer rows take chunks of 4
   h.U = 1;
@@ -951,11 +952,11 @@ int gemv_plan(GemvLaunch& h, int target_wgs) {
   // enough rows to give each of the 256 CUs a full 16-wave row group run 16-wave workgroups, one per CU:
   // a quarter of the blocks per wave and a quarter of the redundant prologues.
   h.NW = 4;
-  if (!h.comb_x && h.bd_heads <= 0 && total_rows >= 192L * 16 * RPW * h.R) h.NW = 16;
+  if (!cg && h.bd_heads <= 0 && total_rows >= 192L * 16 * RPW * h.R) h.NW = 16;
   if (h.force_NW == 4 || h.force_NW == 16) h.NW = h.force_NW;
   if (h.NW == 16 && h.glu && h.quant == DSK_QUANT_Q3_K && h.U > 2 && h.force_U <= 0) h.U = 2;  // 128 VGPRs per lane at 16 waves
   const int RG = h.NW * RPW * h.R;
-  h.part_unit = h.comb_x ? RG : 1;
+  h.part_unit = cg ? RG : 1;
   if (h.bd_heads > 0) {
     const int n_groups = (h.t[0].rows + RG - 1) / RG;
     int per_head = target_wgs / h.bd_heads;
@@ -977,7 +978,7 @@ int gemv_plan(GemvLaunch& h, int target_wgs) {
   h.n_groups = 0;
   for (int i = 0; i < h.n_tasks;) {
     int j = i + 1;
-    while (!h.comb_x && j < h.n_tasks && h.t[j].act_mode == h.t[i].act_mode && h.t[j].a_f32 == h.t[i].a_f32 &&
+    while (!cg && j < h.n_tasks && h.t[j].act_mode == h.t[i].act_mode && h.t[j].a_f32 == h.t[i].a_f32 &&
            h.t[j].a_qs == h.t[i].a_qs && h.t[j].norm_w == h.t[i].norm_w && h.t[j].n == h.t[i].n)
       ++j;
     long rows_g = 0;
@@ -991,10 +992,10 @@ int gemv_plan(GemvLaunch& h, int target_wgs) {
     int share = (int)(W * (work_g / total_work) + 0.5);
     const long units = (rows_g + h.part_unit - 1) / h.part_unit;
     // no more workgroups than half-filled row groups (combine: than whole groups, evenly dealt)
-    long cap = h.comb_x ? units : (2 * rows_g + RG - 1) / RG;
+    long cap = cg ? units : (2 * rows_g + RG - 1) / RG;
     if (share > cap) share = (int)cap;
     if (share < 1) share = 1;
-    if (h.comb_x) share = (int)((units + (units + share - 1) / share - 1) / ((units + share - 1) / share));
+    if (cg) share = (int)((units + (units + share - 1) / share - 1) / ((units + share - 1) / share));
     for (int k = i; k < j; ++k) { h.t[k].wg_begin = wg; h.t[k].wg_end = wg + share; }
     wg += share;
     h.grp_t0[h.n_groups] = i;

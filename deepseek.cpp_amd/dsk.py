@@ -104,6 +104,7 @@ def lib():
         L.dsk_model_set_trace.argtypes = [C.c_void_p, C.c_int]
         L.dsk_model_get_trace_x.argtypes = [C.c_void_p, C.c_int, c_f]
         L.dsk_model_get_routing.argtypes = [C.c_void_p, c_i32, c_f]
+        L.dsk_model_get_slot_outputs.argtypes = [C.c_void_p, c_f]
         L.dsk_profile_forward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(KernelTime), C.c_int, c_i32]
         L.dsk_q8k_quantize.argtypes = [C.c_void_p, c_f, C.c_int, C.c_void_p, c_f, C.c_void_p]
         L.dsk_gemv.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, c_f, c_i32, C.c_int, C.c_int, c_f, c_f]
@@ -150,6 +151,10 @@ class Ctx:
         buf = C.create_string_buffer(128)
         check(lib().dsk_comm_unique_id(buf))
         return buf.raw
+
+    def comm_init_dry(self, rank: int, world: int):
+        """shard `rank` of `world` without a communicator (single-GPU validation of the sharded path)"""
+        check(lib().dsk_comm_init(self.h, None, rank, world))
 
     def comm_init(self, uid: bytes, rank: int, world: int):
         check(lib().dsk_comm_init(self.h, C.c_char_p(uid), rank, world))
@@ -291,6 +296,12 @@ class Model:
         w = np.zeros(self.cfg.n_layers * K, np.float32)
         check(lib().dsk_model_get_routing(self.h, e.ctypes.data_as(c_i32), _f(w)))
         return e.reshape(self.cfg.n_layers, K), w.reshape(self.cfg.n_layers, K)
+
+    def slot_outputs(self):
+        n = self.cfg.n_active_routed + (1 if self.cfg.n_shared_experts > 0 else 0)
+        out = np.zeros((n, self.cfg.dim), np.float32)
+        check(lib().dsk_model_get_slot_outputs(self.h, _f(out)))
+        return out
 
     def profile_forward(self, token: int, pos: int):
         arr = (KernelTime * 64)()

@@ -146,6 +146,8 @@ int dsk_abi_version(void);
  * by rank 0 with dsk_comm_unique_id() and broadcast by the launcher. */
 int dsk_comm_unique_id(void* uid128);
 int dsk_comm_init(dsk_ctx* ctx, const void* uid128, int rank, int world);
+/* uid128 == NULL with world > 1: single-process DRY RUN of shard `rank`: the model binds / computes only the
+   experts this rank owns and skips the all-reduce (used to validate the sharded path on one GPU). */
 /* Which experts of an E-expert routed stack rank `rank` of `world` owns: [*base, *base + *count).
    Host arithmetic only (no GPU needed). */
 int dsk_expert_shard(int n_experts, int world, int rank, int* base, int* count);
@@ -185,6 +187,9 @@ double dsk_model_device_bytes(const dsk_model* m);
 int dsk_model_get_routing(dsk_model* m, int32_t* experts, float* weights);
 /* Copy the residual stream x (dim floats) as it was after `layer` in the last forward;
  * requires dsk_model_set_trace(m, 1) before the forward (disables the graph). */
+/* The per-slot expert outputs W2_k (act(W1_k x) * W3_k x) of the LAST MoE layer of the last forward:
+   (n_active_routed [+1 if shared experts]) x dim floats, slot order = k order, shared expert last. */
+int dsk_model_get_slot_outputs(dsk_model* m, float* out);
 int dsk_model_set_trace(dsk_model* m, int enable);
 int dsk_model_get_trace_x(dsk_model* m, int layer, float* x_out);
 

@@ -205,3 +205,46 @@ def test_synthesized_weights_are_valid_and_deterministic(ctx):
         assert moe.min() >= 0 and moe.max() < c.n_routed_experts and all(len(set(r)) == len(r) for r in moe)
         A.close()
         B.close()
+
+
+@pytest.mark.parametrize("quant", ["q2_k", "f8e5m2"])
+def test_expert_sharded_path_dry_run_on_one_gpu(quant):
+    """The N > 1 compute path without N GPUs: two models on this GPU own shard 0 / 1 of 2 (dsk_comm_init
+    with uid = NULL: no communicator, the all-reduce is skipped).  For the last MoE layer every routed
+    slot must be computed by exactly its owner, bit-identical to the unsharded model, and be exactly 0
+    elsewhere (so that the sum all-reduce is exact); the shared expert is replicated; the stand-alone
+    combine kernel of the sharded path must add the local slots in k order."""
+    import dsk
+    c = synth.preset("tiny_v3", quant, False, n_layers=2, first_k_dense_replace=1)
+    T = synth.synth_model(c, seed=9)
+    K, E = c.n_active_routed, c.n_routed_experts
+    per = -(-E // 2)
+    ctxs = [dsk.Ctx(0) for _ in range(3)]
+    ctxs[1].comm_init_dry(0, 2)
+    ctxs[2].comm_init_dry(1, 2)
+    Ms = [dsk.Model(x, c, T) for x in ctxs]
+    for M in Ms:
+        M.set_trace(True)
+    for tok in (5, 77, 300):
+        for M in Ms:
+            M.forward(tok, 0)
+        (eC, wC), (eA, _), (eB, _) = (M.routing() for M in Ms)
+        assert np.array_equal(eC, eA) and np.array_equal(eC, eB)  # the router is replicated
+        oC, oA, oB = (M.slot_outputs() for M in Ms)
+        owners = eC[1] // per
+        assert set(owners) <= {0, 1}
+        for k in range(K):
+            own, other = (oA, oB) if owners[k] == 0 else (oB, oA)
+            assert np.array_equal(own[k], oC[k]), (tok, k)
+            assert not np.any(other[k]), (tok, k)
+        if c.n_shared_experts > 0:
+            assert np.array_equal(oA[K], oC[K]) and np.array_equal(oB[K], oC[K])
+        # combine kernel: x_C - x_shard = sum over the slots the shard does NOT own of w_k * out_k
+        xC = Ms[0].trace_x(1)
+        for M, rank in ((Ms[1], 0), (Ms[2], 1)):
+            missing = sum((wC[1][k] * oC[k] for k in range(K) if owners[k] != rank), np.zeros(c.dim, np.float32))
+            assert rel_inf(xC - M.trace_x(1), missing) < 1e-4 or np.abs(missing).max() == 0, (tok, rank)
+    for M in Ms:
+        M.close()
+    for x in ctxs:
+        x.close()
