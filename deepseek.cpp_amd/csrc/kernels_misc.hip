@@ -567,17 +567,35 @@ int launch_router_gate(hipStream_t st, const RouterArgs& a) {
 // MHA path: RoPE on q, assemble k/v, f16 cache write, attention-sink rotation.
 // BlockMHA::_attention_impl, src/infer.cpp:956-1020.  One workgroup per head.
 // ------------------------------------------------------------------------------------
-DEV void rope_kv_mha_body(const AttnMhaArgs& a, const StepParams* __restrict__ sp, int h, int tid) {
+// q_lds != null: the rotated query goes to LDS only (the fused kernel is its single consumer)
+template <int NT>
+DEV void rope_kv_mha_body(const AttnMhaArgs& a, const StepParams* __restrict__ sp, int h, int tid, float* q_lds = nullptr) {
   const int hd = a.head_dim, nope = a.nope, rope = a.rope, vd = a.v_dim;
   const int kv_pos = sp->kv_pos, kv_sink = sp->kv_sink;
-  // q rope, in place
-  rope_pairs(a.q + (size_t)h * hd + nope, rope, sp->rope_cs, a.is_v3, tid, 256);
+  if (q_lds) {
+    const float* qg = a.q + (size_t)h * hd;
+    if (tid < nope) q_lds[tid] = qg[tid];
+    if (tid < rope / 2) {  // rope (V2: de-interleaving) src/infer.cpp:648-668; rope_v3 :670-685
+      const float v0 = qg[nope + 2 * tid], v1 = qg[nope + 2 * tid + 1];
+      const float c = sp->rope_cs[2 * tid], s = sp->rope_cs[2 * tid + 1];
+      const float re = v0 * c - v1 * s, im = v0 * s + v1 * c;
+      if (a.is_v3) {
+        q_lds[nope + 2 * tid] = re;
+        q_lds[nope + 2 * tid + 1] = im;
+      } else {
+        q_lds[nope + tid] = re;
+        q_lds[nope + tid + rope / 2] = im;
+      }
+    }
+  } else {
+    rope_pairs(a.q + (size_t)h * hd + nope, rope, sp->rope_cs, a.is_v3, tid, NT);  // q rope, in place
+  }
   // key = [k_nope | rope(k_rope)], value  -> f16 caches at kv_pos
   uint16_t* kc = a.key_cache + ((size_t)kv_pos * a.n_heads + h) * hd;
   uint16_t* vc = a.value_cache + ((size_t)kv_pos * a.n_heads + h) * vd;
   const float* kvb = a.kv_b + (size_t)h * (nope + vd);
-  for (int i = tid; i < nope; i += 256) kc[i] = f2h(kvb[i]);
-  for (int i = tid; i < vd; i += 256) vc[i] = f2h(kvb[nope + i]);
+  for (int i = tid; i < nope; i += NT) kc[i] = f2h(kvb[i]);
+  for (int i = tid; i < vd; i += NT) vc[i] = f2h(kvb[nope + i]);
   if (tid < rope / 2) {
     const float* kr = a.kv_a + a.lora;
     const float v0 = kr[2 * tid], v1 = kr[2 * tid + 1];
@@ -616,7 +634,7 @@ DEV void rope_kv_mha_body(const AttnMhaArgs& a, const StepParams* __restrict__ s
   }
 }
 __global__ __launch_bounds__(256) void rope_kv_mha_kernel(AttnMhaArgs a, const StepParams* __restrict__ sp) {
-  rope_kv_mha_body(a, sp, blockIdx.x, threadIdx.x);
+  rope_kv_mha_body<256>(a, sp, blockIdx.x, threadIdx.x);
 }
 int launch_rope_kv_mha(hipStream_t st, const AttnMhaArgs& a, const StepParams* sp) {
   if (a.rope > 128 || (a.rope & 1)) DSK_FAIL(DSK_ERR_UNSUPPORTED, "rope dim %d (max 128, even)", a.rope);
@@ -631,10 +649,11 @@ int launch_rope_kv_mha(hipStream_t st, const AttnMhaArgs& a, const StepParams* s
 // returns this thread's output element (valid for tid < v_dim).  part: 256 / (v_dim / 4) * v_dim floats.
 // Scores: 16 lanes per cached position (4 positions per wave step, 128-byte coalesced f16 reads);
 // values: 4 output dims per thread, v_dim / 4 threads per position.
-DEV float attn_mha_body(const AttnMhaArgs& a, int kv_len, int h, int tid, float* att, float* scratch, float* part) {
+// q: the head's query (global, or the LDS copy the fused kernel rotated in place).  NT threads; part: NT / (v_dim / 4) * v_dim floats.
+template <int NT>
+DEV float attn_mha_body(const AttnMhaArgs& a, const float* q, int kv_len, int h, int tid, float* att, float* scratch, float* part) {
   const int wave = tid >> 6, lane = tid & 63, grp = lane >> 4, sl = lane & 15;
   const int hd = a.head_dim, vd = a.v_dim, H = a.n_heads;
-  const float* q = a.q + (size_t)h * hd;
   float qv[4][4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -643,54 +662,89 @@ DEV float attn_mha_body(const AttnMhaArgs& a, int kv_len, int h, int tid, float*
     for (int i = 0; i < 4; ++i) qv[j][i] = d0 < hd ? q[d0 + i] : 0.f;
   }
   const float inv = sqrtf((float)hd);
-  for (int t0 = wave * 4; t0 < kv_len; t0 += 16) {
-    const int t = t0 + grp;
-    float p = 0.f;
-    if (t < kv_len) {
-      const uint16_t* kr = a.key_cache + ((size_t)t * H + h) * hd;
-      f16x4 k[4];
+  // 4 positions per 16-lane group and step (16 per wave, 64 per workgroup): up to 16 eight-byte loads in
+  // flight per lane, so a long context streams the cache instead of paying one latency per position
+  for (int t0 = wave * 16; t0 < kv_len; t0 += NT / 4) {
+    f16x4 k[4][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (64 * j + sl * 4 < hd) k[j] = *reinterpret_cast<const f16x4*>(kr + 64 * j + sl * 4);
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + u * 4 + grp;
+      if (t < kv_len) {
+        const uint16_t* kr = a.key_cache + ((size_t)t * H + h) * hd;
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (64 * j + sl * 4 < hd) {
-          p = fmaf(qv[j][0], (float)k[j].x, p);
-          p = fmaf(qv[j][1], (float)k[j].y, p);
-          p = fmaf(qv[j][2], (float)k[j].z, p);
-          p = fmaf(qv[j][3], (float)k[j].w, p);
-        }
+        for (int j = 0; j < 4; ++j)
+          if (64 * j + sl * 4 < hd) k[u][j] = *reinterpret_cast<const f16x4*>(kr + 64 * j + sl * 4);
+      }
     }
-    p = row16_sum(p);
-    if (sl == 0 && t < kv_len) att[t] = p / inv;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + u * 4 + grp;
+      float p = 0.f;
+      if (t < kv_len) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (64 * j + sl * 4 < hd) {
+            p = fmaf(qv[j][0], (float)k[u][j].x, p);
+            p = fmaf(qv[j][1], (float)k[u][j].y, p);
+            p = fmaf(qv[j][2], (float)k[u][j].z, p);
+            p = fmaf(qv[j][3], (float)k[u][j].w, p);
+          }
+      }
+      p = row16_sum(p);
+      if (sl == 0 && t < kv_len) att[t] = p / inv;
+    }
   }
+  // the first two value rows of this thread are requested now: their latency hides behind the softmax
+  const int tpp = vd >> 2;        // threads per position
+  const int TG = NT / tpp;        // positions in flight
+  const int g = tid / tpp, i4 = tid - g * tpp;
+  f16x4 vpre[2] = {};
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+    if (g < TG && g + k * TG < kv_len)
+      vpre[k] = *reinterpret_cast<const f16x4*>(a.value_cache + ((size_t)(g + k * TG) * H + h) * vd + i4 * 4);
   __syncthreads();
   // softmax, src/infer.cpp:472-487
   float mx = -INFINITY;
-  for (int t = tid; t < kv_len; t += 256) mx = fmaxf(mx, att[t]);
-  mx = block_max(mx, scratch, tid, 256);
+  for (int t = tid; t < kv_len; t += NT) mx = fmaxf(mx, att[t]);
+  mx = block_max(mx, scratch, tid, NT);
   float sum = 0.f;
-  for (int t = tid; t < kv_len; t += 256) {
+  for (int t = tid; t < kv_len; t += NT) {
     const float e = expf(att[t] - mx);
     att[t] = e;
     sum += e;
   }
-  sum = block_sum(sum, scratch, tid, 256);
-  for (int t = tid; t < kv_len; t += 256) att[t] = att[t] / sum;
+  sum = block_sum(sum, scratch, tid, NT);
+  for (int t = tid; t < kv_len; t += NT) att[t] = att[t] / sum;
   __syncthreads();
   // mix values: thread (g, i4) sums positions g, g+TG, ... for outputs 4*i4..4*i4+3; groups are added in order
-  const int tpp = vd >> 2;        // threads per position
-  const int TG = 256 / tpp;       // positions in flight
-  const int g = tid / tpp, i4 = tid - g * tpp;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   if (g < TG) {
-    for (int t = g; t < kv_len; t += TG) {
-      const float w = att[t];
-      const f16x4 v = *reinterpret_cast<const f16x4*>(a.value_cache + ((size_t)t * H + h) * vd + i4 * 4);
-      acc[0] = fmaf(w, (float)v.x, acc[0]);
-      acc[1] = fmaf(w, (float)v.y, acc[1]);
-      acc[2] = fmaf(w, (float)v.z, acc[2]);
-      acc[3] = fmaf(w, (float)v.w, acc[3]);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int t = g + k * TG;
+      if (t < kv_len) {
+        const float w = att[t];
+        acc[0] = fmaf(w, (float)vpre[k].x, acc[0]);
+        acc[1] = fmaf(w, (float)vpre[k].y, acc[1]);
+        acc[2] = fmaf(w, (float)vpre[k].z, acc[2]);
+        acc[3] = fmaf(w, (float)vpre[k].w, acc[3]);
+      }
+    }
+    for (int t0 = g + 2 * TG; t0 < kv_len; t0 += 4 * TG) {  // 4 rows in flight per thread
+      f16x4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (t0 + k * TG < kv_len) v[k] = *reinterpret_cast<const f16x4*>(a.value_cache + ((size_t)(t0 + k * TG) * H + h) * vd + i4 * 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (t0 + k * TG < kv_len) {
+          const float w = att[t0 + k * TG];
+          acc[0] = fmaf(w, (float)v[k].x, acc[0]);
+          acc[1] = fmaf(w, (float)v[k].y, acc[1]);
+          acc[2] = fmaf(w, (float)v[k].z, acc[2]);
+          acc[3] = fmaf(w, (float)v[k].w, acc[3]);
+        }
     }
     *reinterpret_cast<f32x4*>(part + (size_t)g * vd + i4 * 4) = f32x4{acc[0], acc[1], acc[2], acc[3]};
   }
@@ -705,7 +759,8 @@ __global__ __launch_bounds__(256) void attn_mha_kernel(AttnMhaArgs a, const Step
   __shared__ float scratch[4];
   __shared__ __attribute__((aligned(16))) float part[1024];
   const int h = blockIdx.x, tid = threadIdx.x;
-  const float o = attn_mha_body(a, kv_len_override > 0 ? kv_len_override : sp->kv_len, h, tid, reinterpret_cast<float*>(smem), scratch, part);
+  const float o = attn_mha_body<256>(a, a.q + (size_t)h * a.head_dim, kv_len_override > 0 ? kv_len_override : sp->kv_len, h, tid,
+                                reinterpret_cast<float*>(smem), scratch, part);
   if (tid < a.v_dim) a.out[(size_t)h * a.v_dim + tid] = o;
 }
 
@@ -713,15 +768,18 @@ __global__ __launch_bounds__(256) void attn_mha_kernel(AttnMhaArgs a, const Step
 // (src/infer.cpp:956-1020), attention (:728-762), and the Q8_K quantisation of the concatenated head
 // outputs that the wo GEMV consumes (src/quant.cpp:616-653): a 256-block spans 256 / v_dim heads, the
 // LAST of them to arrive (write-through stores, one counter per block) quantises the block.
-__global__ __launch_bounds__(256) void attn_mha_fused_kernel(AttnMhaArgs a, const StepParams* __restrict__ sp) {
+// 16 waves per head: a long context is a stream of 80 KB per position and layer; 128 heads x 16 waves keep
+// enough eight-byte loads in flight to approach the HBM rate (4 waves per head reach 1.5 TB/s).
+__global__ __launch_bounds__(1024) void attn_mha_fused_kernel(AttnMhaArgs a, const StepParams* __restrict__ sp) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  __shared__ float scratch[4];
-  __shared__ __attribute__((aligned(16))) float part[1024];
+  __shared__ float scratch[16];
+  __shared__ __attribute__((aligned(16))) float part[4096];
   __shared__ int last_flag;
+  __shared__ __attribute__((aligned(16))) float q_s[256];
   const int h = blockIdx.x, tid = threadIdx.x, vd = a.v_dim;
-  rope_kv_mha_body(a, sp, h, tid);
-  __syncthreads();  // q (rotated in place) and this position's k / v are re-read below by other threads
-  const float o = attn_mha_body(a, sp->kv_len, h, tid, reinterpret_cast<float*>(smem), scratch, part);
+  rope_kv_mha_body<1024>(a, sp, h, tid, q_s);
+  __syncthreads();  // q (rotated into LDS) and this position's k / v are read below by other threads
+  const float o = attn_mha_body<1024>(a, q_s, sp->kv_len, h, tid, reinterpret_cast<float*>(smem), scratch, part);
   if (!a.q_qs) {
     if (tid < vd) a.out[(size_t)h * vd + tid] = o;
     return;
@@ -757,7 +815,7 @@ int launch_attn_mha_fused(hipStream_t st, const AttnMhaArgs& a, const StepParams
   const size_t lds = (size_t)max_kv * 4;
   if (lds > 150 * 1024) DSK_FAIL(DSK_ERR_UNSUPPORTED, "attn: kv_len %d does not fit LDS", max_kv);
   if (lds > 64 * 1024) hipFuncSetAttribute((const void*)attn_mha_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(attn_mha_fused_kernel, dim3(a.n_heads), dim3(256), lds, st, a, sp);
+  hipLaunchKernelGGL(attn_mha_fused_kernel, dim3(a.n_heads), dim3(1024), lds, st, a, sp);
   return DSK_OK;
 }
 int launch_attn_mha(hipStream_t st, const AttnMhaArgs& a, const StepParams* sp, int kv_len_override, int max_kv) {
