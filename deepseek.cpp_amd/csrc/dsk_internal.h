@@ -198,8 +198,19 @@ struct AttnMhaArgs {
   unsigned* q_counter;
 };
 int launch_rope_kv_mha(hipStream_t st, const AttnMhaArgs& a, const StepParams* sp);
+// Per-head fusion of the second-stage projections with attention (kernels_gemv.hip head_attn_kernel):
+// workgroup h computes head h's rows of wq_b (optional) and wkv_b into LDS, then runs the attention step.
+struct HeadAttnArgs {
+  GemvTask tq, tkv;      // rows = the FULL matrices; the kernel takes rows [h * rows_per_head, +rows_per_head)
+  int has_q;             // 0: q was produced by the first-stage launch (q_lora_rank == 0), read a.q
+  int quant, b0, b1;
+  int lq_log2, lkv_log2; // lanes per row of the two projections
+  int lds_q, lds_kv;     // bytes of the two staged activation vectors
+  AttnMhaArgs a;
+};
+int head_attn_plan(HeadAttnArgs& A);
+int launch_head_attn(hipStream_t st, const HeadAttnArgs& A, const StepParams* sp, int max_kv);
 int launch_attn_mha(hipStream_t st, const AttnMhaArgs& a, const StepParams* sp, int kv_len_override, int max_kv);
-int launch_attn_mha_fused(hipStream_t st, const AttnMhaArgs& a, const StepParams* sp, int max_kv);
 struct AttnMlaArgs {
   float* q_rope;         // (H, rope)
   const float* q_c;      // (H, lora)

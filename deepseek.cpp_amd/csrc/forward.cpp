@@ -128,6 +128,8 @@ int build_plans(dsk_model* m) {
   m->lp_qkv_a.assign(nl, -1); m->lp_qkv_b.assign(nl, -1); m->lp_wv_b.assign(nl, -1); m->lp_wo.assign(nl, -1);
   m->lp_w13.assign(nl, -1); m->lp_w2.assign(nl, -1); m->lp_w2_shared.assign(nl, -1);
   m->plans.clear();
+  m->head_attn.assign(nl, HeadAttnArgs());
+  m->head_attn_bytes.assign(nl, 0.0);
   for (int l = 0; l < nl; ++l) {
     Layer& L = m->L[l];
     {  // 1. wq_a (or wq) || wkv_a on rmsnorm(x, attn_norm)
@@ -167,6 +169,25 @@ int build_plans(dsk_model* m) {
       }
       h.algo_bytes = bytes;
       DSK_TRY(add_plan(m, h, &m->lp_qkv_b[l]));
+      if (!c.use_mla) {  // MHA: the same projections, consumed per head by the fused attention launch
+        HeadAttnArgs A;
+        memset(&A, 0, sizeof A);
+        A.quant = wq; A.b0 = std::max(1, c.block_size[0]); A.b1 = std::max(1, c.block_size[1]);
+        A.has_q = c.q_lora_rank > 0;
+        const GemvLaunch& P = m->plans[m->lp_qkv_b[l]];
+        if (A.has_q) { A.tq = P.t[0]; A.tkv = P.t[1]; }
+        else A.tkv = P.t[0];
+        AttnMhaArgs& a = A.a;
+        a.q = m->q; a.kv_b = m->kv_b; a.kv_a = m->kv_a; a.key_cache = L.key_cache; a.value_cache = L.value_cache; a.out = m->att_out;
+        a.n_heads = H; a.head_dim = m->head_dim; a.nope = c.qk_nope_head_dim; a.rope = c.qk_rope_head_dim; a.v_dim = c.v_head_dim;
+        a.lora = c.kv_lora_rank; a.is_v3 = c.has_moegate_bias;
+        a.q_counter = m->att_counter;
+        if (kq) { a.q_qs = m->a_att.qs; a.q_d = m->a_att.d; a.q_bsums = m->a_att.bsums; }
+        DSK_TRY(head_attn_plan(A));
+        A.a.out = m->att_out;
+        m->head_attn[l] = A;
+        m->head_attn_bytes[l] = bytes;
+      }
     }
     if (c.use_mla) {  // per-head wv_b on the per-head latent outputs (src/infer.cpp:1134-1137): block-diagonal
       GemvLaunch h;
@@ -343,16 +364,10 @@ static int attention_mha(dsk_model* m, int l, int max_kv) {
   hipStream_t st = m->ctx->stream;
   const int H = c.n_heads, hd = m->head_dim;
   DSK_TRY(run_plan(m, "gemv_qkv_a", m->lp_qkv_a[l]));
-  DSK_TRY(run_plan(m, "gemv_qkv_b", m->lp_qkv_b[l]));
-  AttnMhaArgs a;
-  a.q = m->q; a.kv_b = m->kv_b; a.kv_a = m->kv_a; a.key_cache = L.key_cache; a.value_cache = L.value_cache; a.out = m->att_out;
-  a.n_heads = H; a.head_dim = hd; a.nope = c.qk_nope_head_dim; a.rope = c.qk_rope_head_dim; a.v_dim = c.v_head_dim;
-  a.lora = c.kv_lora_rank; a.is_v3 = c.has_moegate_bias;
-  a.q_qs = nullptr; a.q_d = nullptr; a.q_bsums = nullptr; a.q_counter = m->att_counter;
-  if (is_kq(c.weight_quant)) { a.q_qs = m->a_att.qs; a.q_d = m->a_att.d; a.q_bsums = m->a_att.bsums; }
-  // rope + cache write + attention + Q8_K of the head outputs: one launch
-  PROFILED("attn_mha", (double)m->sp_host->kv_len * H * (hd + c.v_head_dim) * 2 + (double)H * (hd * 6 + c.v_head_dim * 11),
-           launch_attn_mha_fused(st, a, m->sp_dev, max_kv));
+  // second-stage projections (wq_b, wkv_b) + rope + cache write + attention + Q8_K of the head outputs:
+  // one launch, one workgroup per head (kernels_gemv.hip head_attn_kernel)
+  PROFILED("attn_mha", m->head_attn_bytes[l] + (double)m->sp_host->kv_len * H * (hd + c.v_head_dim) * 2 + (double)H * (hd * 2 + c.v_head_dim * 11),
+           launch_head_attn(st, m->head_attn[l], m->sp_dev, max_kv));
   DSK_TRY(run_plan(m, "gemv_wo", m->lp_wo[l]));  // residual: src/infer.cpp:832-834
   return DSK_OK;
 }

@@ -24,6 +24,7 @@
 //     slots in k order, then the shared expert (src/infer.cpp:873-878, 899-903);
 //   * all reductions are fixed-order shuffles: no atomics, bit-reproducible run to run.
 #include "dsk_internal.h"
+#include "attn_device.h"
 #include <type_traits>
 
 typedef unsigned int u32;
@@ -828,6 +829,121 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvLaunch* __restr
     }
   }
   if (tl && tid == 0) tl[3] = wall_clock64();
+}
+
+// ------------------------------------------------------------------------------------
+// Second-stage projections + attention, per head (MHA path, src/infer.cpp:976-1049).
+// q = wq_b . norm(q_a) and kv_b = wkv_b . norm(kv_a) are consumed head by head: head h needs exactly
+// rows [h*head_dim, +head_dim) of wq_b and [h*(nope+v), +(nope+v)) of wkv_b.  One 16-wave workgroup per
+// head computes those rows straight into LDS and goes on with RoPE, the cache write and attention: q and
+// kv_b never travel through HBM, and a whole launch (boundary, descriptor, prologue, tail) disappears.
+// Only n_heads CUs stream weights here, but this stage is 18 MB of a 200 MB layer.
+// ------------------------------------------------------------------------------------
+template <int QT>
+__global__ __launch_bounds__(1024) void head_attn_kernel(const HeadAttnArgs A, const StepParams* __restrict__ sp) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ float scratch[16];
+  __shared__ __attribute__((aligned(16))) float q_s[256];
+  __shared__ __attribute__((aligned(16))) float kvb_s[512];
+  __shared__ __attribute__((aligned(16))) float part[4096];
+  __shared__ int last_flag;
+  constexpr bool KQ = QT == DSK_QUANT_Q2_K || QT == DSK_QUANT_Q3_K;
+  constexpr int NW = 16;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int h = blockIdx.x;
+  const AttnMhaArgs& a = A.a;
+  uint8_t* act_q = smem;
+  uint8_t* act_kv = smem + A.lds_q;
+  float* att = reinterpret_cast<float*>(smem + A.lds_q + A.lds_kv);
+  if (A.has_q) {
+    if (KQ) stage_q8<QT == DSK_QUANT_Q2_K, NW>(A.tq, act_q, tid, scratch);
+    else stage_f32<NW>(A.tq, reinterpret_cast<float*>(act_q), tid, scratch);
+    __syncthreads();  // scratch is reused by the second staging
+  }
+  if (KQ) stage_q8<QT == DSK_QUANT_Q2_K, NW>(A.tkv, act_kv, tid, scratch);
+  else stage_f32<NW>(A.tkv, reinterpret_cast<float*>(act_kv), tid, scratch);
+  __syncthreads();
+
+  // head h's rows of one projection: 64/LPR rows per wave and step.  (Dealing both projections' rows to the
+  // waves as one unit list, or 2 row sets per lane, measured slower: this stage is VALU-bound on its one CU.)
+  auto head_rows = [&](const GemvTask& T, const uint8_t* act, int lpr_log2, int nrows, float* out_lds) {
+    const int RPW = 64 >> lpr_log2;
+    const int rloc = lane >> lpr_log2, sub = lane & ((1 << lpr_log2) - 1);
+    const WPtr P = resolve(T);
+    const KQRsrc B = kq_rsrc<QT, false>(P);
+    const int nb = T.n >> 8, its = (nb * 4) >> lpr_log2;
+    for (int base = wave * RPW; base < nrows; base += NW * RPW) {  // wave-uniform bounds, no barrier inside
+      const int lr = base + rloc;
+      const bool valid = lr < nrows;
+      int row[1] = {h * nrows + (valid ? lr : nrows - 1)};
+      float acc[1], acc2[1];
+      if constexpr (KQ) {
+        int rowblk[1] = {row[0] * nb + (sub >> 2)};
+        rows_dot_kq<QT, 1, 4, false>(B, its, lpr_log2, sub & 3, rowblk, act + sub * ITEM_LDS, acc, acc2);
+      } else {
+        rows_dot_f<QT, 1, 4, false>(P, T.n, A.b0, A.b1, lpr_log2, lane, row, act, acc, acc2);
+      }
+      if (sub == 0 && valid) out_lds[lr] = acc[0];
+    }
+  };
+  if (A.has_q) head_rows(A.tq, act_q, A.lq_log2, a.head_dim, q_s);
+  else
+    for (int i = tid; i < a.head_dim; i += 1024) q_s[i] = a.q[(size_t)h * a.head_dim + i];
+  head_rows(A.tkv, act_kv, A.lkv_log2, a.nope + a.v_dim, kvb_s);
+  __syncthreads();
+  ad::rope_kv_from_lds<1024>(a, sp, h, tid, q_s, kvb_s);
+  __syncthreads();  // the rotated q (LDS) and this position's k / v (global, same CU) are read by other threads below
+  const float o = ad::attn_mha_body<1024>(a, q_s, sp->kv_len, h, tid, att, scratch, part);
+  ad::attn_out_q8(a, h, tid, o, &last_flag);
+}
+
+static int head_lpr_log2(int quant, int n) {
+  const bool kq = quant == DSK_QUANT_Q2_K || quant == DSK_QUANT_Q3_K;
+  const int epi = kq ? 64 : (quant == DSK_QUANT_F32 ? 4 : (quant == DSK_QUANT_F16 ? 8 : 16));
+  int lpr = 64;
+  while (lpr > 1 && (n / epi) % lpr) lpr >>= 1;
+  int l = 0;
+  while ((1 << (l + 1)) <= lpr) ++l;
+  return l;
+}
+int head_attn_plan(HeadAttnArgs& A) {
+  const bool kq = A.quant == DSK_QUANT_Q2_K || A.quant == DSK_QUANT_Q3_K;
+  const int epi = kq ? 64 : (A.quant == DSK_QUANT_F32 ? 4 : (A.quant == DSK_QUANT_F16 ? 8 : 16));
+  if (A.a.head_dim > 256 || A.a.head_dim % 4 || A.a.v_dim > 256 || A.a.v_dim % 4 || A.a.nope + A.a.v_dim > 512)
+    DSK_FAIL(DSK_ERR_UNSUPPORTED, "attn: head_dim %d / nope %d / v_head_dim %d", A.a.head_dim, A.a.nope, A.a.v_dim);
+  if (A.a.rope > 128 || (A.a.rope & 1)) DSK_FAIL(DSK_ERR_UNSUPPORTED, "rope dim %d (max 128, even)", A.a.rope);
+  if (A.a.q_qs && (A.a.n_heads * A.a.v_dim) % 256) DSK_FAIL(DSK_ERR_INVALID, "attn: n_heads * v_head_dim = %d is not a multiple of 256", A.a.n_heads * A.a.v_dim);
+  for (const GemvTask* T : {&A.tq, &A.tkv}) {
+    if (T == &A.tq && !A.has_q) continue;
+    if (T->n % (kq ? 256 : epi)) DSK_FAIL(DSK_ERR_INVALID, "head projections: n=%d", T->n);
+  }
+  A.lq_log2 = A.has_q ? head_lpr_log2(A.quant, A.tq.n) : 0;
+  A.lkv_log2 = head_lpr_log2(A.quant, A.tkv.n);
+  auto lds = [&](int n) { return (int)(((kq ? (size_t)(n / 64) * ITEM_LDS : (size_t)n * 4) + 15) & ~(size_t)15); };
+  A.lds_q = A.has_q ? lds(A.tq.n) : 0;
+  A.lds_kv = lds(A.tkv.n);
+  if (A.b0 < 1) A.b0 = 1;
+  if (A.b1 < 1) A.b1 = 1;
+  return DSK_OK;
+}
+template <int QT>
+static int launch_head_attn_q(hipStream_t st, const HeadAttnArgs& A, const StepParams* sp, size_t lds) {
+  auto k = head_attn_kernel<QT>;
+  if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k, dim3(A.a.n_heads), dim3(1024), lds, st, A, sp);
+  return DSK_OK;
+}
+int launch_head_attn(hipStream_t st, const HeadAttnArgs& A, const StepParams* sp, int max_kv) {
+  const size_t lds = (size_t)A.lds_q + A.lds_kv + (size_t)max_kv * 4;
+  if (lds > 120 * 1024) DSK_FAIL(DSK_ERR_UNSUPPORTED, "attn: kv_len %d does not fit LDS", max_kv);
+  switch (A.quant) {
+    case DSK_QUANT_F32: return launch_head_attn_q<DSK_QUANT_F32>(st, A, sp, lds);
+    case DSK_QUANT_F16: return launch_head_attn_q<DSK_QUANT_F16>(st, A, sp, lds);
+    case DSK_QUANT_F8E5M2: return launch_head_attn_q<DSK_QUANT_F8E5M2>(st, A, sp, lds);
+    case DSK_QUANT_Q2_K: return launch_head_attn_q<DSK_QUANT_Q2_K>(st, A, sp, lds);
+    case DSK_QUANT_Q3_K: return launch_head_attn_q<DSK_QUANT_Q3_K>(st, A, sp, lds);
+  }
+  DSK_FAIL(DSK_ERR_INVALID, "head_attn: bad quant %d", A.quant);
 }
 
 // ------------------------------------------------------------------------------------

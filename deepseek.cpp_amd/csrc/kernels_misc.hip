@@ -764,60 +764,6 @@ __global__ __launch_bounds__(256) void attn_mha_kernel(AttnMhaArgs a, const Step
   if (tid < a.v_dim) a.out[(size_t)h * a.v_dim + tid] = o;
 }
 
-// The whole per-head attention step in ONE launch: RoPE + cache write + sink rotation
-// (src/infer.cpp:956-1020), attention (:728-762), and the Q8_K quantisation of the concatenated head
-// outputs that the wo GEMV consumes (src/quant.cpp:616-653): a 256-block spans 256 / v_dim heads, the
-// LAST of them to arrive (write-through stores, one counter per block) quantises the block.
-// 16 waves per head: a long context is a stream of 80 KB per position and layer; 128 heads x 16 waves keep
-// enough eight-byte loads in flight to approach the HBM rate (4 waves per head reach 1.5 TB/s).
-__global__ __launch_bounds__(1024) void attn_mha_fused_kernel(AttnMhaArgs a, const StepParams* __restrict__ sp) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  __shared__ float scratch[16];
-  __shared__ __attribute__((aligned(16))) float part[4096];
-  __shared__ int last_flag;
-  __shared__ __attribute__((aligned(16))) float q_s[256];
-  const int h = blockIdx.x, tid = threadIdx.x, vd = a.v_dim;
-  rope_kv_mha_body<1024>(a, sp, h, tid, q_s);
-  __syncthreads();  // q (rotated into LDS) and this position's k / v are read below by other threads
-  const float o = attn_mha_body<1024>(a, q_s, sp->kv_len, h, tid, reinterpret_cast<float*>(smem), scratch, part);
-  if (!a.q_qs) {
-    if (tid < vd) a.out[(size_t)h * vd + tid] = o;
-    return;
-  }
-  if (tid < vd) __hip_atomic_store(a.out + (size_t)h * vd + tid, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  const int b_first = (h * vd) >> 8, b_last = ((h + 1) * vd - 1) >> 8;
-  for (int b = b_first; b <= b_last; ++b) {
-    if (tid == 0) {
-      const int h0 = (b * 256) / vd, h1 = min((b * 256 + 255) / vd, a.n_heads - 1);
-      const unsigned old = __hip_atomic_fetch_add(a.q_counter + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      last_flag = old == (unsigned)(h1 - h0);
-      if (last_flag) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __hip_atomic_store(a.q_counter + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    __syncthreads();
-    if (last_flag && tid < 64) {
-      float v[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = __hip_atomic_load(a.out + (size_t)b * 256 + tid * 4 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      q8k_block(v, tid, a.q_qs + (size_t)b * 256, a.q_d + b, a.q_bsums + (size_t)b * 16);
-    }
-    __syncthreads();
-  }
-}
-int launch_attn_mha_fused(hipStream_t st, const AttnMhaArgs& a, const StepParams* sp, int max_kv) {
-  if (a.rope > 128 || (a.rope & 1)) DSK_FAIL(DSK_ERR_UNSUPPORTED, "rope dim %d (max 128, even)", a.rope);
-  if (a.head_dim > 256 || a.head_dim % 4 || a.v_dim > 256 || a.v_dim % 4) DSK_FAIL(DSK_ERR_UNSUPPORTED, "attn: head_dim %d / v_head_dim %d", a.head_dim, a.v_dim);
-  if (a.q_qs && (a.n_heads * a.v_dim) % 256) DSK_FAIL(DSK_ERR_INVALID, "attn: n_heads * v_head_dim = %d is not a multiple of 256", a.n_heads * a.v_dim);
-  const size_t lds = (size_t)max_kv * 4;
-  if (lds > 150 * 1024) DSK_FAIL(DSK_ERR_UNSUPPORTED, "attn: kv_len %d does not fit LDS", max_kv);
-  if (lds > 64 * 1024) hipFuncSetAttribute((const void*)attn_mha_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(attn_mha_fused_kernel, dim3(a.n_heads), dim3(1024), lds, st, a, sp);
-  return DSK_OK;
-}
 int launch_attn_mha(hipStream_t st, const AttnMhaArgs& a, const StepParams* sp, int kv_len_override, int max_kv) {
   if (a.head_dim > 256 || a.head_dim % 4 || a.v_dim > 256 || a.v_dim % 4) DSK_FAIL(DSK_ERR_UNSUPPORTED, "attn: head_dim %d / v_head_dim %d", a.head_dim, a.v_dim);
   const size_t lds = (size_t)max_kv * 4;
