@@ -177,6 +177,11 @@ struct RouterArgs {       // F32 router GEMV (+ optional rmsnorm prologue) + moe
   int* active_experts;
   float* active_weights;
   float* scores_out;
+  // optional: the Q8_K quantisation of the normed x (what the experts' w1/w3 GEMV consumes), written by the
+  // first dim/256 workgroups -- every workgroup knows the norm scale anyway, so this costs one wave a block
+  int8_t* q_qs;
+  float* q_d;
+  int16_t* q_bsums;
   int dbg;                // micro-benchmark only: 1 = skip the gate, 2 = skip the weight stream, 4 = skip the norm
 };
 int launch_router_gate(hipStream_t st, const RouterArgs& a);

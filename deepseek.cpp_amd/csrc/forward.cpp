@@ -255,7 +255,8 @@ int build_plans(dsk_model* m) {
         task_weights(T, w1);
         task_weights2(T, w3);
         task_expert(T, w1, ae, k);
-        task_act_norm(T, m->x, L.t[DSK_ROLE_FFN_NORM], c.norm_eps);
+        if (kq && c.dim % 256 == 0) task_act_q8(T, m->a_xb);  // the router launch leaves Q8_K(rmsnorm(x)) behind
+        else task_act_norm(T, m->x, L.t[DSK_ROLE_FFN_NORM], c.norm_eps);
         task_out_hb(m, T, l, (size_t)k * hb_stride);
       }
       double bytes = K * e13 + c.dim * 8.0 + 4.0 * K * mi;
@@ -263,7 +264,8 @@ int build_plans(dsk_model* m) {
         GemvTask& T = h.t[h.n_tasks++];
         task_weights(T, L.t[DSK_ROLE_SHARED_W1]);
         task_weights2(T, L.t[DSK_ROLE_SHARED_W3]);
-        task_act_norm(T, m->x, L.t[DSK_ROLE_FFN_NORM], c.norm_eps);
+        if (kq && c.dim % 256 == 0) task_act_q8(T, m->a_xb);
+        else task_act_norm(T, m->x, L.t[DSK_ROLE_FFN_NORM], c.norm_eps);
         task_out_hb(m, T, l, (size_t)K * hb_stride);
         bytes += 2 * weight_bytes_2d(m, wq, shared_n, c.dim) + 4.0 * shared_n;
       }
@@ -422,6 +424,7 @@ static int ffn(dsk_model* m, int l) {
   r.active_experts = m->route_e + (size_t)l * K;
   r.active_weights = m->route_w + (size_t)l * K;
   r.scores_out = m->gate_scores + (size_t)l * E;
+  if (is_kq(c.weight_quant) && c.dim % 256 == 0) { r.q_qs = m->a_xb.qs; r.q_d = m->a_xb.d; r.q_bsums = m->a_xb.bsums; }
   PROFILED("router_gate", (double)E * c.dim * 4 + c.dim * 8.0, launch_router_gate(st, r));
   if (m->ctx->world > 1) HIP_TRY(hipMemsetAsync(m->eout, 0, (size_t)K * c.dim * 4, st));
   DSK_TRY(run_plan(m, "gemv_experts_w13", m->lp_w13[l]));

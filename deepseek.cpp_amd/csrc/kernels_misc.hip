@@ -525,6 +525,14 @@ __global__ __launch_bounds__(1024) void router_gate_kernel(RouterArgs a) {
     }
     acc = wave_sum_dpp(acc);
   }
+  if (a.q_qs && a.norm_w && wave == 0) {  // Q8_K of rmsnorm(x): block b by workgroup b (src/quant.cpp:616-653)
+    for (int b = blockIdx.x; b < dim / 256; b += gridDim.x) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(a.x + b * 256 + lane * 4);
+      const f32x4 nw = *reinterpret_cast<const f32x4*>(a.norm_w + b * 256 + lane * 4);
+      const float v[4] = {xv.x * scale * nw.x, xv.y * scale * nw.y, xv.z * scale * nw.z, xv.w * scale * nw.w};
+      q8k_block(v, lane, a.q_qs + (size_t)b * 256, a.q_d + b, a.q_bsums + (size_t)b * 16);
+    }
+  }
   if (lane == 0) part[wave] = acc;
   __syncthreads();
   if (tid < RW && blockIdx.x * RW + tid < E) {
