@@ -116,6 +116,8 @@ struct GemvLaunch {
   // per group) runs  x[row] += w_k * out_k[row]  in k order, then + shared (src/infer.cpp:874-877,900-903)
   float* comb_x;
   unsigned* comb_counter;
+  int zero_absent;    // expert-sharded W2 launch: a task whose expert lives on another GPU stores zeros (the sum
+                      // all-reduce then needs no separate zero-fill of the slot buffer)
   int comb_geometry;  // plan exactly like a fused-combine launch (the expert-sharded W2 launch: same
                       // summation trees as on one GPU => bit-identical slot outputs)
   // debug (DSK_TIMELINE=1 with dsk_bench_gemv): 4 wall-clock stamps per workgroup (entry, staged, first
@@ -158,6 +160,8 @@ struct NormJob {         // one workgroup of norm_q8_kernel
 };
 
 // ---- launchers (kernels_misc.hip) --------------------------------------------------
+// x[i] += sum_k w[k] * eout[k][i] (k order), then + eout[n_slots][i] if add_shared (src/infer.cpp:874-877, 900-903)
+int launch_moe_combine(hipStream_t st, float* x, const float* eout, const float* weights, int n_slots, int add_shared, int n);
 int launch_quantize_q8k(hipStream_t st, const float* x, int n, int8_t* qs, float* d, int16_t* bsums);
 int launch_norm_jobs(hipStream_t st, const NormJob* jobs, int n_jobs, const StepParams* sp);
 int launch_repack_q2k(hipStream_t st, const uint8_t* aos, size_t n_blocks, uint8_t* qs, uint8_t* sc, uint8_t* dm);

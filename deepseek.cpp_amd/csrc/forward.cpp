@@ -292,7 +292,7 @@ int build_plans(dsk_model* m) {
         bytes += weight_bytes_2d(m, wq, c.dim, shared_n) + 4.0 * shared_n + 4.0 * c.dim;
       }
       if (m->ctx->world == 1) { h.comb_x = m->x; h.comb_counter = m->comb_counter; }
-      else h.comb_geometry = 1;
+      else { h.comb_geometry = 1; h.zero_absent = 1; }
       h.algo_bytes = bytes;
       DSK_TRY(add_plan(m, h, &m->lp_w2[l]));
     }
@@ -426,21 +426,17 @@ static int ffn(dsk_model* m, int l) {
   r.scores_out = m->gate_scores + (size_t)l * E;
   if (is_kq(c.weight_quant) && c.dim % 256 == 0) { r.q_qs = m->a_xb.qs; r.q_d = m->a_xb.d; r.q_bsums = m->a_xb.bsums; }
   PROFILED("router_gate", (double)E * c.dim * 4 + c.dim * 8.0, launch_router_gate(st, r));
-  if (m->ctx->world > 1) HIP_TRY(hipMemsetAsync(m->eout, 0, (size_t)K * c.dim * 4, st));
+  const bool exchange = m->ctx->world > 1 && !m->class_filter;  // (class timing enqueues one kernel class only)
   DSK_TRY(run_plan(m, "gemv_experts_w13", m->lp_w13[l]));
   DSK_TRY(run_plan(m, "gemv_experts_w2", m->lp_w2[l]));
-  if (m->ctx->world > 1) {
+  if (exchange || (m->ctx->world > 1 && m->class_filter)) {
     // every routed slot is non-zero on exactly one rank: a sum all-reduce is exact and order-independent
-    if (m->ctx->comm) {  // (null only in a single-rank dry run of a shard, dsk_comm_init with uid = NULL)
+    if (m->ctx->comm && exchange) {  // (comm is null only in a single-rank dry run of a shard, dsk_comm_init with uid = NULL)
       ncclResult_t rr = ncclAllReduce(m->eout, m->eout, (size_t)K * c.dim, ncclFloat, ncclSum, m->ctx->comm, st);
       if (rr != ncclSuccess) DSK_FAIL(DSK_ERR_COMM, "ncclAllReduce: %s", ncclGetErrorString(rr));
     }
-    NormJob j;  // combine in k order, then the shared expert (src/infer.cpp:874-877, 900-903)
-    memset(&j, 0, sizeof j);
-    j.x = m->x; j.n = c.dim; j.eps = c.norm_eps;
-    j.eout = m->eout; j.eweights = m->route_w + (size_t)l * K; j.n_routed_slots = K;
-    j.add_shared = c.n_shared_experts > 0; j.x_store = m->x;
-    PROFILED("moe_combine", (double)c.dim * (K + 3) * 4, launch_norm_jobs(st, &j, 1, m->sp_dev));
+    PROFILED("moe_combine", (double)c.dim * (K + 3) * 4,
+             launch_moe_combine(st, m->x, m->eout, m->route_w + (size_t)l * K, K, c.n_shared_experts > 0, c.dim));
   }
   return DSK_OK;
 }

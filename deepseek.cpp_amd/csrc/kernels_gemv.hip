@@ -758,7 +758,11 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvLaunch* __restr
     const int lo = (r_lo > vb ? r_lo : vb) - vb, hi = (r_hi < ve ? r_hi : ve) - vb;
     if (lo >= hi) continue;
     const WPtr P = resolve(T);
-    if (!P.present) continue;
+    if (!P.present) {  // the expert lives on another GPU
+      if (L.zero_absent && !GLU)
+        for (int rr = lo + tid; rr < hi; rr += NW * 64) T.out[rr] = 0.f;
+      continue;
+    }
     const KQRsrc B = kq_rsrc<QT, GLU>(P);
     const int nb = T.n >> 8, its = (nb * 4) >> lpr_log2;
     for (int base = lo; base < hi; base += RG) {
@@ -855,13 +859,39 @@ __global__ __launch_bounds__(1024) void head_attn_kernel(const HeadAttnArgs A, c
   uint8_t* act_q = smem;
   uint8_t* act_kv = smem + A.lds_q;
   float* att = reinterpret_cast<float*>(smem + A.lds_q + A.lds_kv);
-  if (A.has_q) {
-    if (KQ) stage_q8<QT == DSK_QUANT_Q2_K, NW>(A.tq, act_q, tid, scratch);
-    else stage_f32<NW>(A.tq, reinterpret_cast<float*>(act_q), tid, scratch);
-    __syncthreads();  // scratch is reused by the second staging
+  const int nbq = A.has_q ? A.tq.n >> 8 : 0, nbkv = A.tkv.n >> 8;
+  if (KQ && nbq + nbkv <= NW && A.tkv.act_mode == ACT_F32_NORM && (!A.has_q || A.tq.act_mode == ACT_F32_NORM)) {
+    // both latents (q_a: 6 blocks, kv_a: 2 blocks for DeepSeek-V3) normed + quantised in ONE pass: wave w owns
+    // block w of the concatenation; two sums of squares share one barrier (src/infer.cpp:601-611, quant.cpp:616-653)
+    const bool mine = wave < nbq + nbkv, is_q = wave < nbq;
+    const GemvTask& T = is_q ? A.tq : A.tkv;
+    const int b = is_q ? wave : wave - nbq;
+    f32x4 t = {0.f, 0.f, 0.f, 0.f}, wv = {0.f, 0.f, 0.f, 0.f};
+    if (mine) {
+      t = *reinterpret_cast<const f32x4*>(T.a_f32 + b * 256 + lane * 4);
+      wv = *reinterpret_cast<const f32x4*>(T.norm_w + b * 256 + lane * 4);
+    }
+    float ss = fmaf(t.x, t.x, fmaf(t.y, t.y, fmaf(t.z, t.z, t.w * t.w)));
+    ss = wave_sum(ss);
+    if (lane == 0) scratch[wave] = mine ? ss : 0.f;
+    __syncthreads();
+    float total = 0.f;
+    if (is_q) for (int i = 0; i < nbq; ++i) total += scratch[i];
+    else for (int i = nbq; i < nbq + nbkv; ++i) total += scratch[i];
+    if (mine) {
+      const float scale = 1.0f / sqrtf(total / (float)T.n + T.eps);
+      float v[4] = {t.x * scale * wv.x, t.y * scale * wv.y, t.z * scale * wv.z, t.w * scale * wv.w};
+      q8k_block_lds<QT == DSK_QUANT_Q2_K>(v, lane, (is_q ? act_q : act_kv) + (size_t)b * 4 * ITEM_LDS);
+    }
+  } else {
+    if (A.has_q) {
+      if (KQ) stage_q8<QT == DSK_QUANT_Q2_K, NW>(A.tq, act_q, tid, scratch);
+      else stage_f32<NW>(A.tq, reinterpret_cast<float*>(act_q), tid, scratch);
+      __syncthreads();  // scratch is reused by the second staging
+    }
+    if (KQ) stage_q8<QT == DSK_QUANT_Q2_K, NW>(A.tkv, act_kv, tid, scratch);
+    else stage_f32<NW>(A.tkv, reinterpret_cast<float*>(act_kv), tid, scratch);
   }
-  if (KQ) stage_q8<QT == DSK_QUANT_Q2_K, NW>(A.tkv, act_kv, tid, scratch);
-  else stage_f32<NW>(A.tkv, reinterpret_cast<float*>(act_kv), tid, scratch);
   __syncthreads();
 
   // head h's rows of one projection: 64/LPR rows per wave and step.  (Dealing both projections' rows to the

@@ -99,6 +99,21 @@ __global__ __launch_bounds__(256) void quantize_q8k_kernel(const float* __restri
   q8k_block(v, lane, qs + (size_t)b * 256, d + b, bsums + (size_t)b * 16);
 }
 
+// stand-alone MoE combine of the expert-sharded path (after the all-reduce of the slot outputs)
+__global__ __launch_bounds__(256) void moe_combine_kernel(float* __restrict__ x, const float* __restrict__ eout, const float* __restrict__ w,
+                                                          int n_slots, int add_shared, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float xv = x[i];
+  for (int k = 0; k < n_slots; ++k) xv = fmaf(eout[(size_t)k * n + i], w[k], xv);
+  if (add_shared) xv += eout[(size_t)n_slots * n + i];
+  x[i] = xv;
+}
+int launch_moe_combine(hipStream_t st, float* x, const float* eout, const float* weights, int n_slots, int add_shared, int n) {
+  hipLaunchKernelGGL(moe_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, st, x, eout, weights, n_slots, add_shared, n);
+  return DSK_OK;
+}
+
 int launch_quantize_q8k(hipStream_t st, const float* x, int n, int8_t* qs, float* d, int16_t* bsums) {
   if (n <= 0 || n % 256) DSK_FAIL(DSK_ERR_INVALID, "q8k: n=%d must be a positive multiple of 256", n);
   const int nb = n / 256;
