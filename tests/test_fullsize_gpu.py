@@ -139,3 +139,30 @@ def test_full_width_reduced_depth_v3_model_vs_oracle(ctx, oracle):
             os.rmdir(d)
     M.close()
     O.close()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("quant", ["f8e5m2", "q2_k"])
+def test_v2lite_full_width_reduced_depth_vs_oracle(ctx, oracle, quant):
+    """BASELINE.json configs[1] / [2]: DeepSeek-V2-Lite shapes (dim 2048, 16 heads, vocab 102400, 64 routed
+    experts top-6 greedy softmax, 2 shared, no q_lora; pad256 variant for Q2_K), 1 dense + 1 MoE block.
+    F8E5M2 is a float path: logits within 1e-3, routing identical.  Q2_K: flip-free trials to 1e-5, none gross."""
+    import dsk
+    c = synth.preset("v2lite", quant, False, n_layers=2, first_k_dense_replace=1, max_seq_len=64)
+    T = synth.random_block_model(c, seed=8)
+    M, O = dsk.Model(ctx, c, T), oracle.model(c, T)
+    errs, same = [], 0
+    toks = [7, 1234, 50000, 102399, 99]
+    for t in toks:
+        lo, lh = O.forward(t, 0), M.forward(t, 0)
+        errs.append(rel_inf(lh, lo))
+        same += int(np.array_equal(M.routing()[0], O.routing()[0]))
+    seq = [rel_inf(M.forward(t, p), O.forward(t, p)) for p, t in enumerate([5, 6, 7, 8])]
+    M.close()
+    O.close()
+    if quant == "f8e5m2":
+        assert max(errs + seq) < 1e-3, (errs, seq)
+        assert same == len(toks)
+    else:
+        assert min(errs) < 1e-5 and max(errs + seq) < 0.1, (errs, seq)
+        assert same >= len(toks) - 2
