@@ -230,6 +230,25 @@ struct AttnMlaArgs {
   int n_heads, head_dim, rope, lora, is_v3;
 };
 int launch_rope_kv_mla(hipStream_t st, const AttnMlaArgs& a, const StepParams* sp);
+// MLA, model path: (1) one workgroup normalises the latent, writes this position's cache entries and rotates the
+// sink keys; (2) one 16-wave workgroup per head: RoPE of q_rope, attention over the shared latent cache, the head's
+// wv_b rows, Q8_K of the concatenated outputs (kernels_gemv.hip mla_head_kernel).
+struct MlaKvArgs {
+  const float* kv_a;      // (lora + rope) raw output of wkv_a
+  const float* norm_w;    // kv_a_norm
+  float eps;
+  uint16_t *nope_cache, *rope_cache;
+  int lora, rope, is_v3;
+};
+int launch_mla_kv_write(hipStream_t st, const MlaKvArgs& a, const StepParams* sp);
+struct MlaHeadArgs {
+  AttnMlaArgs a;          // q_rope (un-rotated), q_c, caches; out unused
+  GemvTask twv;           // the (H * v_head_dim, lora) stack; the kernel takes rows [h * v, +v)
+  int quant, b0, b1, lpr_log2, lds_act;
+  AttnMhaArgs fin;        // out (H, v), v_dim, n_heads, Q8_K outputs + counter (only these fields are used)
+};
+int mla_head_plan(MlaHeadArgs& A);
+int launch_mla_head(hipStream_t st, const MlaHeadArgs& A, const StepParams* sp, int max_kv);
 int launch_attn_mla(hipStream_t st, const AttnMlaArgs& a, const StepParams* sp, int kv_len_override, int max_kv);
 int launch_rope_only(hipStream_t st, float* vec, int n_heads, int d, const float* cs, int is_v3);
 int launch_fill_tensor(hipStream_t st, const DTensor& t, uint64_t seed, float wscale);

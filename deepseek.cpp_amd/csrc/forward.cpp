@@ -129,6 +129,7 @@ int build_plans(dsk_model* m) {
   m->lp_w13.assign(nl, -1); m->lp_w2.assign(nl, -1); m->lp_w2_shared.assign(nl, -1);
   m->plans.clear();
   m->head_attn.assign(nl, HeadAttnArgs());
+  m->mla_head.assign(nl, MlaHeadArgs());
   m->head_attn_bytes.assign(nl, 0.0);
   for (int l = 0; l < nl; ++l) {
     Layer& L = m->L[l];
@@ -201,6 +202,18 @@ int build_plans(dsk_model* m) {
       T.out = m->vb_out;
       h.algo_bytes = weight_bytes_2d(m, wq, H * c.v_head_dim, c.kv_lora_rank) + 4.0 * H * (c.kv_lora_rank + c.v_head_dim);
       DSK_TRY(add_plan(m, h, &m->lp_wv_b[l]));
+      MlaHeadArgs A;  // the fused per-head launch: attention over the latent cache + this head's wv_b rows + Q8_K
+      memset(&A, 0, sizeof A);
+      A.quant = wq; A.b0 = std::max(1, c.block_size[0]); A.b1 = std::max(1, c.block_size[1]);
+      A.twv = m->plans[m->lp_wv_b[l]].t[0];
+      A.a.q_rope = m->q_rope; A.a.q_c = m->q_c; A.a.kv_a = m->kv_a; A.a.nope_cache = L.nope_cache; A.a.rope_cache = L.rope_cache;
+      A.a.out = m->att_out; A.a.n_heads = H; A.a.head_dim = m->head_dim; A.a.rope = c.qk_rope_head_dim; A.a.lora = c.kv_lora_rank;
+      A.a.is_v3 = c.has_moegate_bias;
+      A.fin.out = m->vb_out; A.fin.v_dim = c.v_head_dim; A.fin.n_heads = H; A.fin.q_counter = m->att_counter;
+      if (kq) { A.fin.q_qs = m->a_att.qs; A.fin.q_d = m->a_att.d; A.fin.q_bsums = m->a_att.bsums; }
+      DSK_TRY(mla_head_plan(A));
+      m->mla_head[l] = A;
+      m->head_attn_bytes[l] = h.algo_bytes;
     }
     {  // 6. wo, x += .
       GemvLaunch h;
@@ -380,21 +393,17 @@ static int attention_mla(dsk_model* m, int l, int max_kv) {
   hipStream_t st = m->ctx->stream;
   const int H = c.n_heads;
   DSK_TRY(run_plan(m, "gemv_qkv_a", m->lp_qkv_a[l]));
-  {  // rmsnorm of the latent (src/infer.cpp:1089); the rope part of kv_a stays raw for rope_kv
-    NormJob j;
-    memset(&j, 0, sizeof j);
-    j.x = m->kv_a; j.weight = reinterpret_cast<const float*>(L.t[DSK_ROLE_KV_A_NORM].qs); j.n = c.kv_lora_rank; j.eps = c.norm_eps;
-    j.y_f32 = m->kv_a;
-    PROFILED("norm_latent", (double)c.kv_lora_rank * 12, launch_norm_jobs(st, &j, 1, m->sp_dev));
-  }
   DSK_TRY(run_plan(m, "gemv_qkv_b", m->lp_qkv_b[l]));
-  AttnMlaArgs a;
-  a.q_rope = m->q_rope; a.q_c = m->q_c; a.kv_a = m->kv_a; a.nope_cache = L.nope_cache; a.rope_cache = L.rope_cache; a.out = m->att_out;
-  a.n_heads = H; a.head_dim = m->head_dim; a.rope = c.qk_rope_head_dim; a.lora = c.kv_lora_rank; a.is_v3 = c.has_moegate_bias;
-  PROFILED("rope_kv", (double)H * c.qk_rope_head_dim * 8 + c.kv_lora_rank * 6, launch_rope_kv_mla(st, a, m->sp_dev));
-  PROFILED("attn_mla", (double)m->sp_host->kv_len * (c.kv_lora_rank + c.qk_rope_head_dim) * 2, launch_attn_mla(st, a, m->sp_dev, 0, max_kv));
-  DSK_TRY(run_plan(m, "gemv_wv_b", m->lp_wv_b[l]));  // per-head wv_b (src/infer.cpp:1134-1137)
-  DSK_TRY(run_quant(m, m->vb_out, H * c.v_head_dim, m->a_att));
+  {  // latent norm + this position's cache entries + sink rotation: one small workgroup (src/infer.cpp:1089-1110)
+    MlaKvArgs kv;
+    kv.kv_a = m->kv_a; kv.norm_w = reinterpret_cast<const float*>(L.t[DSK_ROLE_KV_A_NORM].qs); kv.eps = c.norm_eps;
+    kv.nope_cache = L.nope_cache; kv.rope_cache = L.rope_cache; kv.lora = c.kv_lora_rank; kv.rope = c.qk_rope_head_dim;
+    kv.is_v3 = c.has_moegate_bias;
+    PROFILED("rope_kv", (double)c.kv_lora_rank * 14 + c.qk_rope_head_dim * 6, launch_mla_kv_write(st, kv, m->sp_dev));
+  }
+  // q rope + attention over the shared latent cache + per-head wv_b + Q8_K of the outputs: one launch
+  PROFILED("attn_mla", m->head_attn_bytes[l] + (double)m->sp_host->kv_len * (c.kv_lora_rank + c.qk_rope_head_dim) * 2 + (double)H * c.v_head_dim * 9,
+           launch_mla_head(st, m->mla_head[l], m->sp_dev, max_kv));
   DSK_TRY(run_plan(m, "gemv_wo", m->lp_wo[l]));
   return DSK_OK;
 }

@@ -977,6 +977,210 @@ int launch_head_attn(hipStream_t st, const HeadAttnArgs& A, const StepParams* sp
 }
 
 // ------------------------------------------------------------------------------------
+// MLA attention, per head (src/infer.cpp:1072-1141, attn_mla :766-804): one 16-wave workgroup rotates q_rope,
+// scores the shared latent cache (every head reads the same (kv_len x 576) f16 rows: L2 / Infinity-Cache hits),
+// softmax, mixes the latent values, applies the head's wv_b rows (128 x 512) and leaves the Q8_K copy for wo.
+// ------------------------------------------------------------------------------------
+template <int QT>
+__global__ __launch_bounds__(1024) void mla_head_kernel(const MlaHeadArgs A, const StepParams* __restrict__ sp) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ float scratch[16];
+  __shared__ __attribute__((aligned(16))) float q_s[768];    // q_c | rotated q_rope
+  __shared__ __attribute__((aligned(16))) float o_s[512];    // latent output of this head
+  __shared__ __attribute__((aligned(16))) float out_s[256];  // wv_b rows of this head
+  __shared__ __attribute__((aligned(16))) float part[4096];
+  __shared__ int last_flag;
+  constexpr bool KQ = QT == DSK_QUANT_Q2_K || QT == DSK_QUANT_Q3_K;
+  constexpr int NT = 1024, NW = 16;
+  typedef ad::f16x4 h4;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int grp = lane >> 4, sl = lane & 15;
+  const int h = blockIdx.x;
+  const AttnMlaArgs& a = A.a;
+  const int lora = a.lora, rope = a.rope, kv_len = sp->kv_len;
+  uint8_t* act = smem;
+  float* att = reinterpret_cast<float*>(smem + A.lds_act);
+  // ---- q: latent part as is, rope part rotated (src/infer.cpp:1075-1084) ----
+  for (int i = tid; i < lora; i += NT) q_s[i] = a.q_c[(size_t)h * lora + i];
+  if (tid < rope / 2) {
+    const float* qr = a.q_rope + (size_t)h * rope;
+    const float v0 = qr[2 * tid], v1 = qr[2 * tid + 1];
+    const float c = sp->rope_cs[2 * tid], s = sp->rope_cs[2 * tid + 1];
+    const float re = v0 * c - v1 * s, im = v0 * s + v1 * c;
+    if (a.is_v3) {
+      q_s[lora + 2 * tid] = re;
+      q_s[lora + 2 * tid + 1] = im;
+    } else {
+      q_s[lora + tid] = re;
+      q_s[lora + tid + rope / 2] = im;
+    }
+  }
+  __syncthreads();
+  // ---- scores: 16 lanes per position, 2 positions per group and step ----
+  const int nj = lora >> 6;  // f16x4 loads per lane for the latent part (8 for lora 512)
+  float qv[8][4], qr4[4];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qv[j][i] = j < nj ? q_s[64 * j + sl * 4 + i] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) qr4[i] = sl * 4 + i < rope ? q_s[lora + sl * 4 + i] : 0.f;
+  const float inv = sqrtf((float)a.head_dim);
+  for (int t0 = wave * 8; t0 < kv_len; t0 += NW * 8) {
+    h4 kc[2][8], kr[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int t = t0 + u * 4 + grp;
+      if (t < kv_len) {
+        const uint16_t* c = a.nope_cache + (size_t)t * lora;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j < nj) kc[u][j] = *reinterpret_cast<const h4*>(c + 64 * j + sl * 4);
+        if (sl * 4 < rope) kr[u] = *reinterpret_cast<const h4*>(a.rope_cache + (size_t)t * rope + sl * 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int t = t0 + u * 4 + grp;
+      float p = 0.f;
+      if (t < kv_len) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j < nj) {
+            p = fmaf(qv[j][0], (float)kc[u][j].x, p);
+            p = fmaf(qv[j][1], (float)kc[u][j].y, p);
+            p = fmaf(qv[j][2], (float)kc[u][j].z, p);
+            p = fmaf(qv[j][3], (float)kc[u][j].w, p);
+          }
+        if (sl * 4 < rope) {
+          p = fmaf(qr4[0], (float)kr[u].x, p);
+          p = fmaf(qr4[1], (float)kr[u].y, p);
+          p = fmaf(qr4[2], (float)kr[u].z, p);
+          p = fmaf(qr4[3], (float)kr[u].w, p);
+        }
+      }
+      p = ad::row16_sum(p);
+      if (sl == 0 && t < kv_len) att[t] = p / inv;
+    }
+  }
+  __syncthreads();
+  // ---- softmax (src/infer.cpp:472-487) ----
+  float mx = -INFINITY;
+  for (int t = tid; t < kv_len; t += NT) mx = fmaxf(mx, att[t]);
+  mx = ad::block_max(mx, scratch, tid, NT);
+  float sum = 0.f;
+  for (int t = tid; t < kv_len; t += NT) {
+    const float e = expf(att[t] - mx);
+    att[t] = e;
+    sum += e;
+  }
+  sum = ad::block_sum(sum, scratch, tid, NT);
+  for (int t = tid; t < kv_len; t += NT) att[t] = att[t] / sum;
+  __syncthreads();
+  // ---- latent values: lora / 4 threads per position, NT / (lora / 4) positions in flight, 4 rows per thread ----
+  {
+    const int tpp = lora >> 2, TG = NT / tpp;
+    const int g = tid / tpp, i4 = tid - g * tpp;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g < TG) {
+      for (int t0 = g; t0 < kv_len; t0 += 4 * TG) {
+        h4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (t0 + k * TG < kv_len) v[k] = *reinterpret_cast<const h4*>(a.nope_cache + (size_t)(t0 + k * TG) * lora + i4 * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (t0 + k * TG < kv_len) {
+            const float w = att[t0 + k * TG];
+            acc[0] = fmaf(w, (float)v[k].x, acc[0]);
+            acc[1] = fmaf(w, (float)v[k].y, acc[1]);
+            acc[2] = fmaf(w, (float)v[k].z, acc[2]);
+            acc[3] = fmaf(w, (float)v[k].w, acc[3]);
+          }
+      }
+      *reinterpret_cast<f32x4*>(part + (size_t)g * lora + i4 * 4) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    }
+    __syncthreads();
+    if (tid < lora) {
+      float o = 0.f;
+      for (int gg = 0; gg < TG; ++gg) o += part[gg * lora + tid];
+      o_s[tid] = o;
+    }
+    __syncthreads();
+  }
+  // ---- this head's wv_b rows on the latent output (src/infer.cpp:1134-1137) ----
+  const int vd = A.fin.v_dim;
+  if constexpr (KQ) {
+    if (wave < (lora >> 8)) {  // Q8_K of o_s: one 256-block per wave
+      float v[4] = {o_s[wave * 256 + lane * 4], o_s[wave * 256 + lane * 4 + 1], o_s[wave * 256 + lane * 4 + 2], o_s[wave * 256 + lane * 4 + 3]};
+      q8k_block_lds<QT == DSK_QUANT_Q2_K>(v, lane, act + (size_t)wave * 4 * ITEM_LDS);
+    }
+  } else {
+    for (int i = tid; i < lora; i += NT) reinterpret_cast<float*>(act)[i] = o_s[i];
+  }
+  __syncthreads();
+  {
+    const int lpr_log2 = A.lpr_log2, RPW = 64 >> lpr_log2;
+    const int rloc = lane >> lpr_log2, sub = lane & ((1 << lpr_log2) - 1);
+    const WPtr P = resolve(A.twv);
+    const KQRsrc B = kq_rsrc<QT, false>(P);
+    const int nb = lora >> 8, its = (nb * 4) >> lpr_log2;
+    for (int base = wave * RPW; base < vd; base += NW * RPW) {
+      const int lr = base + rloc;
+      const bool valid = lr < vd;
+      int row[1] = {h * vd + (valid ? lr : vd - 1)};
+      float acc[1], acc2[1];
+      if constexpr (KQ) {
+        int rowblk[1] = {row[0] * nb + (sub >> 2)};
+        rows_dot_kq<QT, 1, 4, false>(B, its, lpr_log2, sub & 3, rowblk, act + sub * ITEM_LDS, acc, acc2);
+      } else {
+        // reference indexing of the F8 block scales for this stack: expert_index = head (src/infer.cpp:437-438)
+        WPtr Ph = P;
+        if (Ph.scale) Ph.scale += (size_t)h * ((vd + A.b0 - 1) / A.b0) * ((lora + A.b1 - 1) / A.b1);
+        int lrow[1] = {valid ? lr : vd - 1};
+        Ph.qs += (size_t)h * vd * lora * FTraits<QT>::ESZ;
+        rows_dot_f<QT, 1, 4, false>(Ph, lora, A.b0, A.b1, lpr_log2, lane, lrow, act, acc, acc2);
+      }
+      if (sub == 0 && valid) out_s[lr] = acc[0];
+    }
+  }
+  __syncthreads();
+  ad::attn_out_q8(A.fin, h, tid, tid < vd ? out_s[tid] : 0.f, &last_flag);
+}
+
+int mla_head_plan(MlaHeadArgs& A) {
+  const bool kq = A.quant == DSK_QUANT_Q2_K || A.quant == DSK_QUANT_Q3_K;
+  if (A.a.lora > 512 || A.a.lora % 64 || A.a.rope > 64 || A.a.rope % 4 || A.fin.v_dim > 256)
+    DSK_FAIL(DSK_ERR_UNSUPPORTED, "mla: kv_lora_rank %d / rope %d / v_head_dim %d", A.a.lora, A.a.rope, A.fin.v_dim);
+  if (kq && A.a.lora % 256) DSK_FAIL(DSK_ERR_INVALID, "mla: kv_lora_rank %d is not a multiple of 256", A.a.lora);
+  if (A.fin.q_qs && (A.fin.n_heads * A.fin.v_dim) % 256) DSK_FAIL(DSK_ERR_INVALID, "mla: n_heads * v_head_dim = %d is not a multiple of 256", A.fin.n_heads * A.fin.v_dim);
+  A.lpr_log2 = head_lpr_log2(A.quant, A.a.lora);
+  A.lds_act = (int)(((kq ? (size_t)(A.a.lora / 64) * ITEM_LDS : (size_t)A.a.lora * 4) + 15) & ~(size_t)15);
+  if (A.b0 < 1) A.b0 = 1;
+  if (A.b1 < 1) A.b1 = 1;
+  return DSK_OK;
+}
+template <int QT>
+static int launch_mla_head_q(hipStream_t st, const MlaHeadArgs& A, const StepParams* sp, size_t lds) {
+  auto k = mla_head_kernel<QT>;
+  if (lds > 32 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k, dim3(A.a.n_heads), dim3(1024), lds, st, A, sp);
+  return DSK_OK;
+}
+int launch_mla_head(hipStream_t st, const MlaHeadArgs& A, const StepParams* sp, int max_kv) {
+  const size_t lds = (size_t)A.lds_act + (size_t)max_kv * 4;
+  if (lds > 100 * 1024) DSK_FAIL(DSK_ERR_UNSUPPORTED, "mla: kv_len %d does not fit LDS", max_kv);
+  switch (A.quant) {
+    case DSK_QUANT_F32: return launch_mla_head_q<DSK_QUANT_F32>(st, A, sp, lds);
+    case DSK_QUANT_F16: return launch_mla_head_q<DSK_QUANT_F16>(st, A, sp, lds);
+    case DSK_QUANT_F8E5M2: return launch_mla_head_q<DSK_QUANT_F8E5M2>(st, A, sp, lds);
+    case DSK_QUANT_Q2_K: return launch_mla_head_q<DSK_QUANT_Q2_K>(st, A, sp, lds);
+    case DSK_QUANT_Q3_K: return launch_mla_head_q<DSK_QUANT_Q3_K>(st, A, sp, lds);
+  }
+  DSK_FAIL(DSK_ERR_INVALID, "mla_head: bad quant %d", A.quant);
+}
+
+// ------------------------------------------------------------------------------------
 // host side: choose the launch geometry and fill the descriptor
 // ------------------------------------------------------------------------------------
 static int ilog2(int v) {
