@@ -254,6 +254,7 @@ int launch_rope_only(hipStream_t st, float* vec, int n_heads, int d, const float
 int launch_fill_tensor(hipStream_t st, const DTensor& t, uint64_t seed, float wscale);
 int launch_fill_f32(hipStream_t st, float* p, size_t n, uint64_t seed, float mean, float std);
 int launch_read_bw(hipStream_t st, const void* p, size_t bytes, float* sink);
+int launch_argmax(hipStream_t st, const float* x, int n, int* out);  // first maximum (strict >), src/sampler.cpp:28-39
 
 // ---- engine.cpp helpers shared with ops_api.cpp ----------------------------------
 struct dsk_ctx;

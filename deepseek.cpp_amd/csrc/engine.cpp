@@ -490,6 +490,8 @@ extern "C" int dsk_model_finalize(dsk_model* m) {
   HIP_TRY(hipHostMalloc((void**)&m->sp_host, sizeof(StepParams), hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void**)&m->logits_host, (size_t)c.vocab_size * 4, hipHostMallocDefault));
   memset(m->sp_host, 0, sizeof(StepParams));
+  HIP_TRY(hipMalloc((void**)&m->argmax_dev, 64));
+  HIP_TRY(hipHostMalloc((void**)&m->argmax_host, 64, hipHostMallocDefault));
   HIP_TRY(hipMalloc((void**)&m->router_counter, 64));
   HIP_TRY(hipMemset(m->router_counter, 0, 64));
   HIP_TRY(hipMalloc((void**)&m->att_counter, ((size_t)c.n_heads * c.v_head_dim / 256 + 2) * 4));
@@ -515,8 +517,10 @@ extern "C" int dsk_model_destroy(dsk_model* m) {
   if (!m) return DSK_OK;
   hipSetDevice(m->ctx->device);
   hipStreamSynchronize(m->ctx->stream);
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 3; ++i)
     if (m->graph[i]) hipGraphExecDestroy(m->graph[i]);
+  if (m->argmax_dev) hipFree(m->argmax_dev);
+  if (m->argmax_host) hipHostFree(m->argmax_host);
   for (int i = 0; i < 3; ++i)
     if (!(i == DSK_ROLE_OUTPUT && m->tied && m->finalized)) free_tensor(m->g[i]);
   for (auto& L : m->L) {

@@ -450,6 +450,7 @@ static int ffn(dsk_model* m, int l) {
   return DSK_OK;
 }
 
+enum { MODE_ARGMAX = 2 };  // internal: OUTPUT_LOGITS + device argmax (dsk_forward_argmax)
 // enqueue one whole token on the stream (no host synchronisation inside)
 static int enqueue_forward(dsk_model* m, int mode, int max_kv) {
   const dsk_config& c = m->c;
@@ -465,6 +466,11 @@ static int enqueue_forward(dsk_model* m, int mode, int max_kv) {
   }
   if (mode == DSK_MODE_HYDRATE_KV_CACHE) return DSK_OK;  // src/infer.cpp:1284-1287
   DSK_TRY(run_plan(m, "gemv_lm_head", m->lp_head));
+  if (mode == MODE_ARGMAX) {  // greedy step: the token id is all that leaves the device
+    PROFILED("argmax", (double)c.vocab_size * 4, launch_argmax(st, m->logits, c.vocab_size, m->argmax_dev));
+    if (!m->class_filter) HIP_TRY(hipMemcpyAsync(m->argmax_host, m->argmax_dev, 4, hipMemcpyDeviceToHost, st));
+    return DSK_OK;
+  }
   if (!m->class_filter) HIP_TRY(hipMemcpyAsync(m->logits_host, m->logits, (size_t)c.vocab_size * 4, hipMemcpyDeviceToHost, st));
   return DSK_OK;
 }
@@ -479,8 +485,7 @@ static int check_forward_args(dsk_model* m, int token, int pos, int mode, float*
   return DSK_OK;
 }
 
-extern "C" int dsk_forward(dsk_model* m, int token, int pos, int mode, float* host_logits) {
-  DSK_TRY(check_forward_args(m, token, pos, mode, host_logits));
+static int run_token(dsk_model* m, int token, int pos, int mode) {
   HIP_TRY(hipSetDevice(m->ctx->device));
   hipStream_t st = m->ctx->stream;
   DSK_TRY(fill_step_params(m, token, pos));
@@ -489,7 +494,7 @@ extern "C" int dsk_forward(dsk_model* m, int token, int pos, int mode, float* ho
   // launches is as fast as the graph replay (the host stays ~10 launches ahead), and it keeps RCCL's
   // lazily initialised collectives out of stream capture.
   const bool graphable = m->use_graph && !m->trace && !m->profiling && !m->ctx->comm;
-  const int gi = mode == DSK_MODE_OUTPUT_LOGITS ? 1 : 0;
+  const int gi = mode;  // 0 hydrate, 1 logits, 2 argmax
   if (graphable && !m->graph_primed[gi]) {
     m->graph_primed[gi] = true;  // first token of a mode runs eagerly (first-use initialisation), the second is captured
     DSK_TRY(enqueue_forward(m, mode, max_kv));
@@ -513,7 +518,21 @@ extern "C" int dsk_forward(dsk_model* m, int token, int pos, int mode, float* ho
   }
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipGetLastError());
+  return DSK_OK;
+}
+
+extern "C" int dsk_forward(dsk_model* m, int token, int pos, int mode, float* host_logits) {
+  DSK_TRY(check_forward_args(m, token, pos, mode, host_logits));
+  DSK_TRY(run_token(m, token, pos, mode));
   if (mode == DSK_MODE_OUTPUT_LOGITS) memcpy(host_logits, m->logits_host, (size_t)m->c.vocab_size * 4);
+  return DSK_OK;
+}
+
+extern "C" int dsk_forward_argmax(dsk_model* m, int token, int pos, int32_t* next_token) {
+  DSK_TRY(check_forward_args(m, token, pos, DSK_MODE_OUTPUT_LOGITS, m ? m->logits_host : nullptr));
+  if (!next_token) DSK_FAIL(DSK_ERR_INVALID, "forward_argmax: null output");
+  DSK_TRY(run_token(m, token, pos, MODE_ARGMAX));
+  *next_token = *m->argmax_host;
   return DSK_OK;
 }
 

@@ -114,6 +114,37 @@ int launch_moe_combine(hipStream_t st, float* x, const float* eout, const float*
   return DSK_OK;
 }
 
+// argmax with Sampler::sample_argmax's tie rule: the lowest index among equal maxima (src/sampler.cpp:28-39;
+// -FLT_MAX start value: a vector of NaNs / -inf yields index 0 like the reference)
+__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ x, int n, int* __restrict__ out) {
+  __shared__ float sv[16];
+  __shared__ int si[16];
+  const int tid = threadIdx.x;
+  float best = -3.402823466e+38f;
+  int bi = 0x7fffffff;
+  for (int i = tid; i < n; i += 1024) {
+    const float v = x[i];
+    if (v > best) { best = v; bi = i; }  // ascending i per thread: strict > keeps the first
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float ov = __shfl_xor(best, off);
+    const int oi = __shfl_xor(bi, off);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if ((tid & 63) == 0) { sv[tid >> 6] = best; si[tid >> 6] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 16; ++w)
+      if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+    *out = bi == 0x7fffffff ? 0 : bi;
+  }
+}
+int launch_argmax(hipStream_t st, const float* x, int n, int* out) {
+  hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, st, x, n, out);
+  return DSK_OK;
+}
+
 int launch_quantize_q8k(hipStream_t st, const float* x, int n, int8_t* qs, float* d, int16_t* bsums) {
   if (n <= 0 || n % 256) DSK_FAIL(DSK_ERR_INVALID, "q8k: n=%d must be a positive multiple of 256", n);
   const int nb = n / 256;

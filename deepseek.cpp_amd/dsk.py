@@ -103,6 +103,7 @@ def lib():
         L.dsk_model_set_graph.argtypes = [C.c_void_p, C.c_int]
         L.dsk_model_set_trace.argtypes = [C.c_void_p, C.c_int]
         L.dsk_model_get_trace_x.argtypes = [C.c_void_p, C.c_int, c_f]
+        L.dsk_forward_argmax.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32)]
         L.dsk_model_get_routing.argtypes = [C.c_void_p, c_i32, c_f]
         L.dsk_model_get_slot_outputs.argtypes = [C.c_void_p, c_f]
         L.dsk_profile_forward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(KernelTime), C.c_int, c_i32]
@@ -289,6 +290,11 @@ class Model:
         x = np.zeros(self.cfg.dim, np.float32)
         check(lib().dsk_model_get_trace_x(self.h, layer, _f(x)))
         return x
+
+    def forward_argmax(self, token: int, pos: int) -> int:
+        nxt = C.c_int32()
+        check(lib().dsk_forward_argmax(self.h, token, pos, C.byref(nxt)))
+        return nxt.value
 
     def routing(self):
         K = max(1, self.cfg.n_active_routed)

@@ -248,3 +248,20 @@ def test_expert_sharded_path_dry_run_on_one_gpu(quant):
         M.close()
     for x in ctxs:
         x.close()
+
+
+def test_forward_argmax_matches_host_argmax(ctx):
+    """dsk_forward_argmax = dsk_forward + Sampler::sample_argmax (first maximum), graph and eager."""
+    import dsk
+    for quant, mla in (("q2_k", False), ("fp16", True)):
+        c = synth.preset("tiny_v3", quant, mla)
+        T = synth.synth_model(c, seed=13)
+        A, B = dsk.Model(ctx, c, T), dsk.Model(ctx, c, T)
+        tok_a = tok_b = 17
+        for pos in range(6):  # first call eager, later ones replay the captured graph
+            lg = A.forward(tok_a, pos)
+            nxt = B.forward_argmax(tok_b, pos)
+            assert nxt == int(np.argmax(lg)), pos  # np.argmax also returns the first maximum
+            tok_a = tok_b = nxt
+        A.close()
+        B.close()
