@@ -127,6 +127,9 @@ struct GemvLaunch {
   double algo_bytes;          // host-side bookkeeping for the roofline report
 };
 
+// dsk_profile_forward: when both are set, the next GEMV launch records them as the kernel's OWN start / stop
+// (hipExtLaunchKernel: dispatch timestamps, no extra barrier packets), i.e. the duration rocprofv3 reports
+extern thread_local hipEvent_t g_prof_start, g_prof_stop;
 int gemv_plan(GemvLaunch& h, int target_wgs);
 int gemv_launch(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& host);
 

@@ -29,7 +29,7 @@ struct Prof {
   bool skip = false;
   hipEvent_t e0 = nullptr, e1 = nullptr;
 };
-static int prof_begin(dsk_model* m, const char* name, double bytes, Prof* p) {
+static int prof_begin(dsk_model* m, const char* name, double bytes, Prof* p, bool record_start = true) {
   p->m = m;
   if (m->class_filter) {  // dsk_time_kernel_class: only the launches of one class are enqueued
     p->skip = strcmp(name, m->class_filter) != 0;
@@ -51,7 +51,7 @@ static int prof_begin(dsk_model* m, const char* name, double bytes, Prof* p) {
   k.algo_bytes += bytes;
   HIP_TRY(hipEventCreate(&p->e0));
   HIP_TRY(hipEventCreate(&p->e1));
-  HIP_TRY(hipEventRecord(p->e0, m->ctx->stream));
+  if (record_start) HIP_TRY(hipEventRecord(p->e0, m->ctx->stream));
   return DSK_OK;
 }
 static int prof_end(Prof* p) {
@@ -336,6 +336,17 @@ void free_plans(dsk_model* m) {
 
 static int run_plan(dsk_model* m, const char* name, int idx) {
   if (idx < 0) DSK_FAIL(DSK_ERR_STATE, "missing launch plan for %s", name);
+  if (m->profiling && !m->class_filter) {
+    // the kernel's own dispatch timestamps (hipExtLaunchKernel): in-situ duration, as rocprofv3 reports it
+    Prof p;
+    DSK_TRY(prof_begin(m, name, m->plans[idx].algo_bytes, &p, false));
+    g_prof_start = p.e0; g_prof_stop = p.e1;
+    int r = gemv_launch(m->ctx->stream, m->plans_dev + idx, m->plans[idx]);
+    g_prof_start = g_prof_stop = nullptr;
+    DSK_TRY(r);
+    m->ktimes[p.idx].ev.push_back({p.e0, p.e1});
+    return DSK_OK;
+  }
   PROFILED(name, m->plans[idx].algo_bytes, gemv_launch(m->ctx->stream, m->plans_dev + idx, m->plans[idx]));
   return DSK_OK;
 }
@@ -489,7 +500,8 @@ static int run_token(dsk_model* m, int token, int pos, int mode) {
   HIP_TRY(hipSetDevice(m->ctx->device));
   hipStream_t st = m->ctx->stream;
   DSK_TRY(fill_step_params(m, token, pos));
-  const int max_kv = m->c.max_seq_len;  // LDS for attention scores is sized for the allocation: graph-replay safe
+  // LDS for attention scores is sized once (graph-replay safe): kv_len never exceeds the ring W nor the allocation
+  const int max_kv = std::min(m->c.max_seq_len, std::max(1, m->c.rs_original_max_position_embeddings));
   // A sharded model (real communicator) is enqueued eagerly: measured on MI355X an eager stream of these
   // launches is as fast as the graph replay (the host stays ~10 launches ahead), and it keeps RCCL's
   // lazily initialised collectives out of stream capture.
@@ -580,7 +592,7 @@ extern "C" int dsk_profile_forward(dsk_model* m, int token, int pos, dsk_kernel_
   DSK_TRY(fill_step_params(m, token, pos));
   for (auto& k : m->ktimes) { k.launches = 0; k.algo_bytes = 0; }
   m->profiling = true;
-  int r = enqueue_forward(m, DSK_MODE_OUTPUT_LOGITS, m->c.max_seq_len);
+  int r = enqueue_forward(m, DSK_MODE_OUTPUT_LOGITS, std::min(m->c.max_seq_len, std::max(1, m->c.rs_original_max_position_embeddings)));
   m->profiling = false;
   if (r != DSK_OK) return r;
   HIP_TRY(hipStreamSynchronize(m->ctx->stream));
@@ -627,11 +639,11 @@ extern "C" int dsk_time_kernel_class(dsk_model* m, const char* name, int pos, in
   m->class_filter = name;
   m->class_launches = 0;
   m->class_bytes = 0;
-  int r = enqueue_forward(m, DSK_MODE_OUTPUT_LOGITS, m->c.max_seq_len);  // warm-up pass (also counts the launches)
+  int r = enqueue_forward(m, DSK_MODE_OUTPUT_LOGITS, std::min(m->c.max_seq_len, std::max(1, m->c.rs_original_max_position_embeddings)));  // warm-up pass (also counts the launches)
   const int per_token = m->class_launches;
   const double bytes = m->class_bytes;
   if (r == DSK_OK) r = hipEventRecord(e0, st) == hipSuccess ? DSK_OK : DSK_ERR_HIP;
-  for (int i = 0; i < reps && r == DSK_OK; ++i) r = enqueue_forward(m, DSK_MODE_OUTPUT_LOGITS, m->c.max_seq_len);
+  for (int i = 0; i < reps && r == DSK_OK; ++i) r = enqueue_forward(m, DSK_MODE_OUTPUT_LOGITS, std::min(m->c.max_seq_len, std::max(1, m->c.rs_original_max_position_embeddings)));
   m->class_filter = nullptr;
   if (r == DSK_OK) r = hipEventRecord(e1, st) == hipSuccess ? DSK_OK : DSK_ERR_HIP;
   if (r == DSK_OK) r = hipEventSynchronize(e1) == hipSuccess ? DSK_OK : DSK_ERR_HIP;

@@ -26,6 +26,7 @@
 #include "dsk_internal.h"
 #include "attn_device.h"
 #include <type_traits>
+#include <hip/hip_ext.h>
 
 typedef unsigned int u32;
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
@@ -1189,17 +1190,21 @@ static int ilog2(int v) {
   return l;
 }
 
+thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
+
 template <int QT, int R, int U, int NW>
 static void launch_one(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& h) {
   dim3 grid(h.grid), block(NW * 64);
   if (h.glu) {
     auto k = gemv_kernel<QT, R, U, true, NW>;
     if (h.lds_bytes > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds_bytes);
-    hipLaunchKernelGGL(k, grid, block, h.lds_bytes, st, dev);
+    if (g_prof_start && g_prof_stop) hipExtLaunchKernelGGL(k, grid, block, (uint32_t)h.lds_bytes, st, g_prof_start, g_prof_stop, 0u, dev);
+    else hipLaunchKernelGGL(k, grid, block, h.lds_bytes, st, dev);
   } else {
     auto k = gemv_kernel<QT, R, U, false, NW>;
     if (h.lds_bytes > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds_bytes);
-    hipLaunchKernelGGL(k, grid, block, h.lds_bytes, st, dev);
+    if (g_prof_start && g_prof_stop) hipExtLaunchKernelGGL(k, grid, block, (uint32_t)h.lds_bytes, st, g_prof_start, g_prof_stop, 0u, dev);
+    else hipLaunchKernelGGL(k, grid, block, h.lds_bytes, st, dev);
   }
 }
 template <int QT, int NW>
