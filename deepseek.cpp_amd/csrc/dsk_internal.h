@@ -233,6 +233,23 @@ struct AttnMlaArgs {
   int n_heads, head_dim, rope, lora, is_v3;
 };
 int launch_rope_kv_mla(hipStream_t st, const AttnMlaArgs& a, const StepParams* sp);
+// MLA attention for LONG contexts on the matrix cores (kernels_misc.hip mla_flash_kernel): all heads share one latent
+// cache, so scores = Q[H x 576] . C^T and out = P . C are GEMMs.  Workgroup (chunk, head group of 32) walks its
+// chunk of positions 32 at a time with exact-f32 MFMA (v_mfma_f32_32x32x2_f32: an fma chain, K/V are f16-exact) and
+// an online softmax, and leaves (m, l, O) partials; they are merged per head by mla_head_kernel / mla_merge_kernel.
+struct MlaFlashArgs {
+  const float* q_c;          // (H, lora)
+  const float* q_rope;       // (H, rope)
+  int rotate_q;              // 1: q_rope is un-rotated, apply sp->rope_cs (model path)
+  const uint16_t* nope_cache;
+  const uint16_t* rope_cache;
+  float* part_o;             // (n_chunks, H, lora)
+  float* part_ml;            // (n_chunks, H, 2): running max, running sum
+  int n_heads, head_dim, lora, rope, is_v3;
+  int chunk_len, n_chunks;   // positions per chunk (multiple of 32), chunks in the grid
+};
+int launch_mla_flash(hipStream_t st, const MlaFlashArgs& a, const StepParams* sp, int kv_len_override);
+int launch_mla_merge(hipStream_t st, const MlaFlashArgs& a, const StepParams* sp, int kv_len_override, float* out);
 // MLA, model path: (1) one workgroup normalises the latent, writes this position's cache entries and rotates the
 // sink keys; (2) one 16-wave workgroup per head: RoPE of q_rope, attention over the shared latent cache, the head's
 // wv_b rows, Q8_K of the concatenated outputs (kernels_gemv.hip mla_head_kernel).
@@ -249,6 +266,10 @@ struct MlaHeadArgs {
   GemvTask twv;           // the (H * v_head_dim, lora) stack; the kernel takes rows [h * v, +v)
   int quant, b0, b1, lpr_log2, lds_act;
   AttnMhaArgs fin;        // out (H, v), v_dim, n_heads, Q8_K outputs + counter (only these fields are used)
+  // long contexts: kv_len >= flash_thresh (> 0) => the attention part is the merge of mla_flash_kernel's partials
+  int flash_thresh, fl_chunk_len, fl_n_chunks;
+  const float* fl_part_o;
+  const float* fl_part_ml;
 };
 int mla_head_plan(MlaHeadArgs& A);
 int launch_mla_head(hipStream_t st, const MlaHeadArgs& A, const StepParams* sp, int max_kv);

@@ -490,6 +490,11 @@ extern "C" int dsk_model_finalize(dsk_model* m) {
   HIP_TRY(hipHostMalloc((void**)&m->sp_host, sizeof(StepParams), hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void**)&m->logits_host, (size_t)c.vocab_size * 4, hipHostMallocDefault));
   memset(m->sp_host, 0, sizeof(StepParams));
+  if (c.use_mla && c.kv_lora_rank == 512 && c.qk_rope_head_dim == 64) {  // long-context MLA on the matrix cores
+    HIP_TRY(hipMalloc((void**)&m->fl_part_o, (size_t)64 * c.n_heads * c.kv_lora_rank * 4));
+    HIP_TRY(hipMalloc((void**)&m->fl_part_ml, (size_t)64 * c.n_heads * 8));
+    m->scratch_bytes += (double)64 * c.n_heads * (c.kv_lora_rank * 4 + 8);
+  }
   HIP_TRY(hipMalloc((void**)&m->argmax_dev, 64));
   HIP_TRY(hipHostMalloc((void**)&m->argmax_host, 64, hipHostMallocDefault));
   HIP_TRY(hipMalloc((void**)&m->router_counter, 64));
@@ -517,8 +522,10 @@ extern "C" int dsk_model_destroy(dsk_model* m) {
   if (!m) return DSK_OK;
   hipSetDevice(m->ctx->device);
   hipStreamSynchronize(m->ctx->stream);
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < 6; ++i)
     if (m->graph[i]) hipGraphExecDestroy(m->graph[i]);
+  if (m->fl_part_o) hipFree(m->fl_part_o);
+  if (m->fl_part_ml) hipFree(m->fl_part_ml);
   if (m->argmax_dev) hipFree(m->argmax_dev);
   if (m->argmax_host) hipHostFree(m->argmax_host);
   for (int i = 0; i < 3; ++i)

@@ -130,6 +130,11 @@ int build_plans(dsk_model* m) {
   m->plans.clear();
   m->head_attn.assign(nl, HeadAttnArgs());
   m->mla_head.assign(nl, MlaHeadArgs());
+  {
+    MlaFlashArgs z;
+    memset(&z, 0, sizeof z);
+    m->mla_flash.assign(nl, z);
+  }
   m->head_attn_bytes.assign(nl, 0.0);
   for (int l = 0; l < nl; ++l) {
     Layer& L = m->L[l];
@@ -211,6 +216,16 @@ int build_plans(dsk_model* m) {
       A.a.is_v3 = c.has_moegate_bias;
       A.fin.out = m->vb_out; A.fin.v_dim = c.v_head_dim; A.fin.n_heads = H; A.fin.q_counter = m->att_counter;
       if (kq) { A.fin.q_qs = m->a_att.qs; A.fin.q_d = m->a_att.d; A.fin.q_bsums = m->a_att.bsums; }
+      if (m->fl_part_o) {  // kv_len >= 512: scores / values of all heads on the matrix cores, merged per head here
+        const int max_kv = std::min(c.max_seq_len, std::max(1, c.rs_original_max_position_embeddings));
+        MlaFlashArgs F;
+        memset(&F, 0, sizeof F);
+        F.q_c = m->q_c; F.q_rope = m->q_rope; F.rotate_q = 1; F.nope_cache = L.nope_cache; F.rope_cache = L.rope_cache;
+        F.part_o = m->fl_part_o; F.part_ml = m->fl_part_ml; F.n_heads = H; F.head_dim = m->head_dim; F.lora = c.kv_lora_rank;
+        F.rope = c.qk_rope_head_dim; F.is_v3 = c.has_moegate_bias; F.n_chunks = 64; F.chunk_len = ((max_kv + 63) / 64 + 31) / 32 * 32;
+        m->mla_flash[l] = F;
+        A.flash_thresh = 512; A.fl_chunk_len = F.chunk_len; A.fl_n_chunks = F.n_chunks; A.fl_part_o = F.part_o; A.fl_part_ml = F.part_ml;
+      }
       DSK_TRY(mla_head_plan(A));
       m->mla_head[l] = A;
       m->head_attn_bytes[l] = h.algo_bytes;
@@ -412,6 +427,8 @@ static int attention_mla(dsk_model* m, int l, int max_kv) {
     kv.is_v3 = c.has_moegate_bias;
     PROFILED("rope_kv", (double)c.kv_lora_rank * 14 + c.qk_rope_head_dim * 6, launch_mla_kv_write(st, kv, m->sp_dev));
   }
+  if (m->mla_flash[l].part_o && m->sp_host->kv_len >= 512)  // long-context regime (its own graph: dsk_forward)
+    PROFILED("attn_mla_flash", (double)m->sp_host->kv_len * (c.kv_lora_rank + c.qk_rope_head_dim) * 2, launch_mla_flash(st, m->mla_flash[l], m->sp_dev, 0));
   // q rope + attention over the shared latent cache + per-head wv_b + Q8_K of the outputs: one launch
   PROFILED("attn_mla", m->head_attn_bytes[l] + (double)m->sp_host->kv_len * (c.kv_lora_rank + c.qk_rope_head_dim) * 2 + (double)H * c.v_head_dim * 9,
            launch_mla_head(st, m->mla_head[l], m->sp_dev, max_kv));
@@ -506,7 +523,9 @@ static int run_token(dsk_model* m, int token, int pos, int mode) {
   // launches is as fast as the graph replay (the host stays ~10 launches ahead), and it keeps RCCL's
   // lazily initialised collectives out of stream capture.
   const bool graphable = m->use_graph && !m->trace && !m->profiling && !m->ctx->comm;
-  const int gi = mode;  // 0 hydrate, 1 logits, 2 argmax
+  // the long-context MLA regime enqueues one more launch per block: its own captured graph
+  const bool long_mla = m->fl_part_o && m->sp_host->kv_len >= 512;
+  const int gi = mode + (long_mla ? 3 : 0);  // 0 hydrate, 1 logits, 2 argmax
   if (graphable && !m->graph_primed[gi]) {
     m->graph_primed[gi] = true;  // first token of a mode runs eagerly (first-use initialisation), the second is captured
     DSK_TRY(enqueue_forward(m, mode, max_kv));

@@ -1017,6 +1017,28 @@ __global__ __launch_bounds__(1024) void mla_head_kernel(const MlaHeadArgs A, con
     }
   }
   __syncthreads();
+  const bool merged = A.flash_thresh > 0 && kv_len >= A.flash_thresh;  // uniform: mla_flash_kernel ran before us
+  if (merged) {
+    // out = sum_c e^(m_c - M) O_c / sum_c e^(m_c - M) l_c over the chunk partials of this head
+    const int nc = min(A.fl_n_chunks, (kv_len + A.fl_chunk_len - 1) / A.fl_chunk_len);
+    const int H = a.n_heads;
+    float* wc = part;  // per-chunk weights e^(m_c - M) / L, computed once
+    if (tid < 64) {
+      const float mc = tid < nc ? A.fl_part_ml[((size_t)tid * H + h) * 2] : -INFINITY;
+      const float lc = tid < nc ? A.fl_part_ml[((size_t)tid * H + h) * 2 + 1] : 0.f;
+      const float M = ad::wave_max_dpp(mc);
+      const float e = tid < nc ? expf(mc - M) : 0.f;
+      const float Lsum = ad::wave_sum_dpp(e * lc);
+      wc[tid] = e / Lsum;
+    }
+    __syncthreads();
+    if (tid < lora) {
+      float o = 0.f;
+      for (int c = 0; c < nc; ++c) o = fmaf(wc[c], A.fl_part_o[((size_t)c * H + h) * lora + tid], o);
+      o_s[tid] = o;
+    }
+    __syncthreads();
+  } else {
   // ---- scores: 16 lanes per position, 2 positions per group and step ----
   const int nj = lora >> 6;  // f16x4 loads per lane for the latent part (8 for lora 512)
   float qv[8][4], qr4[4];
@@ -1109,6 +1131,7 @@ __global__ __launch_bounds__(1024) void mla_head_kernel(const MlaHeadArgs A, con
     }
     __syncthreads();
   }
+  }  // !merged
   // ---- this head's wv_b rows on the latent output (src/infer.cpp:1134-1137) ----
   const int vd = A.fin.v_dim;
   if constexpr (KQ) {

@@ -928,6 +928,203 @@ int launch_mla_kv_write(hipStream_t st, const MlaKvArgs& a, const StepParams* sp
   return DSK_OK;
 }
 
+// ------------------------------------------------------------------------------------
+// MLA attention on the matrix cores (long contexts).  See MlaFlashArgs in dsk_internal.h.
+// v_mfma_f32_32x32x2_f32: A one f32 per lane A[i = l&31][k = l>>5], B one f32 per lane B[k = l>>5][j = l&31],
+// C/D 16 f32 per lane: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+// ------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define FL_KSTRIDE 580   // halfs per staged cache row (576 + 4): 290 dwords, odd multiple of 2 -> conflict-free column reads
+#define FL_PSTRIDE 33
+
+// 8 waves per workgroup: the K range of the score GEMM and the latent columns of the value GEMM are split 8 ways, so a
+// wave issues 36 + 32 MFMAs per 32-position block and two waves share a SIMD.  All B operands of a block are read
+// from LDS into registers BEFORE the MFMA chain (a dependent ds_read -> cvt -> mfma per step tripled the time).
+#define FL_NWV 8
+__global__ __launch_bounds__(FL_NWV * 64) void mla_flash_kernel(MlaFlashArgs a, const StepParams* __restrict__ sp, int kv_len_override) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t fl_smem[];
+  unsigned short* Ks = reinterpret_cast<unsigned short*>(fl_smem);                                   // [32][FL_KSTRIDE]
+  float (*Sp)[32][FL_PSTRIDE] = reinterpret_cast<float (*)[32][FL_PSTRIDE]>(fl_smem + 32 * FL_KSTRIDE * 2);  // [FL_NWV][32][33]
+  float (*Pm)[FL_PSTRIDE] = reinterpret_cast<float (*)[FL_PSTRIDE]>(fl_smem + 32 * FL_KSTRIDE * 2 + FL_NWV * 32 * FL_PSTRIDE * 4);
+  __shared__ float m_s[32], l_s[32], al_s[32];
+  const int kv_len = kv_len_override > 0 ? kv_len_override : sp->kv_len;
+  const int p0 = blockIdx.x * a.chunk_len;
+  if (p0 >= kv_len) return;
+  const int p1 = min(kv_len, p0 + a.chunk_len);
+  const int hg = blockIdx.y, tid = threadIdx.x, w = tid >> 6, l = tid & 63, i = l & 31, kh = l >> 5;
+  const int lora = a.lora, rope = a.rope, KT = lora + rope;  // 576
+  const int head = hg * 32 + i;
+  const bool hv = head < a.n_heads;
+  // ---- this wave's eighth of the K range of Q, one value per (MFMA step, lane): k = 2*(ks0 + s) + kh ----
+  constexpr int steps = 288 / FL_NWV;  // k-pairs per wave: (512 + 64) / 2 / 8 (launch_mla_flash admits only these dims)
+  const int ks0 = w * steps;
+  float qa[steps];
+#pragma unroll
+  for (int s = 0; s < steps; ++s) {
+    float v = 0.f;
+    if (hv) {
+      const int k = 2 * (ks0 + s) + kh;
+      if (k < lora) {
+        v = a.q_c[(size_t)head * lora + k];
+      } else {
+        const int kr = k - lora;
+        const float* qr = a.q_rope + (size_t)head * rope;
+        if (!a.rotate_q) {
+          v = qr[kr];
+        } else {  // rope (V2: de-interleaving) src/infer.cpp:648-668; rope_v3 :670-685
+          const int j = a.is_v3 ? kr >> 1 : (kr < rope / 2 ? kr : kr - rope / 2);
+          const bool im = a.is_v3 ? (kr & 1) : (kr >= rope / 2);
+          const float v0 = qr[2 * j], v1 = qr[2 * j + 1];
+          const float c = sp->rope_cs[2 * j], sn = sp->rope_cs[2 * j + 1];
+          v = im ? v0 * sn + v1 * c : v0 * c - v1 * sn;
+        }
+      }
+    }
+    qa[s] = v;
+  }
+  constexpr int NTO = 2;  // 32-column output tiles per wave: 512 / 8 / 32
+  f32x16 oacc[NTO];
+#pragma unroll
+  for (int t = 0; t < NTO; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+  if (tid < 32) { m_s[tid] = -INFINITY; l_s[tid] = 0.f; }
+  const float inv = sqrtf((float)a.head_dim);
+  for (int b0 = p0; b0 < p1; b0 += 32) {
+    const int nvalid = min(32, p1 - b0);
+    // ---- stage 32 cache rows (latent | rope) as f16, 8 bytes per store; rows past nvalid are zero ----
+    {
+      const int per_row = KT / 4;  // 8-byte chunks per row (144)
+      for (int c = tid; c < 32 * per_row; c += FL_NWV * 64) {
+        const int r = c / per_row, cc = c - r * per_row;
+        uint2 v = {0u, 0u};
+        if (r < nvalid) {
+          const int k = cc * 4;
+          if (k < lora) v = *reinterpret_cast<const uint2*>(a.nope_cache + (size_t)(b0 + r) * lora + k);
+          else v = *reinterpret_cast<const uint2*>(a.rope_cache + (size_t)(b0 + r) * rope + (k - lora));
+        }
+        *reinterpret_cast<uint2*>(Ks + r * FL_KSTRIDE + cc * 4) = v;
+      }
+    }
+    __syncthreads();
+    // ---- partial scores of this wave's K range: S[head][pos] ----
+    uint2 kk[steps / 2];  // 4 halfs (2 steps) per 8-byte LDS read
+    const unsigned short* krow = Ks + i * FL_KSTRIDE + 2 * ks0;
+#pragma unroll
+    for (int s2 = 0; s2 < steps / 2; ++s2) kk[s2] = *reinterpret_cast<const uint2*>(krow + 4 * s2);
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < steps / 2; ++s2) {
+      const float b0v = h2f((unsigned short)(kh ? kk[s2].x >> 16 : kk[s2].x & 0xffff));
+      const float b1v = h2f((unsigned short)(kh ? kk[s2].y >> 16 : kk[s2].y & 0xffff));
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[2 * s2], b0v, sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[2 * s2 + 1], b1v, sacc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Sp[w][(r & 3) + 8 * (r >> 2) + 4 * kh][i] = sacc[r];
+    // value operands of this wave for the whole block: requested now, consumed after the softmax
+    unsigned short vv[16][NTO];
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+      for (int t = 0; t < NTO; ++t) vv[s][t] = Ks[(2 * s + kh) * FL_KSTRIDE + w * (NTO * 32) + t * 32 + i];
+    __syncthreads();
+    // ---- sum the partial tiles in wave order, online softmax per head row: threads 0..255 -> (row, 4 columns) ----
+    if (tid < 256) {
+      const int r = tid >> 3, c4 = (tid & 7) * 4;
+      float sv[4], mx = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float acc = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < FL_NWV; ++ww) acc += Sp[ww][r][c4 + j];
+        sv[j] = acc / inv;
+        if (c4 + j >= nvalid) sv[j] = -INFINITY;
+        mx = fmaxf(mx, sv[j]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 1));
+      mx = fmaxf(mx, __shfl_xor(mx, 2));
+      mx = fmaxf(mx, __shfl_xor(mx, 4));
+      const float m_old = m_s[r], m_new = fmaxf(m_old, mx);
+      float ps = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float pv = c4 + j < nvalid ? expf(sv[j] - m_new) : 0.f;
+        Pm[r][c4 + j] = pv;
+        ps += pv;
+      }
+      ps += __shfl_xor(ps, 1);
+      ps += __shfl_xor(ps, 2);
+      ps += __shfl_xor(ps, 4);
+      // the 8 threads of a row are lanes of ONE wave: every read of m_s[r] / l_s[r] above precedes this write
+      if ((tid & 7) == 0) {
+        al_s[r] = m_old == -INFINITY ? 0.f : expf(m_old - m_new);
+        l_s[r] = l_s[r] * al_s[r] + ps;
+        m_s[r] = m_new;
+      }
+    }
+    __syncthreads();
+    // ---- O = O * alpha + P . V for this wave's 64 latent columns ----
+    float pa[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) pa[s] = Pm[i][2 * s + kh];
+#pragma unroll
+    for (int t = 0; t < NTO; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[t][r] *= al_s[(r & 3) + 8 * (r >> 2) + 4 * kh];
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+      for (int t = 0; t < NTO; ++t) oacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[s], h2f(vv[s][t]), oacc[t], 0, 0, 0);
+    __syncthreads();  // Ks / Pm are rewritten by the next block
+  }
+  // ---- partials: O (un-normalised), running max and sum ----
+  const int chunk = blockIdx.x;
+#pragma unroll
+  for (int t = 0; t < NTO; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int hrow = hg * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      if (hrow < a.n_heads) a.part_o[((size_t)chunk * a.n_heads + hrow) * lora + w * (NTO * 32) + t * 32 + i] = oacc[t][r];
+    }
+  }
+  if (tid < 32 && hg * 32 + tid < a.n_heads) {
+    a.part_ml[((size_t)chunk * a.n_heads + hg * 32 + tid) * 2] = m_s[tid];
+    a.part_ml[((size_t)chunk * a.n_heads + hg * 32 + tid) * 2 + 1] = l_s[tid];
+  }
+}
+int launch_mla_flash(hipStream_t st, const MlaFlashArgs& a, const StepParams* sp, int kv_len_override) {
+  if (a.lora != 512 || a.rope != 64) DSK_FAIL(DSK_ERR_UNSUPPORTED, "mla flash attention: kv_lora_rank %d / rope %d (512 / 64 only)", a.lora, a.rope);
+  if (a.chunk_len % 32 || a.n_chunks < 1) DSK_FAIL(DSK_ERR_INVALID, "mla flash attention: chunk_len %d", a.chunk_len);
+  const size_t lds = 32 * FL_KSTRIDE * 2 + FL_NWV * 32 * FL_PSTRIDE * 4 + 32 * FL_PSTRIDE * 4;
+  static bool attr_set = false;
+  if (!attr_set) { hipFuncSetAttribute((const void*)mla_flash_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  hipLaunchKernelGGL(mla_flash_kernel, dim3(a.n_chunks, (a.n_heads + 31) / 32), dim3(FL_NWV * 64), lds, st, a, sp, kv_len_override);
+  return DSK_OK;
+}
+
+// merge the chunk partials of one head: out = sum_c e^(m_c - M) O_c / sum_c e^(m_c - M) l_c
+__global__ __launch_bounds__(512) void mla_merge_kernel(MlaFlashArgs a, const StepParams* __restrict__ sp, int kv_len_override, float* __restrict__ out) {
+  const int h = blockIdx.x, tid = threadIdx.x;
+  const int kv_len = kv_len_override > 0 ? kv_len_override : sp->kv_len;
+  const int nc = min(a.n_chunks, (kv_len + a.chunk_len - 1) / a.chunk_len);
+  float M = -INFINITY;
+  for (int c = 0; c < nc; ++c) M = fmaxf(M, a.part_ml[((size_t)c * a.n_heads + h) * 2]);
+  float L = 0.f;
+  for (int c = 0; c < nc; ++c) L += expf(a.part_ml[((size_t)c * a.n_heads + h) * 2] - M) * a.part_ml[((size_t)c * a.n_heads + h) * 2 + 1];
+  for (int i = tid; i < a.lora; i += 512) {
+    float o = 0.f;
+    for (int c = 0; c < nc; ++c) o = fmaf(expf(a.part_ml[((size_t)c * a.n_heads + h) * 2] - M), a.part_o[((size_t)c * a.n_heads + h) * a.lora + i], o);
+    out[(size_t)h * a.lora + i] = o / L;
+  }
+}
+int launch_mla_merge(hipStream_t st, const MlaFlashArgs& a, const StepParams* sp, int kv_len_override, float* out) {
+  hipLaunchKernelGGL(mla_merge_kernel, dim3(a.n_heads), dim3(512), 0, st, a, sp, kv_len_override, out);
+  return DSK_OK;
+}
+
 int launch_rope_kv_mla(hipStream_t st, const AttnMlaArgs& a, const StepParams* sp) {
   if (a.rope > 128 || (a.rope & 1)) DSK_FAIL(DSK_ERR_UNSUPPORTED, "rope dim %d (max 128, even)", a.rope);
   hipLaunchKernelGGL(rope_kv_mla_kernel, dim3(a.n_heads), dim3(256), 0, st, a, sp);

@@ -258,6 +258,21 @@ extern "C" int dsk_attn_mla(dsk_ctx* ctx, const float* q_c, const float* q_rope,
   memset(&a, 0, sizeof a);
   a.q_c = dqc.as<float>(); a.q_rope = dqr.as<float>(); a.nope_cache = dc.as<uint16_t>(); a.rope_cache = dr.as<uint16_t>();
   a.out = dout.as<float>(); a.n_heads = n_heads; a.head_dim = head_dim; a.rope = rope_dim; a.lora = kv_lora_rank;
+  if (kv_len >= 512 && kv_lora_rank == 512 && rope_dim == 64) {  // long context: matrix-core path (partials + merge)
+    MlaFlashArgs f;
+    memset(&f, 0, sizeof f);
+    f.q_c = a.q_c; f.q_rope = a.q_rope; f.rotate_q = 0; f.nope_cache = a.nope_cache; f.rope_cache = a.rope_cache;
+    f.n_heads = n_heads; f.head_dim = head_dim; f.lora = kv_lora_rank; f.rope = rope_dim;
+    f.n_chunks = 64; f.chunk_len = ((kv_len + 63) / 64 + 31) / 32 * 32;
+    DevBuf po, pml;
+    DSK_TRY(po.alloc((size_t)f.n_chunks * n_heads * kv_lora_rank * 4));
+    DSK_TRY(pml.alloc((size_t)f.n_chunks * n_heads * 8));
+    f.part_o = po.as<float>(); f.part_ml = pml.as<float>();
+    DSK_TRY(launch_mla_flash(st, f, nullptr, kv_len));
+    DSK_TRY(launch_mla_merge(st, f, nullptr, kv_len, dout.as<float>()));
+    HIP_TRY(hipMemcpyAsync(out, dout.p, (size_t)n_heads * kv_lora_rank * 4, hipMemcpyDeviceToHost, st));
+    return finish(ctx);
+  }
   DSK_TRY(launch_attn_mla(st, a, nullptr, kv_len, kv_len));
   HIP_TRY(hipMemcpyAsync(out, dout.p, (size_t)n_heads * kv_lora_rank * 4, hipMemcpyDeviceToHost, st));
   return finish(ctx);

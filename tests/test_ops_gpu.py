@@ -230,3 +230,18 @@ def test_attn_vs_reference_golden_and_kat(ctx, ops_gold):
     for q, want in (([0., 1e4, 0., 0.], [0, 1, 0, 0]), ([0., 0., 1e4, 0.], [0, 0, 1, 0])):
         out = ctx.attn_mha(np.array(q, np.float32), kb16, kb16, 1, 4, 4, 4)
         assert np.allclose(out, want, atol=1e-6)
+
+
+@pytest.mark.parametrize("kv_len", [512, 777, 2100])
+def test_attn_mla_long_context_matrix_core_path(ctx, oracle, kv_len):
+    """kv_len >= 512 takes the MFMA path (exact-f32 matrix cores, chunked online softmax + merge): same result as
+    the reference's attn_mla (src/infer.cpp:766-804) up to f32 summation order."""
+    rng = np.random.default_rng(kv_len)
+    H, lora, rope, hd = 40, 512, 64, 192  # 40 heads: a ragged last head group
+    q_c = rng.standard_normal((H, lora)).astype(np.float32) * 0.2
+    q_r = rng.standard_normal((H, rope)).astype(np.float32) * 0.2
+    ckv = rng.standard_normal((kv_len, lora)).astype(np.float16)
+    kr = rng.standard_normal((kv_len, rope)).astype(np.float16)
+    got = ctx.attn_mla(q_c, q_r, ckv.view(np.uint16), kr.view(np.uint16), H, hd, lora, rope, kv_len)
+    ref = oracle.attn_mla(q_c, q_r, ckv.view(np.uint16), kr.view(np.uint16), H, hd, lora, rope, kv_len)
+    assert np.max(np.abs(got - ref)) < 2e-5 * max(1.0, float(np.max(np.abs(ref)))), float(np.max(np.abs(got - ref)))
