@@ -216,7 +216,7 @@ int build_plans(dsk_model* m) {
       A.a.is_v3 = c.has_moegate_bias;
       A.fin.out = m->vb_out; A.fin.v_dim = c.v_head_dim; A.fin.n_heads = H; A.fin.q_counter = m->att_counter;
       if (kq) { A.fin.q_qs = m->a_att.qs; A.fin.q_d = m->a_att.d; A.fin.q_bsums = m->a_att.bsums; }
-      if (m->fl_part_o) {  // kv_len >= 512: scores / values of all heads on the matrix cores, merged per head here
+      if (m->fl_part_o) {  // kv_len >= MLA_FLASH_MIN_KV: scores / values of all heads on the matrix cores, merged per head here
         const int max_kv = std::min(c.max_seq_len, std::max(1, c.rs_original_max_position_embeddings));
         MlaFlashArgs F;
         memset(&F, 0, sizeof F);
@@ -224,7 +224,7 @@ int build_plans(dsk_model* m) {
         F.part_o = m->fl_part_o; F.part_ml = m->fl_part_ml; F.n_heads = H; F.head_dim = m->head_dim; F.lora = c.kv_lora_rank;
         F.rope = c.qk_rope_head_dim; F.is_v3 = c.has_moegate_bias; F.n_chunks = 64; F.chunk_len = ((max_kv + 63) / 64 + 31) / 32 * 32;
         m->mla_flash[l] = F;
-        A.flash_thresh = 512; A.fl_chunk_len = F.chunk_len; A.fl_n_chunks = F.n_chunks; A.fl_part_o = F.part_o; A.fl_part_ml = F.part_ml;
+        A.flash_thresh = MLA_FLASH_MIN_KV; A.fl_chunk_len = F.chunk_len; A.fl_n_chunks = F.n_chunks; A.fl_part_o = F.part_o; A.fl_part_ml = F.part_ml;
       }
       DSK_TRY(mla_head_plan(A));
       m->mla_head[l] = A;
@@ -427,7 +427,7 @@ static int attention_mla(dsk_model* m, int l, int max_kv) {
     kv.is_v3 = c.has_moegate_bias;
     PROFILED("rope_kv", (double)c.kv_lora_rank * 14 + c.qk_rope_head_dim * 6, launch_mla_kv_write(st, kv, m->sp_dev));
   }
-  if (m->mla_flash[l].part_o && m->sp_host->kv_len >= 512)  // long-context regime (its own graph: dsk_forward)
+  if (m->mla_flash[l].part_o && m->sp_host->kv_len >= MLA_FLASH_MIN_KV)  // long-context regime (its own graph: dsk_forward)
     PROFILED("attn_mla_flash", (double)m->sp_host->kv_len * (c.kv_lora_rank + c.qk_rope_head_dim) * 2, launch_mla_flash(st, m->mla_flash[l], m->sp_dev, 0));
   // q rope + attention over the shared latent cache + per-head wv_b + Q8_K of the outputs: one launch
   PROFILED("attn_mla", m->head_attn_bytes[l] + (double)m->sp_host->kv_len * (c.kv_lora_rank + c.qk_rope_head_dim) * 2 + (double)H * c.v_head_dim * 9,
@@ -524,7 +524,7 @@ static int run_token(dsk_model* m, int token, int pos, int mode) {
   // lazily initialised collectives out of stream capture.
   const bool graphable = m->use_graph && !m->trace && !m->profiling && !m->ctx->comm;
   // the long-context MLA regime enqueues one more launch per block: its own captured graph
-  const bool long_mla = m->fl_part_o && m->sp_host->kv_len >= 512;
+  const bool long_mla = m->fl_part_o && m->sp_host->kv_len >= MLA_FLASH_MIN_KV;
   const int gi = mode + (long_mla ? 3 : 0);  // 0 hydrate, 1 logits, 2 argmax
   if (graphable && !m->graph_primed[gi]) {
     m->graph_primed[gi] = true;  // first token of a mode runs eagerly (first-use initialisation), the second is captured

@@ -958,29 +958,41 @@ __global__ __launch_bounds__(FL_NWV * 64) void mla_flash_kernel(MlaFlashArgs a, 
   // ---- this wave's eighth of the K range of Q, one value per (MFMA step, lane): k = 2*(ks0 + s) + kh ----
   constexpr int steps = 288 / FL_NWV;  // k-pairs per wave: (512 + 64) / 2 / 8 (launch_mla_flash admits only these dims)
   const int ks0 = w * steps;
+  // Q tile of this head group through LDS (coalesced row reads; per-lane strided global reads cost 12 us).  The whole
+  // [32][576] tile fits the dynamic LDS of the main loop (not yet in use); row stride 577 floats: conflict-free column
+  // reads.  A lane then picks its strided elements and rotates the rope pairs (src/infer.cpp:648-685).
   float qa[steps];
-#pragma unroll
-  for (int s = 0; s < steps; ++s) {
-    float v = 0.f;
-    if (hv) {
-      const int k = 2 * (ks0 + s) + kh;
-      if (k < lora) {
-        v = a.q_c[(size_t)head * lora + k];
-      } else {
-        const int kr = k - lora;
-        const float* qr = a.q_rope + (size_t)head * rope;
-        if (!a.rotate_q) {
-          v = qr[kr];
-        } else {  // rope (V2: de-interleaving) src/infer.cpp:648-668; rope_v3 :670-685
-          const int j = a.is_v3 ? kr >> 1 : (kr < rope / 2 ? kr : kr - rope / 2);
-          const bool im = a.is_v3 ? (kr & 1) : (kr >= rope / 2);
-          const float v0 = qr[2 * j], v1 = qr[2 * j + 1];
-          const float c = sp->rope_cs[2 * j], sn = sp->rope_cs[2 * j + 1];
-          v = im ? v0 * sn + v1 * c : v0 * c - v1 * sn;
-        }
+  {
+    constexpr int QST = 577;
+    float* Qs = reinterpret_cast<float*>(fl_smem);
+    for (int c = tid; c < 32 * 144; c += FL_NWV * 64) {  // 144 float4 per row
+      const int r = c / 144, cc = c - r * 144;
+      const int k = cc * 4;
+      const int hh = hg * 32 + r;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (hh < a.n_heads) {
+        if (k < lora) v = *reinterpret_cast<const f32x4*>(a.q_c + (size_t)hh * lora + k);
+        else v = *reinterpret_cast<const f32x4*>(a.q_rope + (size_t)hh * rope + (k - lora));
       }
+      float* dst = Qs + r * QST + k;
+      dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
     }
-    qa[s] = v;
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < steps; ++s) {
+      const int k = 2 * (ks0 + s) + kh;
+      float v = Qs[i * QST + k];
+      if (k >= lora && a.rotate_q) {
+        const int kr = k - lora;
+        const int j = a.is_v3 ? kr >> 1 : (kr < rope / 2 ? kr : kr - rope / 2);
+        const bool im = a.is_v3 ? (kr & 1) : (kr >= rope / 2);
+        const float v0 = Qs[i * QST + lora + 2 * j], v1 = Qs[i * QST + lora + 2 * j + 1];
+        const float c = sp->rope_cs[2 * j], sn = sp->rope_cs[2 * j + 1];
+        v = im ? v0 * sn + v1 * c : v0 * c - v1 * sn;
+      }
+      qa[s] = hv ? v : 0.f;
+    }
+    __syncthreads();
   }
   constexpr int NTO = 2;  // 32-column output tiles per wave: 512 / 8 / 32
   f32x16 oacc[NTO];

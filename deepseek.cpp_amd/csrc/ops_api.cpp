@@ -258,7 +258,7 @@ extern "C" int dsk_attn_mla(dsk_ctx* ctx, const float* q_c, const float* q_rope,
   memset(&a, 0, sizeof a);
   a.q_c = dqc.as<float>(); a.q_rope = dqr.as<float>(); a.nope_cache = dc.as<uint16_t>(); a.rope_cache = dr.as<uint16_t>();
   a.out = dout.as<float>(); a.n_heads = n_heads; a.head_dim = head_dim; a.rope = rope_dim; a.lora = kv_lora_rank;
-  if (kv_len >= 512 && kv_lora_rank == 512 && rope_dim == 64) {  // long context: matrix-core path (partials + merge)
+  if (kv_len >= MLA_FLASH_MIN_KV && kv_lora_rank == 512 && rope_dim == 64) {  // long context: matrix-core path (partials + merge)
     MlaFlashArgs f;
     memset(&f, 0, sizeof f);
     f.q_c = a.q_c; f.q_rope = a.q_rope; f.rotate_q = 0; f.nope_cache = a.nope_cache; f.rope_cache = a.rope_cache;

@@ -232,9 +232,9 @@ def test_attn_vs_reference_golden_and_kat(ctx, ops_gold):
         assert np.allclose(out, want, atol=1e-6)
 
 
-@pytest.mark.parametrize("kv_len", [512, 777, 2100])
+@pytest.mark.parametrize("kv_len", [768, 1001, 2100])
 def test_attn_mla_long_context_matrix_core_path(ctx, oracle, kv_len):
-    """kv_len >= 512 takes the MFMA path (exact-f32 matrix cores, chunked online softmax + merge): same result as
+    """kv_len >= 768 takes the MFMA path (exact-f32 matrix cores, chunked online softmax + merge): same result as
     the reference's attn_mla (src/infer.cpp:766-804) up to f32 summation order."""
     rng = np.random.default_rng(kv_len)
     H, lora, rope, hd = 40, 512, 64, 192  # 40 heads: a ragged last head group
