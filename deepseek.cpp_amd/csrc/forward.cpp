@@ -32,7 +32,14 @@ struct Prof {
 static int prof_begin(dsk_model* m, const char* name, double bytes, Prof* p, bool record_start = true) {
   p->m = m;
   if (m->class_filter) {  // dsk_time_kernel_class: only the launches of one class are enqueued
-    p->skip = strcmp(name, m->class_filter) != 0;
+    // the filter may name several classes joined by '+' (interleaved in their in-model order)
+    p->skip = true;
+    for (const char* f = m->class_filter; f && *f;) {
+      const char* e = strchr(f, '+');
+      const size_t len = e ? (size_t)(e - f) : strlen(f);
+      if (strlen(name) == len && strncmp(name, f, len) == 0) p->skip = false;
+      f = e ? e + 1 : nullptr;
+    }
     if (!p->skip) { m->class_launches++; m->class_bytes += bytes; }
     return DSK_OK;
   }
