@@ -59,7 +59,6 @@ struct DTensor {
 // pointer in it is fixed for the life of the model, so a captured graph can replay it).
 enum { EPI_STORE = 0, EPI_ADD = 1 };
 enum { ACT_Q8 = 0, ACT_F32 = 1, ACT_F32_NORM = 2 };
-enum { GEMV_MODE_TASKS = 0, GEMV_MODE_ACCUM = 1 };
 #define GEMV_MAX_TASKS 12
 
 struct GemvTask {
@@ -80,11 +79,10 @@ struct GemvTask {
   const float* a_f32;      // ACT_F32 / ACT_F32_NORM: f32 vector (quantised / normed in the prologue)
   const float* norm_w;     // rmsnorm weight
   float eps;
-  float* norm_out;         // optional: workgroup 0 of the task also stores the normed f32 vector
   // output
   float* out;
   int epilogue;            // EPI_*
-  const float* accum_w;    // GEMV_MODE_ACCUM: device pointer to this slot's mixing weight (null: 1)
+  const float* accum_w;    // fused MoE combine: device pointer to this slot's mixing weight (null: 1, the shared expert)
   // Consecutive tasks reading the SAME activation vector form an activation group: they share one
   // workgroup range and their rows are concatenated into one virtual row space that the group's
   // workgroups split evenly (so 8 routed experts + the shared expert balance like one dense matrix)
@@ -101,7 +99,7 @@ struct GemvLaunch {
   int pad_[6];
   GemvTask t[GEMV_MAX_TASKS];
   int n_tasks;
-  int quant, mode, glu, act;  // act = DSK_ACT_* of the GLU epilogue
+  int quant, glu, act;  // act = DSK_ACT_* of the GLU epilogue
   int lpr_log2, R, U, grid;
   int NW;                     // waves per workgroup (4 or 16)
   int part_unit;              // rows are dealt to workgroups in multiples of this

@@ -75,7 +75,7 @@ struct dsk_model {
   // GEMV launch descriptors (forward.cpp): host copies + one device array
   std::vector<GemvLaunch> plans;
   GemvLaunch* plans_dev = nullptr;
-  std::vector<int> lp_qkv_a, lp_qkv_b, lp_wv_b, lp_wo, lp_w13, lp_w2, lp_w2_shared;  // per-layer indices into plans (-1: none)
+  std::vector<int> lp_qkv_a, lp_qkv_b, lp_wv_b, lp_wo, lp_w13, lp_w2;  // per-layer indices into plans (-1: none)
   int lp_head = -1;
   std::vector<MlaHeadArgs> mla_head;   // per layer (MLA path)
   std::vector<double> head_attn_bytes;

@@ -133,7 +133,7 @@ int build_plans(dsk_model* m) {
   const int shared_n = c.n_shared_experts * mi;
   const int hb_stride = std::max(std::max(mi, shared_n), 1);
   m->lp_qkv_a.assign(nl, -1); m->lp_qkv_b.assign(nl, -1); m->lp_wv_b.assign(nl, -1); m->lp_wo.assign(nl, -1);
-  m->lp_w13.assign(nl, -1); m->lp_w2.assign(nl, -1); m->lp_w2_shared.assign(nl, -1);
+  m->lp_w13.assign(nl, -1); m->lp_w2.assign(nl, -1);
   m->plans.clear();
   m->head_attn.assign(nl, HeadAttnArgs());
   m->mla_head.assign(nl, MlaHeadArgs());
@@ -148,7 +148,7 @@ int build_plans(dsk_model* m) {
     {  // 1. wq_a (or wq) || wkv_a on rmsnorm(x, attn_norm)
       GemvLaunch h;
       memset(&h, 0, sizeof h);
-      h.quant = wq; h.mode = GEMV_MODE_TASKS;
+      h.quant = wq;
       GemvTask& a = h.t[h.n_tasks++];
       const DTensor& tq = c.q_lora_rank > 0 ? L.t[DSK_ROLE_WQ_A] : L.t[DSK_ROLE_WQ];
       task_weights(a, tq);
@@ -164,7 +164,7 @@ int build_plans(dsk_model* m) {
     {  // 2. second-stage projections on the normed latents
       GemvLaunch h;
       memset(&h, 0, sizeof h);
-      h.quant = wq; h.mode = GEMV_MODE_TASKS;
+      h.quant = wq;
       double bytes = 0;
       auto add = [&](const DTensor& t, const float* x, const DTensor& norm, float* out) {
         GemvTask& T = h.t[h.n_tasks++];
@@ -205,7 +205,7 @@ int build_plans(dsk_model* m) {
     if (c.use_mla) {  // per-head wv_b on the per-head latent outputs (src/infer.cpp:1134-1137): block-diagonal
       GemvLaunch h;
       memset(&h, 0, sizeof h);
-      h.quant = wq; h.mode = GEMV_MODE_TASKS;
+      h.quant = wq;
       h.bd_heads = H;
       GemvTask& T = h.t[h.n_tasks++];
       task_weights(T, L.t[DSK_ROLE_WV_B]);
@@ -240,7 +240,7 @@ int build_plans(dsk_model* m) {
     {  // 6. wo, x += .
       GemvLaunch h;
       memset(&h, 0, sizeof h);
-      h.quant = wq; h.mode = GEMV_MODE_TASKS;
+      h.quant = wq;
       GemvTask& T = h.t[h.n_tasks++];
       task_weights(T, L.t[DSK_ROLE_WO]);
       const float* src = c.use_mla ? m->vb_out : m->att_out;
@@ -254,7 +254,7 @@ int build_plans(dsk_model* m) {
       {  // dense w1/w3 GLU on rmsnorm(x, ffn_norm)
         GemvLaunch h;
         memset(&h, 0, sizeof h);
-        h.quant = wq; h.mode = GEMV_MODE_TASKS; h.glu = 1;
+        h.quant = wq; h.glu = 1;
         GemvTask& T = h.t[h.n_tasks++];
         task_weights(T, L.t[DSK_ROLE_W1]);
         task_weights2(T, L.t[DSK_ROLE_W3]);
@@ -266,7 +266,7 @@ int build_plans(dsk_model* m) {
       {  // dense w2, x += .
         GemvLaunch h;
         memset(&h, 0, sizeof h);
-        h.quant = wq; h.mode = GEMV_MODE_TASKS;
+        h.quant = wq;
         GemvTask& T = h.t[h.n_tasks++];
         task_weights(T, L.t[DSK_ROLE_W2]);
         task_act_hb(m, T, l, 0);
@@ -284,7 +284,7 @@ int build_plans(dsk_model* m) {
     {  // 8. routed w1/w3 (k slots) || shared w1/w3, GLU
       GemvLaunch h;
       memset(&h, 0, sizeof h);
-      h.quant = wq; h.mode = GEMV_MODE_TASKS; h.glu = 1;
+      h.quant = wq; h.glu = 1;
       for (int k = 0; k < K; ++k) {
         GemvTask& T = h.t[h.n_tasks++];
         task_weights(T, w1);
@@ -310,7 +310,7 @@ int build_plans(dsk_model* m) {
     {  // 9. per-slot W2 into eout[slot]; 1 GPU: the combine rides in the same launch; sharded: all-reduce first
       GemvLaunch h;
       memset(&h, 0, sizeof h);
-      h.quant = wq; h.mode = GEMV_MODE_TASKS;
+      h.quant = wq;
       for (int k = 0; k < K; ++k) {
         GemvTask& T = h.t[h.n_tasks++];
         task_weights(T, w2);
@@ -335,7 +335,7 @@ int build_plans(dsk_model* m) {
   {  // classifier on rmsnorm(x, final_norm) (src/infer.cpp:1292-1316)
     GemvLaunch h;
     memset(&h, 0, sizeof h);
-    h.quant = wq; h.mode = GEMV_MODE_TASKS;
+    h.quant = wq;
     GemvTask& T = h.t[h.n_tasks++];
     const DTensor& cls = m->tied ? m->g[DSK_ROLE_EMBED] : m->g[DSK_ROLE_OUTPUT];
     task_weights(T, cls);

@@ -343,7 +343,6 @@ DEV void stage_q8(const GemvTask& T, uint8_t* lds, int tid, float* scratch, unsi
       const int b = wave + NW * k;
       if (b < nb) {
         float v[4] = {t[k].x * scale * wv[k].x, t[k].y * scale * wv[k].y, t[k].z * scale * wv[k].z, t[k].w * scale * wv[k].w};
-        if (T.norm_out) *reinterpret_cast<f32x4*>(T.norm_out + b * 256 + lane * 4) = f32x4{v[0], v[1], v[2], v[3]};
         q8k_block_lds<Q2META>(v, lane, lds + (size_t)b * 4 * ITEM_LDS);
       }
     }
@@ -376,8 +375,7 @@ DEV void stage_q8(const GemvTask& T, uint8_t* lds, int tid, float* scratch, unsi
           v[1] = v[1] * scale * wv[k].y;
           v[2] = v[2] * scale * wv[k].z;
           v[3] = v[3] * scale * wv[k].w;
-          if (T.norm_out) *reinterpret_cast<f32x4*>(T.norm_out + b * 256 + lane * 4) = f32x4{v[0], v[1], v[2], v[3]};
-        }
+          }
         q8k_block_lds<Q2META>(v, lane, lds + (size_t)b * 4 * ITEM_LDS);
       }
     }
@@ -394,7 +392,6 @@ DEV void stage_f32(const GemvTask& T, float* l_x, int tid, float* scratch) {
     for (int i = tid; i < n; i += NW * 64) {
       const float y = T.a_f32[i] * scale * T.norm_w[i];
       l_x[i] = y;
-      if (T.norm_out) T.norm_out[i] = y;
     }
   } else {
     const f32x4* src = reinterpret_cast<const f32x4*>(T.a_f32);

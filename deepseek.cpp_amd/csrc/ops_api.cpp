@@ -108,7 +108,7 @@ static int gemv_common(dsk_ctx* ctx, int quant, const void* w, size_t w_bytes, c
   // (quantize_acts, src/infer.cpp:327-337) happens in the kernel prologue (ACT_F32)
   GemvLaunch h;
   memset(&h, 0, sizeof h);
-  h.quant = quant; h.mode = GEMV_MODE_TASKS; h.n_tasks = 1; h.b0 = b0; h.b1 = b1;
+  h.quant = quant; h.n_tasks = 1; h.b0 = b0; h.b1 = b1;
   GemvTask& T = h.t[0];
   T.qs = t.qs; T.sc = t.sc; T.hm = t.hm; T.dm = t.dm; T.scale = dsc;
   T.rows = d; T.n = n; T.local_experts = 1;
@@ -348,7 +348,7 @@ extern "C" int dsk_bench_gemv(dsk_ctx* ctx, int quant, int rows, int n, int n_ta
   for (int c = 0; c < copies; ++c) {
     GemvLaunch& h = H[c];
     memset(&h, 0, sizeof h);
-    h.quant = quant; h.mode = GEMV_MODE_TASKS; h.glu = kind == 1; h.act = DSK_ACT_SILU;
+    h.quant = quant; h.glu = kind == 1; h.act = DSK_ACT_SILU;
     h.b0 = h.b1 = 128; h.force_lpr = force_lpr; h.force_R = force_R; h.force_U = force_U;
     if (getenv("DSK_FORCE_NW")) h.force_NW = atoi(getenv("DSK_FORCE_NW"));  // tuning knob of tools/kbench.py
     for (int i = 0; i < n_tasks; ++i) {
