@@ -562,9 +562,11 @@ static int run_token(dsk_model* m, int token, int pos, int mode) {
 extern "C" int dsk_forward(dsk_model* m, int token, int pos, int mode, float* host_logits) {
   DSK_TRY(check_forward_args(m, token, pos, mode, host_logits));
   DSK_TRY(run_token(m, token, pos, mode));
-  if (mode == DSK_MODE_OUTPUT_LOGITS) memcpy(host_logits, m->logits_host, (size_t)m->c.vocab_size * 4);
+  if (mode == DSK_MODE_OUTPUT_LOGITS && host_logits != m->logits_host) memcpy(host_logits, m->logits_host, (size_t)m->c.vocab_size * 4);
   return DSK_OK;
 }
+
+extern "C" float* dsk_model_host_logits(dsk_model* m) { return m && m->finalized ? m->logits_host : nullptr; }
 
 extern "C" int dsk_forward_argmax(dsk_model* m, int token, int pos, int32_t* next_token) {
   DSK_TRY(check_forward_args(m, token, pos, DSK_MODE_OUTPUT_LOGITS, m ? m->logits_host : nullptr));

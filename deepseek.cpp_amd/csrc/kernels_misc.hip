@@ -401,9 +401,19 @@ DEV void gate_body(int e, float v, const float* __restrict__ bias, int E, int K,
     if (e < E) {
       const int g = e / gs, g0 = g * gs;
       int rank = 0;
-      for (int j = g0; j < g0 + gs; ++j) {
-        const float sj = s[j];
-        rank += (sj > v || (sj == v && j < e)) ? 1 : 0;
+      if ((gs & 3) == 0) {  // group starts are multiples of 4: 16-byte LDS reads
+        for (int j = g0; j < g0 + gs; j += 4) {
+          const f32x4 sv = *reinterpret_cast<const f32x4*>(s + j);
+          rank += (sv.x > v || (sv.x == v && j + 0 < e)) ? 1 : 0;
+          rank += (sv.y > v || (sv.y == v && j + 1 < e)) ? 1 : 0;
+          rank += (sv.z > v || (sv.z == v && j + 2 < e)) ? 1 : 0;
+          rank += (sv.w > v || (sv.w == v && j + 3 < e)) ? 1 : 0;
+        }
+      } else {
+        for (int j = g0; j < g0 + gs; ++j) {
+          const float sj = s[j];
+          rank += (sj > v || (sj == v && j < e)) ? 1 : 0;
+        }
       }
       if (rank < tg) {  // survivor: (group, in-group rank) is a unique slot
         cs[g * tg + rank] = v;

@@ -103,6 +103,8 @@ def lib():
         L.dsk_model_set_graph.argtypes = [C.c_void_p, C.c_int]
         L.dsk_model_set_trace.argtypes = [C.c_void_p, C.c_int]
         L.dsk_model_get_trace_x.argtypes = [C.c_void_p, C.c_int, c_f]
+        L.dsk_model_host_logits.argtypes = [C.c_void_p]
+        L.dsk_model_host_logits.restype = C.POINTER(C.c_float)
         L.dsk_forward_argmax.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32)]
         L.dsk_model_get_routing.argtypes = [C.c_void_p, c_i32, c_f]
         L.dsk_model_get_slot_outputs.argtypes = [C.c_void_p, c_f]
@@ -271,14 +273,21 @@ class Model:
             check(lib().dsk_model_synthesize(self.h, synth_seed))
         check(lib().dsk_model_finalize(self.h))
         self._logits = np.zeros(cfg.vocab_size, np.float32)
+        self._pinned = None
+        self._pinned_ptr = None
 
     def forward(self, token: int, pos: int, mode: int = MODE_OUTPUT_LOGITS):
         check(lib().dsk_forward(self.h, token, pos, mode, _f(self._logits)))
         return self._logits.copy() if mode == MODE_OUTPUT_LOGITS else None
 
     def forward_nocopy(self, token: int, pos: int, mode: int = MODE_OUTPUT_LOGITS):
-        check(lib().dsk_forward(self.h, token, pos, mode, _f(self._logits)))
-        return self._logits
+        """logits land in the engine's pinned host buffer; returns a numpy view of it (valid until the next step)"""
+        if self._pinned is None:
+            ptr = lib().dsk_model_host_logits(self.h)
+            self._pinned = np.ctypeslib.as_array(ptr, shape=(self.cfg.vocab_size,))
+            self._pinned_ptr = ptr
+        check(lib().dsk_forward(self.h, token, pos, mode, self._pinned_ptr))
+        return self._pinned
 
     def set_graph(self, on: bool):
         check(lib().dsk_model_set_graph(self.h, int(on)))

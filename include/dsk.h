@@ -172,6 +172,11 @@ int dsk_model_destroy(dsk_model* m);
  * (what InferenceState::logits() holds, src/model.h:137).  HYDRATE: host_logits may be NULL. */
 int dsk_forward(dsk_model* m, int token, int pos, int mode, float* host_logits);
 /* Enable/disable replaying the token step from a captured hipGraph (default on). */
+/* The engine's own pinned host buffer of vocab_size floats (the D2H target of every OUTPUT_LOGITS step).  Passing it
+   as `host_logits` to dsk_forward skips the extra host copy: a host application can make InferenceState::logits()
+   (src/model.h:137) point here.  NULL before finalize. */
+float* dsk_model_host_logits(dsk_model* m);
+
 /* Greedy decode step (the sampler's temperature == 0 branch): like dsk_forward(OUTPUT_LOGITS) but the
    argmax of the logits is taken on the device with Sampler::sample_argmax's tie rule (strict >: the lowest index
    among equal maxima, src/sampler.cpp:28-39) and only the token id crosses PCIe (4 bytes instead of vocab * 4). */
