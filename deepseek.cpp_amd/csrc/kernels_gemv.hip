@@ -1287,16 +1287,23 @@ int gemv_plan(GemvLaunch& h, int target_wgs) {
   if (h.b0 < 1) h.b0 = 1;
   if (h.b1 < 1) h.b1 = 1;
   // lanes per row: the largest power of two <= 64 dividing every task's item count
+  // (K-quants need an exact fit: a lane's quarter must not change between column steps.  The float paths mask a
+  // ragged last step, so they take the widest lane group that wastes <= 1/8 of its slots: V2-Lite's 10944-wide
+  // F8 rows are 684 items = 4 x 171 -- 4 lanes per row would leave 32 workgroups for the whole matrix.)
   int lpr = 64;
   while (lpr > 1) {
     bool ok = true;
-    for (int i = 0; i < h.n_tasks; ++i) ok = ok && ((h.t[i].n / epi) % lpr == 0);
+    for (int i = 0; i < h.n_tasks; ++i) {
+      const int items = h.t[i].n / epi;
+      if (kq) ok = ok && (items % lpr == 0);
+      else ok = ok && ((items + lpr - 1) / lpr * lpr * 8 <= items * 9);
+    }
     if (ok) break;
     lpr >>= 1;
   }
   if (h.force_lpr > 0) {
     for (int i = 0; i < h.n_tasks; ++i)
-      if ((h.t[i].n / epi) % h.force_lpr || (kq && h.force_lpr < 4)) DSK_FAIL(DSK_ERR_INVALID, "gemv: lanes-per-row %d does not divide the row", h.force_lpr);
+      if ((kq && (h.t[i].n / epi) % h.force_lpr) || (kq && h.force_lpr < 4)) DSK_FAIL(DSK_ERR_INVALID, "gemv: lanes-per-row %d does not divide the row", h.force_lpr);
     lpr = h.force_lpr;
   }
   const long rows_eff = h.bd_heads > 0 ? (long)h.t[0].rows * h.bd_heads : total_rows;
