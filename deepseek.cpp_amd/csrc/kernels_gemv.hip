@@ -499,15 +499,19 @@ struct ChunkKQ {
 
 // rowblk[r] = row * nb + (sub >> 2): index of the lane's first super-block; q = sub & 3 its quarter
 template <int QT, int R, int U, bool GLU>
-DEV void load_chunk_kq(ChunkKQ<QT, R, U, GLU>& c, const KQRsrc& B, int its, int lpr_log2, int q, const int (&rowblk)[R], int it0) {
+DEV void load_chunk_kq(ChunkKQ<QT, R, U, GLU>& c, const KQRsrc& B, int its, int items, int sub, int lpr_log2, int q, const int (&rowblk)[R], int it0) {
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int it = it0 + u;
     if (it >= its) break;  // wave-uniform: the trailing steps of the last chunk do no work at all
     const int sblk = (it << lpr_log2) >> 2;  // super-blocks advanced by this column step (scalar)
+    // a ragged LAST step (the lane count does not divide the row's items): lanes past the end re-read the row's last
+    // super-block and get a zero scale -- uniform branch, no cost for exact fits
+    const bool ragged = (it << lpr_log2) + (1 << lpr_log2) > items;
+    const bool dead = ragged && sub + (it << lpr_log2) >= items;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int vb = rowblk[r];
+      const int vb = dead ? rowblk[r] - (sub >> 2) + (items >> 2) - 1 - sblk : rowblk[r];
       c.w[u][r] = __builtin_amdgcn_raw_buffer_load_b128(B.qs, vb * 64 + q * 16, sblk * 64, BUF_NT);
       if (QT == DSK_QUANT_Q2_K) {
         c.scw[u][r] = __builtin_amdgcn_raw_buffer_load_b32(B.sc, vb * 16 + q * 4, sblk * 16, BUF_NT);
@@ -532,19 +536,26 @@ DEV void load_chunk_kq(ChunkKQ<QT, R, U, GLU>& c, const KQRsrc& B, int its, int 
           c.dmw2[u][r] = (u32)__builtin_amdgcn_raw_buffer_load_b16(B.dm2, vb * 2, sblk * 2, BUF_NT);
         }
       }
+      if (ragged && dead) {  // d = dmin = 0: a finite product with 0
+        c.dmw[u][r] = 0;
+        if (GLU) c.dmw2[u][r] = 0;
+      }
     }
   }
 }
 
 // lds_lane = staged vector + sub * ITEM_LDS (the lane's record of column step 0)
 template <int QT, int R, int U, bool GLU>
-DEV void compute_chunk_kq(const ChunkKQ<QT, R, U, GLU>& c, int its, int lpr_log2, int q, int it0, const uint8_t* lds_lane,
+DEV void compute_chunk_kq(const ChunkKQ<QT, R, U, GLU>& c, int its, int items, int sub, int lpr_log2, int q, int it0, const uint8_t* lds_lane,
                           float (&acc)[R], float (&acc2)[R]) {
   const int h = q >> 1, lh = q & 1;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     if (it0 + u >= its) break;
-    const uint8_t* rec = lds_lane + (size_t)((it0 + u) << lpr_log2) * ITEM_LDS;
+    const int item0 = (it0 + u) << lpr_log2;
+    const uint8_t* rec = lds_lane + (size_t)item0 * ITEM_LDS;
+    if (item0 + (1 << lpr_log2) > items && sub + item0 >= items)  // ragged last step: a staged (finite) record
+      rec = lds_lane + (size_t)(items - 1 - sub) * ITEM_LDS;
     u32x4 a[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) a[s] = *reinterpret_cast<const u32x4*>(rec + s * 16);
@@ -636,16 +647,17 @@ DEV void compute_chunk_f(const ChunkF<QT, R, U, GLU>& c, int n, int lpr_log2, in
 // dot products of R rows (x 64/LPR rows per wave) with a staged activation vector.
 // `pre`: the first chunk was already requested by the caller (prefetch across the prologue).
 template <int QT, int R, int U, bool GLU>
-DEV void rows_dot_kq(const KQRsrc& B, int its, int lpr_log2, int q, const int (&rowblk)[R], const uint8_t* lds_lane,
+DEV void rows_dot_kq(const KQRsrc& B, int items, int sub, int lpr_log2, int q, const int (&rowblk)[R], const uint8_t* lds_lane,
                      float (&acc)[R], float (&acc2)[R]) {
+  const int its = (items + (1 << lpr_log2) - 1) >> lpr_log2;
   // (requesting the first weight chunk before the staging prologue was measured and is slower: loads
   // return in order, so the prologue's L2 reads queue behind the HBM reads, and the chunk costs registers)
   ChunkKQ<QT, R, U, GLU> c;
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = acc2[r] = 0.f;
   for (int it0 = 0; it0 < its; it0 += U) {
-    load_chunk_kq<QT, R, U, GLU>(c, B, its, lpr_log2, q, rowblk, it0);
-    compute_chunk_kq<QT, R, U, GLU>(c, its, lpr_log2, q, it0, lds_lane, acc, acc2);
+    load_chunk_kq<QT, R, U, GLU>(c, B, its, items, sub, lpr_log2, q, rowblk, it0);
+    compute_chunk_kq<QT, R, U, GLU>(c, its, items, sub, lpr_log2, q, it0, lds_lane, acc, acc2);
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -762,7 +774,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvLaunch* __restr
       continue;
     }
     const KQRsrc B = kq_rsrc<QT, GLU>(P);
-    const int nb = T.n >> 8, its = (nb * 4) >> lpr_log2;
+    const int nb = T.n >> 8;
     for (int base = lo; base < hi; base += RG) {
       int row[R];
       bool valid[R];
@@ -780,7 +792,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvLaunch* __restr
           int rowblk[R];
 #pragma unroll
           for (int r = 0; r < R; ++r) rowblk[r] = row[r] * nb + (sub >> 2);
-          rows_dot_kq<QT, R, U, GLU>(B, its, lpr_log2, q, rowblk, lds_lane, acc, acc2);
+          rows_dot_kq<QT, R, U, GLU>(B, nb * 4, sub, lpr_log2, q, rowblk, lds_lane, acc, acc2);
         } else {
           rows_dot_f<QT, R, U, GLU>(P, T.n, L.b0, L.b1, lpr_log2, lane, row, smem, acc, acc2);
         }
@@ -899,7 +911,7 @@ __global__ __launch_bounds__(1024) void head_attn_kernel(const HeadAttnArgs A, c
     const int rloc = lane >> lpr_log2, sub = lane & ((1 << lpr_log2) - 1);
     const WPtr P = resolve(T);
     const KQRsrc B = kq_rsrc<QT, false>(P);
-    const int nb = T.n >> 8, its = (nb * 4) >> lpr_log2;
+    const int nb = T.n >> 8;
     for (int base = wave * RPW; base < nrows; base += NW * RPW) {  // wave-uniform bounds, no barrier inside
       const int lr = base + rloc;
       const bool valid = lr < nrows;
@@ -907,7 +919,7 @@ __global__ __launch_bounds__(1024) void head_attn_kernel(const HeadAttnArgs A, c
       float acc[1], acc2[1];
       if constexpr (KQ) {
         int rowblk[1] = {row[0] * nb + (sub >> 2)};
-        rows_dot_kq<QT, 1, 4, false>(B, its, lpr_log2, sub & 3, rowblk, act + sub * ITEM_LDS, acc, acc2);
+        rows_dot_kq<QT, 1, 4, false>(B, nb * 4, sub, lpr_log2, sub & 3, rowblk, act + sub * ITEM_LDS, acc, acc2);
       } else {
         rows_dot_f<QT, 1, 4, false>(P, T.n, A.b0, A.b1, lpr_log2, lane, row, act, acc, acc2);
       }
@@ -1145,7 +1157,7 @@ __global__ __launch_bounds__(1024) void mla_head_kernel(const MlaHeadArgs A, con
     const int rloc = lane >> lpr_log2, sub = lane & ((1 << lpr_log2) - 1);
     const WPtr P = resolve(A.twv);
     const KQRsrc B = kq_rsrc<QT, false>(P);
-    const int nb = lora >> 8, its = (nb * 4) >> lpr_log2;
+    const int nb = lora >> 8;
     for (int base = wave * RPW; base < vd; base += NW * RPW) {
       const int lr = base + rloc;
       const bool valid = lr < vd;
@@ -1153,7 +1165,7 @@ __global__ __launch_bounds__(1024) void mla_head_kernel(const MlaHeadArgs A, con
       float acc[1], acc2[1];
       if constexpr (KQ) {
         int rowblk[1] = {row[0] * nb + (sub >> 2)};
-        rows_dot_kq<QT, 1, 4, false>(B, its, lpr_log2, sub & 3, rowblk, act + sub * ITEM_LDS, acc, acc2);
+        rows_dot_kq<QT, 1, 4, false>(B, nb * 4, sub, lpr_log2, sub & 3, rowblk, act + sub * ITEM_LDS, acc, acc2);
       } else {
         // reference indexing of the F8 block scales for this stack: expert_index = head (src/infer.cpp:437-438)
         WPtr Ph = P;
@@ -1295,7 +1307,7 @@ int gemv_plan(GemvLaunch& h, int target_wgs) {
     bool ok = true;
     for (int i = 0; i < h.n_tasks; ++i) {
       const int items = h.t[i].n / epi;
-      if (kq) ok = ok && (items % lpr == 0);
+      if (kq) ok = ok && (items % lpr == 0 || (lpr >= 32 && (items + lpr - 1) / lpr * lpr * 8 <= items * 9));
       else ok = ok && ((items + lpr - 1) / lpr * lpr * 8 <= items * 9);
     }
     if (ok) break;
@@ -1303,7 +1315,7 @@ int gemv_plan(GemvLaunch& h, int target_wgs) {
   }
   if (h.force_lpr > 0) {
     for (int i = 0; i < h.n_tasks; ++i)
-      if ((kq && (h.t[i].n / epi) % h.force_lpr) || (kq && h.force_lpr < 4)) DSK_FAIL(DSK_ERR_INVALID, "gemv: lanes-per-row %d does not divide the row", h.force_lpr);
+      if (kq && h.force_lpr < 4) DSK_FAIL(DSK_ERR_INVALID, "gemv: lanes-per-row %d does not divide the row", h.force_lpr);
     lpr = h.force_lpr;
   }
   const long rows_eff = h.bd_heads > 0 ? (long)h.t[0].rows * h.bd_heads : total_rows;

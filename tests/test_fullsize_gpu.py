@@ -166,3 +166,22 @@ def test_v2lite_full_width_reduced_depth_vs_oracle(ctx, oracle, quant):
     else:
         assert min(errs) < 1e-5 and max(errs + seq) < 0.1, (errs, seq)
         assert same >= len(toks) - 2
+
+
+@pytest.mark.parametrize("quant", [3, 4], ids=["q2_k", "q3_k"])
+def test_ragged_lane_split_v2lite_dense_w2(ctx, oracle, quant):
+    """DeepSeek-V2-Lite pad256 dense w2: 11008-wide rows = 172 items, no power-of-two lane count >= 8 divides them.
+    The planner takes 64 lanes per row with a ragged third step (dead lanes re-read the last block with a zero
+    scale): same integers, same result as the oracle."""
+    rng = np.random.default_rng(5)
+    rows, n = 2048, 11008
+    if quant == 3:
+        w = rand_q2k(rng, rows, n)
+    else:
+        w = synth.encode_q3k(rng.standard_normal((rows, n)).astype(np.float32) / np.sqrt(n))
+    x = rng.standard_normal(n).astype(np.float32)
+    out = ctx.gemv(quant, w, rows, n, x)
+    sample = np.unique(np.concatenate([[0, rows - 1], rng.integers(0, rows, 40)]))
+    ref = oracle.gemv(quant, np.ascontiguousarray(w[sample]), len(sample), n, x)
+    assert rel_inf(out[sample], ref) < 2e-5, rel_inf(out[sample], ref)
+    assert np.array_equal(out, ctx.gemv(quant, w, rows, n, x))
