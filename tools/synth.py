@@ -392,7 +392,7 @@ def write_dseek(dirname: str, c: Cfg, T: Dict[str, Tens]):
             f.write(b)
 
 
-def random_block_model(c: Cfg, seed: int = 0) -> Dict[str, "Tens"]:
+def random_block_model(c: Cfg, seed: int = 0, tile_blocks: int = 0) -> Dict[str, "Tens"]:
     """A checkpoint of config `c` whose K-quant tensors are VALID RANDOM BLOCKS (random quant / scale
     bytes, d and dmin chosen so that activations stay finite) instead of encoded gaussians: building it
     costs one random-byte fill, so full-width DeepSeek-V3 layers are practical on the host.  Same recipe
@@ -403,10 +403,16 @@ def random_block_model(c: Cfg, seed: int = 0) -> Dict[str, "Tens"]:
         rows = int(np.prod(shape[:-1]))
         n = shape[-1]
         if c.quant == "q2_k":
-            b = rng.integers(0, 256, (rows * (n // 256), 84), dtype=np.uint8)
-            d = (rng.uniform(0.5, 1.5, rows * (n // 256)) / np.sqrt(n) / 13.9).astype(np.float16)
+            nblk = rows * (n // 256)
+            # tile_blocks > 0: tensors larger than that many blocks repeat a random pattern (a 12 GB expert stack
+            # for CPU timing need not be 12 GB of entropy; every byte is still a distinct address)
+            gen = nblk if tile_blocks <= 0 or nblk <= tile_blocks else tile_blocks
+            b = rng.integers(0, 256, (gen, 84), dtype=np.uint8)
+            d = (rng.uniform(0.5, 1.5, gen) / np.sqrt(n) / 13.9).astype(np.float16)
             b[:, 80:82] = d.view(np.uint8).reshape(-1, 2)
             b[:, 82:84] = (1.5 * d.astype(np.float32)).astype(np.float16).view(np.uint8).reshape(-1, 2)
+            if gen < nblk:
+                b = np.tile(b, ((nblk + gen - 1) // gen, 1))[:nblk]
             return Tens(b.reshape(*shape[:-1], -1), tuple(shape), QUANT_IDS["q2_k"])
         w = (rng.standard_normal(shape, dtype=np.float32) / np.sqrt(n)).astype(np.float32)
         return _encode(w, c.quant, c.block_size)
