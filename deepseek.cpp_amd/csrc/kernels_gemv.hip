@@ -714,6 +714,10 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvLaunch* __restr
   constexpr bool KQ = QT == DSK_QUANT_Q2_K || QT == DSK_QUANT_Q3_K;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const unsigned long long t_entry = wall_clock64();
+  // two descriptor fields are requested NOW (cold lines: the group table and the launch geometry), so that a
+  // hinted launch waits for them and for its activation vector at the same time
+  const int n_groups = L.n_groups;
+  const int lpr_log2 = L.lpr_log2;
   const bool hinted = h_n > 0;  // one activation group: its source came with the kernel arguments
   if (hinted) {
     ActSrc S;
@@ -724,7 +728,6 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvLaunch* __restr
     if (KQ) stage_q8<QT == DSK_QUANT_Q2_K, NW>(S, smem, tid, scratch);
     else stage_f32<NW>(S, reinterpret_cast<float*>(smem), tid, scratch);
   }
-  const int lpr_log2 = L.lpr_log2;
   const int RPW = 64 >> lpr_log2;
   const int rloc = lane >> lpr_log2, sub = lane & ((1 << lpr_log2) - 1);
   const int RG = NW * RPW * R;  // rows per workgroup step
@@ -741,7 +744,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvLaunch* __restr
     int g = 0, wg0 = 0;
 #pragma unroll
     for (int k = 0; k < GEMV_MAX_TASKS - 1; ++k)
-      if (k + 1 < L.n_groups && (int)blockIdx.x >= L.grp_wg_end[k]) { g = k + 1; wg0 = L.grp_wg_end[k]; }
+      if (k + 1 < n_groups && (int)blockIdx.x >= L.grp_wg_end[k]) { g = k + 1; wg0 = L.grp_wg_end[k]; }
     t0 = L.grp_t0[g];
     t1 = L.grp_t0[g + 1];
     wi = blockIdx.x - wg0;

@@ -16,7 +16,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libdsk_hip.so")
+LIB_PATH = os.environ.get("DSK_LIB") or os.path.join(HERE, "libdsk_hip.so")  # DSK_LIB: A/B builds of the same library
 
 MODE_HYDRATE_KV_CACHE, MODE_OUTPUT_LOGITS = 0, 1
 QUANT_IDS = {"fp32": 0, "fp16": 1, "f8e5m2": 2, "q2_k": 3, "q3_k": 4}
