@@ -1402,7 +1402,12 @@ int gemv_plan(GemvLaunch& h, int target_wgs) {
   h.NW = 4;
   if (!cg && h.bd_heads <= 0 && total_rows >= 192L * 16 * RPW * h.R) h.NW = 16;
   if (h.force_NW == 4 || h.force_NW == 16) h.NW = h.force_NW;
-  if (h.NW == 16 && h.glu && h.quant == DSK_QUANT_Q3_K && h.U > 2 && h.force_U <= 0) h.U = 2;  // 128 VGPRs per lane at 16 waves
+  // Q3_K items hold three planes per step: under the 128-VGPR budget of a 16-wave workgroup the wide
+  // variants spill inside the column loop (hipcc: 172..664 B of scratch), so they take fewer steps in flight
+  if (h.quant == DSK_QUANT_Q3_K && h.NW == 16 && h.force_U <= 0) {
+    const int cap = h.glu ? 2 : 4;
+    if (h.U > cap) h.U = cap;
+  }
   const int RG = h.NW * RPW * h.R;
   h.part_unit = cg ? RG : 1;
   if (h.bd_heads > 0) {
