@@ -107,9 +107,11 @@ ADEV void q8k_block(const float (&v)[4], int lane, int8_t* qs_blk, float* d_out,
 // RoPE of the head's query (in LDS, in place), key / value assembly from the LDS copy of this head's
 // kv_b rows, f16 cache write at kv_pos, rotation of the attention-sink keys (src/infer.cpp:956-1020).
 template <int NT>
-ADEV void rope_kv_from_lds(const AttnMhaArgs& a, const StepParams* __restrict__ sp, int h, int tid, float* q_s, const float* kvb_s) {
+ADEV void rope_kv_from_lds(const AttnMhaArgs& a, const StepParams* __restrict__ sp, int h, int tid, float* q_s, const float* kvb_s,
+                           bool rotate_sinks = true) {
   const int hd = a.head_dim, nope = a.nope, rope = a.rope, vd = a.v_dim;
-  const int kv_pos = sp->kv_pos, kv_sink = sp->kv_sink;
+  // (split contexts: every split writes the same row at kv_pos, only split 0 -- whose range holds the sink rows -- rotates them)
+  const int kv_pos = sp->kv_pos, kv_sink = rotate_sinks ? sp->kv_sink : 0;
   float qre = 0.f, qim = 0.f;
   if (tid < rope / 2) {  // rope (V2: de-interleaving) src/infer.cpp:648-668; rope_v3 :670-685
     const float v0 = q_s[nope + 2 * tid], v1 = q_s[nope + 2 * tid + 1];
@@ -172,7 +174,14 @@ ADEV void rope_kv_from_lds(const AttnMhaArgs& a, const StepParams* __restrict__ 
 
 // q: the head's query (global, or the LDS copy the fused kernel rotated in place).  NT threads; part: NT / (v_dim / 4) * v_dim floats.
 template <int NT>
-ADEV float attn_mha_body(const AttnMhaArgs& a, const float* q, int kv_len, int h, int tid, float* att, float* scratch, float* part) {
+// Positions [t_lo, t_hi) of the cache.  ml == nullptr: the whole context, normalised softmax (the reference's
+// two-pass arithmetic).  ml != nullptr (split contexts): the weights stay exp(s - m) with m the maximum over the
+// range; ml[0] = m, ml[1] = their sum, and the returned mix is un-normalised -- the merge divides once.
+ADEV float attn_mha_body(const AttnMhaArgs& a, const float* q, int t_lo, int t_hi, int h, int tid, float* att, float* scratch, float* part,
+                         float* ml = nullptr) {
+  const int kv_len = t_hi - t_lo;  // att[] and every loop below are relative to t_lo
+  const uint16_t* const kc = a.key_cache + (size_t)t_lo * a.n_heads * a.head_dim;
+  const uint16_t* const vc = a.value_cache + (size_t)t_lo * a.n_heads * a.v_dim;
   const int wave = tid >> 6, lane = tid & 63, grp = lane >> 4, sl = lane & 15;
   const int hd = a.head_dim, vd = a.v_dim, H = a.n_heads;
   float qv[4][4];
@@ -191,7 +200,7 @@ ADEV float attn_mha_body(const AttnMhaArgs& a, const float* q, int kv_len, int h
     for (int u = 0; u < 4; ++u) {
       const int t = t0 + u * 4 + grp;
       if (t < kv_len) {
-        const uint16_t* kr = a.key_cache + ((size_t)t * H + h) * hd;
+        const uint16_t* kr = kc + ((size_t)t * H + h) * hd;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (64 * j + sl * 4 < hd) k[u][j] = *reinterpret_cast<const f16x4*>(kr + 64 * j + sl * 4);
@@ -223,7 +232,7 @@ ADEV float attn_mha_body(const AttnMhaArgs& a, const float* q, int kv_len, int h
 #pragma unroll
   for (int k = 0; k < 2; ++k)
     if (g < TG && g + k * TG < kv_len)
-      vpre[k] = *reinterpret_cast<const f16x4*>(a.value_cache + ((size_t)(g + k * TG) * H + h) * vd + i4 * 4);
+      vpre[k] = *reinterpret_cast<const f16x4*>(vc + ((size_t)(g + k * TG) * H + h) * vd + i4 * 4);
   __syncthreads();
   // softmax, src/infer.cpp:472-487
   float mx = -INFINITY;
@@ -236,7 +245,9 @@ ADEV float attn_mha_body(const AttnMhaArgs& a, const float* q, int kv_len, int h
     sum += e;
   }
   sum = block_sum(sum, scratch, tid, NT);
-  for (int t = tid; t < kv_len; t += NT) att[t] = att[t] / sum;
+  if (!ml)
+    for (int t = tid; t < kv_len; t += NT) att[t] = att[t] / sum;
+  if (ml && tid == 0) { ml[0] = mx; ml[1] = sum; }
   __syncthreads();
   // mix values: thread (g, i4) sums positions g, g+TG, ... for outputs 4*i4..4*i4+3; groups are added in order
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -256,7 +267,7 @@ ADEV float attn_mha_body(const AttnMhaArgs& a, const float* q, int kv_len, int h
       f16x4 v[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        if (t0 + k * TG < kv_len) v[k] = *reinterpret_cast<const f16x4*>(a.value_cache + ((size_t)(t0 + k * TG) * H + h) * vd + i4 * 4);
+        if (t0 + k * TG < kv_len) v[k] = *reinterpret_cast<const f16x4*>(vc + ((size_t)(t0 + k * TG) * H + h) * vd + i4 * 4);
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (t0 + k * TG < kv_len) {

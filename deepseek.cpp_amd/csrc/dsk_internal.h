@@ -217,9 +217,17 @@ struct HeadAttnArgs {
   int lq_log2, lkv_log2; // lanes per row of the two projections
   int lds_q, lds_kv;     // bytes of the two staged activation vectors
   AttnMhaArgs a;
+  // long contexts: n_split workgroups per head, each over a contiguous share of the cached positions (both
+  // redo the head's projections: the other CUs would idle anyway); partial (O, m, l) per (head, split) go to
+  // split_part, the LAST split of a head to arrive (split_counter[h]) merges them and finishes the head
+  int n_split;
+  float* split_part;        // (H, n_split, v_dim + 2)
+  unsigned* split_counter;  // (H), zero between launches
 };
+#define MHA_SPLIT_MIN_KV 1024  // below this one workgroup per head is faster (default; DSK_MHA_SPLIT_MIN overrides)
+#define MHA_SPLIT_MAX 16
 int head_attn_plan(HeadAttnArgs& A);
-int launch_head_attn(hipStream_t st, const HeadAttnArgs& A, const StepParams* sp, int max_kv);
+int launch_head_attn(hipStream_t st, const HeadAttnArgs& A, const StepParams* sp, int max_kv, int n_split);
 int launch_attn_mha(hipStream_t st, const AttnMhaArgs& a, const StepParams* sp, int kv_len_override, int max_kv);
 struct AttnMlaArgs {
   float* q_rope;         // (H, rope)

@@ -495,6 +495,20 @@ extern "C" int dsk_model_finalize(dsk_model* m) {
     HIP_TRY(hipMalloc((void**)&m->fl_part_ml, (size_t)64 * c.n_heads * 8));
     m->scratch_bytes += (double)64 * c.n_heads * (c.kv_lora_rank * 4 + 8);
   }
+  if (!c.use_mla) {  // long-context MHA: enough workgroups per head to occupy the 256 CUs
+    int S = 256 / std::max(1, c.n_heads);
+    S = std::max(1, std::min(S, MHA_SPLIT_MAX));
+    m->mha_split = S;
+    m->mha_split_min = getenv("DSK_MHA_SPLIT_MIN") ? atoi(getenv("DSK_MHA_SPLIT_MIN")) : MHA_SPLIT_MIN_KV;
+    if (m->mha_split_min < 16 * S) m->mha_split_min = 16 * S;  // every split keeps >= 16 positions (the sink rows stay in split 0)
+    if (S > 1) {
+      const size_t pf = (size_t)c.n_heads * S * (c.v_head_dim + 2) * 4;
+      HIP_TRY(hipMalloc((void**)&m->mha_split_part, pf));
+      HIP_TRY(hipMalloc((void**)&m->mha_split_counter, (size_t)c.n_heads * 4));
+      HIP_TRY(hipMemset(m->mha_split_counter, 0, (size_t)c.n_heads * 4));
+      m->scratch_bytes += (double)pf;
+    }
+  }
   HIP_TRY(hipMalloc((void**)&m->argmax_dev, 64));
   HIP_TRY(hipHostMalloc((void**)&m->argmax_host, 64, hipHostMallocDefault));
   HIP_TRY(hipMalloc((void**)&m->router_counter, 64));
@@ -544,6 +558,8 @@ extern "C" int dsk_model_destroy(dsk_model* m) {
   if (m->router_counter) hipFree(m->router_counter);
   if (m->comb_counter) hipFree(m->comb_counter);
   if (m->att_counter) hipFree(m->att_counter);
+  if (m->mha_split_part) hipFree(m->mha_split_part);
+  if (m->mha_split_counter) hipFree(m->mha_split_counter);
   free_q8(m->a_xb); free_q8(m->a_qa); free_q8(m->a_kva); free_q8(m->a_att); free_q8(m->a_hb);
   if (m->sp_host) hipHostFree(m->sp_host);
   if (m->logits_host) hipHostFree(m->logits_host);

@@ -86,6 +86,10 @@ struct dsk_model {
   double class_bytes = 0;
   unsigned* router_counter = nullptr;
   unsigned* att_counter = nullptr;   // one arrival counter per 256-block of the attention output
+  // MHA long contexts: mha_split workgroups per head from kv_len >= mha_split_min on (head_attn_kernel)
+  int mha_split = 1, mha_split_min = 0;
+  float* mha_split_part = nullptr;
+  unsigned* mha_split_counter = nullptr;
   unsigned* comb_counter = nullptr;  // one arrival counter per row group of the fused MoE combine
   int target_wgs = 1024;
   // profiling

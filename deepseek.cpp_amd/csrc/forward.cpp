@@ -195,6 +195,7 @@ int build_plans(dsk_model* m) {
         a.n_heads = H; a.head_dim = m->head_dim; a.nope = c.qk_nope_head_dim; a.rope = c.qk_rope_head_dim; a.v_dim = c.v_head_dim;
         a.lora = c.kv_lora_rank; a.is_v3 = c.has_moegate_bias;
         a.q_counter = m->att_counter;
+        A.split_part = m->mha_split_part; A.split_counter = m->mha_split_counter;
         if (kq) { a.q_qs = m->a_att.qs; a.q_d = m->a_att.d; a.q_bsums = m->a_att.bsums; }
         DSK_TRY(head_attn_plan(A));
         A.a.out = m->att_out;
@@ -415,7 +416,8 @@ static int attention_mha(dsk_model* m, int l, int max_kv) {
   // second-stage projections (wq_b, wkv_b) + rope + cache write + attention + Q8_K of the head outputs:
   // one launch, one workgroup per head (kernels_gemv.hip head_attn_kernel)
   PROFILED("attn_mha", m->head_attn_bytes[l] + (double)m->sp_host->kv_len * H * (hd + c.v_head_dim) * 2 + (double)H * (hd * 2 + c.v_head_dim * 11),
-           launch_head_attn(st, m->head_attn[l], m->sp_dev, max_kv));
+           launch_head_attn(st, m->head_attn[l], m->sp_dev, max_kv,
+                            m->mha_split > 1 && m->sp_host->kv_len >= m->mha_split_min ? m->mha_split : 1));
   DSK_TRY(run_plan(m, "gemv_wo", m->lp_wo[l]));  // residual: src/infer.cpp:832-834
   return DSK_OK;
 }
@@ -532,7 +534,9 @@ static int run_token(dsk_model* m, int token, int pos, int mode) {
   const bool graphable = m->use_graph && !m->trace && !m->profiling && !m->ctx->comm;
   // the long-context MLA regime enqueues one more launch per block: its own captured graph
   const bool long_mla = m->fl_part_o && m->sp_host->kv_len >= MLA_FLASH_MIN_KV;
-  const int gi = mode + (long_mla ? 3 : 0);  // 0 hydrate, 1 logits, 2 argmax
+  // ... and so does the long-context MHA regime (split contexts: a different grid)
+  const bool long_mha = !m->c.use_mla && m->mha_split > 1 && m->sp_host->kv_len >= m->mha_split_min;
+  const int gi = mode + (long_mla || long_mha ? 3 : 0);  // 0 hydrate, 1 logits, 2 argmax
   if (graphable && !m->graph_primed[gi]) {
     m->graph_primed[gi] = true;  // first token of a mode runs eagerly (first-use initialisation), the second is captured
     DSK_TRY(enqueue_forward(m, mode, max_kv));

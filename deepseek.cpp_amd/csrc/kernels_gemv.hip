@@ -893,10 +893,12 @@ __global__ __launch_bounds__(1024) void head_attn_kernel(const HeadAttnArgs A, c
   __shared__ __attribute__((aligned(16))) float kvb_s[512];
   __shared__ __attribute__((aligned(16))) float part[4096];
   __shared__ int last_flag;
+  __shared__ float ml_s[2];
   constexpr bool KQ = QT == DSK_QUANT_Q2_K || QT == DSK_QUANT_Q3_K;
   constexpr int NW = 16;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int h = blockIdx.x;
+  const int S = A.n_split;  // workgroups per head (1: the whole context here)
+  const int h = S > 1 ? (int)blockIdx.x / S : (int)blockIdx.x, split = S > 1 ? (int)blockIdx.x - h * S : 0;
   const AttnMhaArgs& a = A.a;
   uint8_t* act_q = smem;
   uint8_t* act_kv = smem + A.lds_q;
@@ -963,9 +965,47 @@ __global__ __launch_bounds__(1024) void head_attn_kernel(const HeadAttnArgs A, c
     for (int i = tid; i < a.head_dim; i += 1024) q_s[i] = a.q[(size_t)h * a.head_dim + i];
   head_rows(A.tkv, act_kv, A.lkv_log2, a.nope + a.v_dim, kvb_s);
   __syncthreads();
-  ad::rope_kv_from_lds<1024>(a, sp, h, tid, q_s, kvb_s);
+  ad::rope_kv_from_lds<1024>(a, sp, h, tid, q_s, kvb_s, split == 0);
   __syncthreads();  // the rotated q (LDS) and this position's k / v (global, same CU) are read by other threads below
-  const float o = ad::attn_mha_body<1024>(a, q_s, sp->kv_len, h, tid, att, scratch, part);
+  if (S <= 1) {
+    const float o = ad::attn_mha_body<1024>(a, q_s, 0, sp->kv_len, h, tid, att, scratch, part);
+    ad::attn_out_q8(a, h, tid, o, &last_flag);
+    return;
+  }
+  // ---- split context: this workgroup's share of the positions (every split wrote the same k / v row above)
+  const int kv_len = sp->kv_len, vd = a.v_dim;
+  const int t_lo = (int)((long long)kv_len * split / S), t_hi = (int)((long long)kv_len * (split + 1) / S);
+  float o = ad::attn_mha_body<1024>(a, q_s, t_lo, t_hi, h, tid, att, scratch, part, ml_s);
+  float* P = A.split_part + ((size_t)h * S + split) * (vd + 2);
+  if (tid < vd) __hip_atomic_store(P + tid, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();  // ml_s
+  if (tid < 2) __hip_atomic_store(P + vd + tid, ml_s[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned old = __hip_atomic_fetch_add(A.split_counter + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_flag = old == (unsigned)(S - 1);
+    if (last_flag) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(A.split_counter + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+    }
+  }
+  __syncthreads();
+  if (!last_flag) return;
+  // the head's last split merges: O = sum_s O_s e^{m_s - M} / sum_s l_s e^{m_s - M}, splits in order
+  const float* P0 = A.split_part + (size_t)h * S * (vd + 2);
+  float M = -INFINITY;
+  for (int j = 0; j < S; ++j) M = fmaxf(M, __hip_atomic_load(P0 + (size_t)j * (vd + 2) + vd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  float Lsum = 0.f;
+  o = 0.f;
+  for (int j = 0; j < S; ++j) {
+    const float* Pj = P0 + (size_t)j * (vd + 2);
+    const float w = expf(__hip_atomic_load(Pj + vd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - M);
+    Lsum = fmaf(__hip_atomic_load(Pj + vd + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), w, Lsum);
+    if (tid < vd) o = fmaf(__hip_atomic_load(Pj + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), w, o);
+  }
+  o /= Lsum;
+  __syncthreads();  // last_flag is reused by the finisher
   ad::attn_out_q8(a, h, tid, o, &last_flag);
 }
 
@@ -1002,10 +1042,12 @@ template <int QT>
 static int launch_head_attn_q(hipStream_t st, const HeadAttnArgs& A, const StepParams* sp, size_t lds) {
   auto k = head_attn_kernel<QT>;
   if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k, dim3(A.a.n_heads), dim3(1024), lds, st, A, sp);
+  hipLaunchKernelGGL(k, dim3(A.a.n_heads * (A.n_split > 1 ? A.n_split : 1)), dim3(1024), lds, st, A, sp);
   return DSK_OK;
 }
-int launch_head_attn(hipStream_t st, const HeadAttnArgs& A, const StepParams* sp, int max_kv) {
+int launch_head_attn(hipStream_t st, const HeadAttnArgs& A0, const StepParams* sp, int max_kv, int n_split) {
+  HeadAttnArgs A = A0;
+  A.n_split = (n_split > 1 && A0.split_part && A0.split_counter) ? (n_split > MHA_SPLIT_MAX ? MHA_SPLIT_MAX : n_split) : 1;
   const size_t lds = (size_t)A.lds_q + A.lds_kv + (size_t)max_kv * 4;
   if (lds > 120 * 1024) DSK_FAIL(DSK_ERR_UNSUPPORTED, "attn: kv_len %d does not fit LDS", max_kv);
   switch (A.quant) {

@@ -51,6 +51,29 @@ def test_v3_gemv_shapes_vs_oracle_on_sampled_rows(ctx, oracle, name, rows, n):
     assert np.array_equal(out, ctx.gemv(Q2K, w, rows, n, x))
 
 
+Q3_SHAPES = [("wo", 7168, 16384), ("lm_head_slice", 32768, 7168), ("dense_w2", 7168, 18432), ("wq_b", 24576, 1536)]
+
+
+@pytest.mark.parametrize("name,rows,n", Q3_SHAPES, ids=[s[0] for s in Q3_SHAPES])
+def test_v3_q3k_gemv_shapes_vs_oracle_on_sampled_rows(ctx, oracle, name, rows, n):
+    """Q3_K (W3A8) at the V3 widths: the 16-wave variants with 4 column steps in flight (the planner's cap for
+    Q3_K) and the 64-lane rows of wo; random bytes are valid Q3_K blocks once d is a sane f16."""
+    rng = np.random.default_rng(zlib.crc32(("q3" + name).encode()))
+    b = rng.integers(0, 256, (rows * (n // 256), 110), dtype=np.uint8)
+    d = (rng.uniform(0.5, 1.5, rows * (n // 256)) / np.sqrt(n) / 40.0).astype(np.float16)
+    b[:, 108:110] = d.view(np.uint8).reshape(-1, 2)
+    w = b.reshape(rows, -1)
+    x = rng.standard_normal(n).astype(np.float32)
+    out = ctx.gemv(4, w, rows, n, x)
+    assert np.all(np.isfinite(out))
+    sample = np.unique(np.concatenate([[0, 1, rows - 1, rows // 2], rng.integers(0, rows, 60)]))
+    ref = oracle.gemv(4, np.ascontiguousarray(w[sample]), len(sample), n, x)
+    assert rel_inf(out[sample], ref) < 2e-5, (name, rel_inf(out[sample], ref))
+    out4 = ctx.gemv(4, w, rows, n, (x * np.float32(4.0)).astype(np.float32))
+    assert np.array_equal(out4, out * np.float32(4.0))
+    assert np.array_equal(out, ctx.gemv(4, w, rows, n, x))
+
+
 def test_v3_expert_stack_slices_equal_standalone_matrices(ctx, oracle):
     rng = np.random.default_rng(7)
     E, rows, n = 6, 2048, 7168  # the routed-expert shape (w1 / w3)

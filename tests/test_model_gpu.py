@@ -290,3 +290,31 @@ def test_mla_long_context_regime_matches_oracle(ctx, oracle):
     M.close()
     O.close()
     assert worst < 1e-3, worst
+
+
+@pytest.mark.timeout(900)
+def test_mha_long_context_regime_matches_oracle(ctx, oracle, monkeypatch):
+    """From kv_len >= the split threshold on (default 1024; 256 here) the MHA path runs 256 / n_heads workgroups per
+    head, each over a share of the cached positions, merged by the head's last split (head_attn_kernel), in its own
+    captured graph.  Float weights: logits within 1e-3 of the oracle on both sides of the switch, routing identical;
+    the ring wraps inside the long regime (attention sinks are rotated by split 0 only)."""
+    import dsk
+    monkeypatch.setenv("DSK_MHA_SPLIT_MIN", "256")
+    c = synth.preset("tiny_v3", "fp16", False, max_seq_len=320)
+    c.rs_original_max_position_embeddings = 288  # ring of 288 positions: wraps at pos 288
+    T = synth.synth_model(c, seed=33)
+    M, O = dsk.Model(ctx, c, T), oracle.model(c, T)
+    rng = np.random.default_rng(1)
+    toks = rng.integers(0, c.vocab_size, 310)
+    worst = 0.0
+    for pos, t in enumerate(toks):
+        if pos < 248 and pos % 16:  # fill both caches cheaply, check now and then
+            M.forward(int(t), pos, mode=0)
+            O.forward(int(t), pos, mode=0)
+            continue
+        lg, lo = M.forward(int(t), pos), O.forward(int(t), pos)
+        worst = max(worst, rel_inf(lg, lo))
+        assert np.array_equal(M.routing()[0], O.routing()[0]), pos
+    M.close()
+    O.close()
+    assert worst < 1e-3, worst
