@@ -401,15 +401,8 @@ static int fill_step_params(dsk_model* m, int token, int pos) {
   return DSK_OK;
 }
 
-static int run_quant(dsk_model* m, const float* x, int n, Q8Buf& q8) {
-  if (!is_kq(m->c.weight_quant)) return DSK_OK;
-  PROFILED("quantize_q8k", (double)n * 5.2, launch_quantize_q8k(m->ctx->stream, x, n, q8.qs, q8.d, q8.bsums));
-  return DSK_OK;
-}
-
 static int attention_mha(dsk_model* m, int l, int max_kv) {
   const dsk_config& c = m->c;
-  Layer& L = m->L[l];
   hipStream_t st = m->ctx->stream;
   const int H = c.n_heads, hd = m->head_dim;
   DSK_TRY(run_plan(m, "gemv_qkv_a", m->lp_qkv_a[l]));
