@@ -13,8 +13,12 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <unistd.h>
+
 #include <algorithm>
+#include <chrono>
 #include <map>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -52,6 +56,10 @@ extern "C" int dsk_ctx_destroy(dsk_ctx* c) {
   hipSetDevice(c->device);
   for (int i = 0; i < 8; ++i)
     if (c->op_buf[i]) hipFree(c->op_buf[i]);
+  for (int i = 0; i < dsk_ctx::STAGE_BUFS; ++i) {
+    if (c->pin[i]) hipHostFree(c->pin[i]);
+    if (c->pin_ev[i]) hipEventDestroy(c->pin_ev[i]);
+  }
   if (c->comm) ncclCommDestroy(c->comm);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -68,6 +76,62 @@ int ctx_scratch(dsk_ctx* c, int slot, size_t bytes, void** out) {
   *out = c->op_buf[slot];
   return DSK_OK;
 }
+// ---------------------------------------------------------------------------------
+// host -> HBM staging ring.  `bytes` of `src` (from src_off on) go to dev_dst, asynchronously on the context stream;
+// the SOURCE is consumed when this returns (it has been copied into pinned memory), the device copy completes in
+// stream order.  Pieces of <= STAGE_BYTES; each piece is filled by up to 8 threads (memcpy, or pread on the file).
+// ---------------------------------------------------------------------------------
+static int fill_piece(const HostSrc& src, uint64_t off, char* dst, size_t n) {
+  const size_t min_slice = (size_t)4 << 20;
+  int nt = (int)std::min<size_t>(8, (n + min_slice - 1) / min_slice);
+  if (nt < 1) nt = 1;
+  std::vector<int> rc(nt, 0);
+  auto work = [&](int i) {
+    const size_t a = n * i / nt, b = n * (i + 1) / nt;
+    if (src.fd < 0) {
+      memcpy(dst + a, (const char*)src.ptr + off + a, b - a);
+      return;
+    }
+    size_t done = a;
+    while (done < b) {
+      const ssize_t r = pread(src.fd, dst + done, b - done, (off_t)(src.off + off + done));
+      if (r <= 0) { rc[i] = -1; return; }
+      done += (size_t)r;
+    }
+  };
+  if (nt == 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    for (int i = 1; i < nt; ++i) th.emplace_back(work, i);
+    work(0);
+    for (auto& t : th) t.join();
+  }
+  for (int i = 0; i < nt; ++i)
+    if (rc[i]) DSK_FAIL(DSK_ERR_INVALID, "loader: short read at offset %llu", (unsigned long long)(src.off + off));
+  return DSK_OK;
+}
+int stage_copy(dsk_ctx* ctx, const HostSrc& src, uint64_t src_off, void* dev_dst, size_t bytes) {
+  for (size_t done = 0; done < bytes;) {
+    const size_t n = std::min(bytes - done, dsk_ctx::STAGE_BYTES);
+    const int k = ctx->pin_next;
+    ctx->pin_next = (k + 1) % dsk_ctx::STAGE_BUFS;
+    if (!ctx->pin[k]) {
+      HIP_TRY(hipHostMalloc(&ctx->pin[k], dsk_ctx::STAGE_BYTES, hipHostMallocDefault));
+      HIP_TRY(hipEventCreateWithFlags(&ctx->pin_ev[k], hipEventDisableTiming));
+    }
+    if (ctx->pin_busy[k]) HIP_TRY(hipEventSynchronize(ctx->pin_ev[k]));
+    const auto t0 = std::chrono::steady_clock::now();
+    DSK_TRY(fill_piece(src, src_off + done, (char*)ctx->pin[k], n));
+    ctx->staged_fill_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    HIP_TRY(hipMemcpyAsync((char*)dev_dst + done, ctx->pin[k], n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->pin_ev[k], ctx->stream));
+    ctx->pin_busy[k] = true;
+    ctx->staged_bytes += (double)n;
+    done += n;
+  }
+  return DSK_OK;
+}
+
 hipStream_t ctx_stream(dsk_ctx* c) { return c->stream; }
 int ctx_device(dsk_ctx* c) { return c->device; }
 
@@ -224,35 +288,38 @@ int alloc_tensor(int b0, int b1, DTensor& t, int quant, int e, int rows, int n, 
   return DSK_OK;
 }
 
-// copy the local part of a tensor from the reference's host layout into the device planes
-int upload_tensor(dsk_ctx* ctx, DTensor& t, const void* host_ptr) {
+// copy the local part of a tensor from the reference's host layout (memory or file range) into the device planes;
+// asynchronous on the context stream (the caller synchronises), the source is consumed on return
+int upload_tensor(dsk_ctx* ctx, DTensor& t, const HostSrc& src) {
   hipStream_t st = ctx->stream;
   const size_t per_bytes = mat_bytes(t.quant, t.rows, t.n);
   const size_t lm = t.n_experts > 0 ? (size_t)t.local_experts : 1;
-  const char* src = (const char*)host_ptr + (size_t)t.expert_base * per_bytes;
+  const uint64_t off0 = (uint64_t)t.expert_base * per_bytes;
   if (lm == 0) return DSK_OK;
-  if (!is_kq(t.quant)) {
-    HIP_TRY(hipMemcpyAsync(t.qs, src, lm * per_bytes, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    return DSK_OK;
-  }
-  // K-quants: stage AoS blocks in chunks, re-lay-out into planes on the GPU
+  if (!is_kq(t.quant)) return stage_copy(ctx, src, off0, t.qs, lm * per_bytes);
+  // K-quants: stage AoS blocks in chunks, re-lay-out into planes on the GPU (stream order: the repack of chunk i is
+  // done before the copy of chunk i+1 overwrites the device staging buffer)
   const size_t bsz = t.quant == DSK_QUANT_Q2_K ? 84 : 110;
   const size_t total_blocks = lm * per_bytes / bsz;
-  const size_t chunk_blocks = std::min<size_t>(total_blocks, (size_t)(192u << 20) / bsz / 64 * 64);
+  const size_t chunk_blocks = std::min<size_t>(total_blocks, dsk_ctx::STAGE_BYTES / bsz / 64 * 64);
   void* stage;
   DSK_TRY(ctx_scratch(ctx, 7, chunk_blocks * bsz + 256, &stage));
   for (size_t b0 = 0; b0 < total_blocks; b0 += chunk_blocks) {
     const size_t nb = std::min(chunk_blocks, total_blocks - b0);
-    HIP_TRY(hipMemcpyAsync(stage, src + b0 * bsz, nb * bsz, hipMemcpyHostToDevice, st));
+    DSK_TRY(stage_copy(ctx, src, off0 + b0 * bsz, stage, nb * bsz));
     if (t.quant == DSK_QUANT_Q2_K)
       DSK_TRY(launch_repack_q2k(st, (const uint8_t*)stage, nb, t.qs + b0 * 64, t.sc + b0 * 16, t.dm + b0 * 4));
     else
       DSK_TRY(launch_repack_q3k(st, (const uint8_t*)stage, nb, t.qs + b0 * 64, t.hm + b0 * 32, t.sc + b0 * 12, t.dm + b0 * 2));
-    HIP_TRY(hipStreamSynchronize(st));
   }
   HIP_TRY(hipGetLastError());
   return DSK_OK;
+}
+
+int upload_tensor(dsk_ctx* ctx, DTensor& t, const void* host_ptr) {
+  HostSrc src;
+  src.ptr = host_ptr;
+  return upload_tensor(ctx, t, src);
 }
 
 static int tensor_slot(dsk_model* m, int role, int layer, DTensor** out) {
@@ -285,6 +352,16 @@ static void shard_range(const dsk_model* m, int role, int e, int* base, int* loc
 
 extern "C" int dsk_model_bind(dsk_model* m, int role, int layer, int quant, const int32_t shape[4], const void* host_ptr, size_t bytes) {
   if (!m || !host_ptr || !shape) DSK_FAIL(DSK_ERR_INVALID, "bind: null argument");
+  HostSrc src;
+  src.ptr = host_ptr;
+  DSK_TRY(bind_src(m, role, layer, quant, shape, src, bytes));
+  HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+  return DSK_OK;
+}
+
+// the body of dsk_model_bind over a HostSrc; asynchronous (loader.cpp synchronises once per checkpoint)
+int bind_src(dsk_model* m, int role, int layer, int quant, const int32_t shape[4], const HostSrc& src, size_t bytes) {
+  if (!m || !shape) DSK_FAIL(DSK_ERR_INVALID, "bind: null argument");
   if (m->finalized) DSK_FAIL(DSK_ERR_STATE, "bind after finalize");
   HIP_TRY(hipSetDevice(m->ctx->device));
   const bool is_scale = role >= DSK_ROLE_SCALE;
@@ -294,7 +371,6 @@ extern "C" int dsk_model_bind(dsk_model* m, int role, int layer, int quant, cons
   const RoleShape rs = role_shape(m, r, layer);
   if (!rs.ok) DSK_FAIL(DSK_ERR_INVALID, "bind: role %d is not part of this configuration (layer %d)", r, layer);
   const dsk_config& c = m->c;
-  hipStream_t st = m->ctx->stream;
   int base, local;
   shard_range(m, r, rs.e, &base, &local);
 
@@ -305,8 +381,7 @@ extern "C" int dsk_model_bind(dsk_model* m, int role, int layer, int quant, cons
     const size_t mats = rs.e > 0 ? rs.e : 1;
     if (bytes != per * mats * 4) DSK_FAIL(DSK_ERR_INVALID, "bind: scale bytes %zu, expected %zu", bytes, per * mats * 4);
     const size_t lm = rs.e > 0 ? (size_t)local : 1;
-    if (lm) HIP_TRY(hipMemcpyAsync(t->scale, (const char*)host_ptr + (size_t)base * per * 4, lm * per * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    if (lm) DSK_TRY(stage_copy(m->ctx, src, (uint64_t)base * per * 4, t->scale, lm * per * 4));
     return DSK_OK;
   }
 
@@ -327,7 +402,7 @@ extern "C" int dsk_model_bind(dsk_model* m, int role, int layer, int quant, cons
   if (t->bound()) DSK_FAIL(DSK_ERR_STATE, "bind: role %d layer %d bound twice", r, layer);
   DSK_TRY(alloc_tensor(c.block_size[0], c.block_size[1], *t, quant, rs.e, rs.rows, rs.n, local, base));
   m->weight_bytes += (double)t->bytes;
-  return upload_tensor(m->ctx, *t, host_ptr);
+  return upload_tensor(m->ctx, *t, src);
 }
 
 extern "C" int dsk_model_synthesize(dsk_model* m, uint64_t seed) {

@@ -8,6 +8,14 @@
 
 #include <rccl/rccl.h>
 
+// Where a tensor's bytes come from: host memory (dsk_model_bind) or a byte range of an open file (the .dseek
+// loader, loader.cpp).  Either way they travel through the context's pinned staging ring (engine.cpp stage_copy).
+struct HostSrc {
+  const void* ptr = nullptr;
+  int fd = -1;
+  uint64_t off = 0;  // file offset of byte 0 (fd >= 0)
+};
+
 struct dsk_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -16,7 +24,20 @@ struct dsk_ctx {
   // scratch for op-level entry points
   void* op_buf[8] = {nullptr};
   size_t op_cap[8] = {0};
+  // host -> HBM staging ring: STAGE_BUFS pinned buffers filled by reader threads (memcpy / pread) while the previous
+  // one is in flight on the stream (hipMemcpyAsync); an event per buffer says when it may be refilled
+  static const int STAGE_BUFS = 3;
+  static const size_t STAGE_BYTES = (size_t)64 << 20;
+  void* pin[STAGE_BUFS] = {nullptr};
+  hipEvent_t pin_ev[STAGE_BUFS] = {nullptr};
+  bool pin_busy[STAGE_BUFS] = {false};
+  int pin_next = 0;
+  double staged_bytes = 0, staged_fill_s = 0;  // bookkeeping for dsk_load_stats
 };
+int stage_copy(dsk_ctx* ctx, const HostSrc& src, uint64_t src_off, void* dev_dst, size_t bytes);
+int upload_tensor(dsk_ctx* ctx, DTensor& t, const HostSrc& src);
+struct dsk_model;
+int bind_src(dsk_model* m, int role, int layer, int quant, const int32_t shape[4], const HostSrc& src, size_t bytes);
 
 static const int NROLES = 32;
 int cdiv_i(int a, int b);

@@ -41,6 +41,12 @@ class DskConfig(C.Structure):
     ]
 
 
+class LoadStats(C.Structure):
+    """dsk_load_stats (include/dsk.h)."""
+    _fields_ = [("file_bytes", C.c_uint64), ("staged_bytes", C.c_uint64), ("seconds", C.c_double),
+                ("read_seconds", C.c_double), ("n_files", C.c_int32), ("n_tensors", C.c_int32)]
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char_p), ("launches", C.c_int32), ("total_ms", C.c_float), ("algo_bytes", C.c_double)]
 
@@ -97,6 +103,9 @@ def lib():
         L.dsk_model_create.argtypes = [C.c_void_p, C.POINTER(DskConfig), C.POINTER(C.c_void_p)]
         L.dsk_model_bind.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, c_i32, C.c_void_p, C.c_size_t]
         L.dsk_model_synthesize.argtypes = [C.c_void_p, C.c_uint64]
+        L.dsk_dseek_read_config.argtypes = [C.c_char_p, C.c_int, C.POINTER(DskConfig), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                            C.POINTER(C.c_uint64)]
+        L.dsk_model_load_dseek.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(LoadStats)]
         L.dsk_model_finalize.argtypes = [C.c_void_p]
         L.dsk_model_destroy.argtypes = [C.c_void_p]
         L.dsk_forward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, c_f]
@@ -252,6 +261,13 @@ class Ctx:
         return out.value
 
 
+def read_dseek_config(dirname: str, context: int = 0):
+    """dsk_dseek_read_config: (DskConfig, n_files, n_tensors, tensor_bytes) of a .dseek directory; needs no GPU."""
+    d, nf, nt, nb = DskConfig(), C.c_int32(), C.c_int32(), C.c_uint64()
+    check(lib().dsk_dseek_read_config(dirname.encode(), context, C.byref(d), C.byref(nf), C.byref(nt), C.byref(nb)))
+    return d, nf.value, nt.value, nb.value
+
+
 class Model:
     """dsk_model_* life-cycle.  `tensors`: name -> object with .data/.shape/.quant/.scale (tools.synth.Tens),
     named like the reference's .dseek tensors; or None + synth_seed to generate weights in HBM."""
@@ -275,6 +291,21 @@ class Model:
         self._logits = np.zeros(cfg.vocab_size, np.float32)
         self._pinned = None
         self._pinned_ptr = None
+
+    @classmethod
+    def from_dseek(cls, ctx: "Ctx", dirname: str, context: int = 0) -> "Model":
+        """dsk_model_load_dseek: the checkpoint directory goes straight to HBM (loader.cpp); .load_stats has the rates."""
+        self = cls.__new__(cls)
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        self.load_stats = LoadStats()
+        check(lib().dsk_model_load_dseek(ctx.h, dirname.encode(), context, C.byref(self.h), C.byref(self.load_stats)))
+        self.dcfg = read_dseek_config(dirname, context)[0]
+        self.cfg = self.dcfg  # same field names as the reference Config
+        self._logits = np.zeros(self.cfg.vocab_size, np.float32)
+        self._pinned = None
+        self._pinned_ptr = None
+        return self
 
     def forward(self, token: int, pos: int, mode: int = MODE_OUTPUT_LOGITS):
         check(lib().dsk_forward(self.h, token, pos, mode, _f(self._logits)))

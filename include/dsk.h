@@ -167,6 +167,26 @@ int dsk_model_synthesize(dsk_model* m, uint64_t seed);
 int dsk_model_finalize(dsk_model* m);
 int dsk_model_destroy(dsk_model* m);
 
+/* ---- direct-to-HBM `.dseek` loader ---------------------------
+ * Replaces, for this device, YALMData::from_directory (src/codec.cpp:333-365: every file of the directory in
+ * sorted order, metadata from the first), Config::from_yalm (src/model.cpp:21-127) and the by-name tensor walk of the
+ * Model / Block constructors (src/model.cpp:766-871).  Tensor byte ranges are read with parallel preads into pinned
+ * staging buffers and copied to HBM while the next piece is read; a sharded context reads only its own experts.
+ * `context` > 0 caps max_seq_len like the reference's -c option (src/model.cpp:73-76). */
+typedef struct dsk_load_stats {
+  uint64_t file_bytes;     /* bytes of the tensors the model consumed (all ranks' experts included) */
+  uint64_t staged_bytes;   /* bytes that actually went host -> HBM on this rank */
+  double seconds;          /* wall time of the whole call (open + parse + read + copy + finalize) */
+  double read_seconds;     /* of which: filling the pinned buffers (pread) */
+  int32_t n_files, n_tensors;
+} dsk_load_stats;
+/* Parse the checkpoint's header(s) only: the configuration the model would get, number of files and tensors,
+ * total tensor bytes.  No GPU needed. */
+int dsk_dseek_read_config(const char* dir, int context, dsk_config* out, int32_t* n_files, int32_t* n_tensors,
+                          uint64_t* tensor_bytes);
+/* create + bind every tensor + finalize.  `stats` may be NULL. */
+int dsk_model_load_dseek(dsk_ctx* ctx, const char* dir, int context, dsk_model** out, dsk_load_stats* stats);
+
 /* ---- the hot path (replaces Model::forward, src/model.cpp:874-883) -------- */
 /* One token.  mode == OUTPUT_LOGITS: host_logits receives vocab_size floats
  * (what InferenceState::logits() holds, src/model.h:137).  HYDRATE: host_logits may be NULL. */

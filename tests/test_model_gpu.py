@@ -318,3 +318,77 @@ def test_mha_long_context_regime_matches_oracle(ctx, oracle, monkeypatch):
     M.close()
     O.close()
     assert worst < 1e-3, worst
+
+
+LOADER_CASES = [("tiny_v3", "q2_k", False), ("tiny_v3", "q3_k", True), ("tiny_v3", "f8e5m2", False), ("tiny_v3", "fp16", True),
+                ("tiny_v2lite", "q2_k", False), ("tiny_v2lite", "fp32", False)]
+
+
+@pytest.mark.parametrize("preset,quant,mla", LOADER_CASES, ids=[f"{a}-{b}-{'mla' if c else 'mha'}" for a, b, c in LOADER_CASES])
+def test_dseek_loader_gives_the_same_model_as_the_bind_walk(ctx, tmp_path, preset, quant, mla):
+    """dsk_model_load_dseek (file ranges -> pinned staging ring -> HBM, csrc/loader.cpp) against the same tensors bound
+    one by one from host memory (dsk_model_bind, the walk of INTEGRATION.md): bit-identical logits and routing, across
+    three shard files."""
+    import dsk
+    c = synth.preset(preset, quant, mla)
+    T = synth.synth_model(c, seed=21)
+    d = str(tmp_path / "ckpt")
+    synth.write_dseek(d, c, T, shards=3)
+    A, B = dsk.Model(ctx, c, T), dsk.Model.from_dseek(ctx, d)
+    st = B.load_stats
+    n_scale = sum(1 for t in T.values() if t.scale is not None)
+    assert st.n_files == 3 and st.n_tensors == len(T) + n_scale
+    assert st.file_bytes == st.staged_bytes == sum(t.data.nbytes + (t.scale.nbytes if t.scale is not None else 0) for t in T.values())
+    assert st.seconds > 0
+    for pos, tok in enumerate([3, 200, 41, 7]):
+        assert np.array_equal(A.forward(tok, pos), B.forward(tok, pos)), pos
+        assert np.array_equal(A.routing()[0], B.routing()[0])
+    A.close()
+    B.close()
+
+
+def test_dseek_loader_on_a_sharded_context_reads_only_its_experts(tmp_path):
+    """Expert-sharded rank (dry run, no communicator): the loader stages only the experts this rank owns, and the model
+    equals the one bound from memory on the same shard."""
+    import dsk
+    c = synth.preset("tiny_v3", "q2_k", False, n_layers=2, first_k_dense_replace=1)
+    T = synth.synth_model(c, seed=22)
+    d = str(tmp_path / "ckpt")
+    synth.write_dseek(d, c, T, shards=2)
+    routed = sum(t.data.nbytes for n, t in T.items() if ".mlp.w" in n and t.data.ndim == 3)
+    for rank in (0, 1):
+        x1, x2 = dsk.Ctx(0), dsk.Ctx(0)
+        x1.comm_init_dry(rank, 2)
+        x2.comm_init_dry(rank, 2)
+        A, B = dsk.Model(x1, c, T), dsk.Model.from_dseek(x2, d)
+        st = B.load_stats
+        assert st.file_bytes - st.staged_bytes == routed // 2, (st.file_bytes, st.staged_bytes, routed)
+        for pos, tok in enumerate([9, 310]):
+            assert np.array_equal(A.forward(tok, pos), B.forward(tok, pos))
+            assert np.array_equal(A.slot_outputs(), B.slot_outputs())
+        A.close()
+        B.close()
+        x1.close()
+        x2.close()
+
+
+def test_dseek_loader_errors(ctx, tmp_path):
+    import dsk
+    c = synth.preset("tiny_v3", "q2_k", False)
+    T = synth.synth_model(c, seed=23)
+    # a tensor the constructors require is missing
+    T2 = dict(T)
+    del T2["model.layers.0.attn.wo.weight"]
+    synth.write_dseek(str(tmp_path / "a"), c, T2)
+    with pytest.raises(dsk.DskError, match="attn.wo.weight is missing"):
+        dsk.Model.from_dseek(ctx, str(tmp_path / "a"))
+    # wrong byte count for the configuration (a different hidden size in the metadata)
+    c3 = synth.preset("tiny_v3", "q2_k", False, hidden_dim=c.hidden_dim * 2)
+    synth.write_dseek(str(tmp_path / "b"), c3, T)
+    with pytest.raises(dsk.DskError, match="bytes"):
+        dsk.Model.from_dseek(ctx, str(tmp_path / "b"))
+    # the context survives a failed load
+    synth.write_dseek(str(tmp_path / "c"), c, T)
+    M = dsk.Model.from_dseek(ctx, str(tmp_path / "c"))
+    assert np.all(np.isfinite(M.forward(5, 0)))
+    M.close()

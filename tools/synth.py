@@ -365,31 +365,36 @@ def bind_all(T: Dict[str, Tens], bind):
 _DT = {np.dtype(np.float32): "F32", np.dtype(np.float16): "F16", np.dtype(np.uint8): "U8"}
 
 
-def write_dseek(dirname: str, c: Cfg, T: Dict[str, Tens]):
-    """One shard `shard_000.dseek`: u64 header len | JSON | data (src/codec.cpp:304-331)."""
+def write_dseek(dirname: str, c: Cfg, T: Dict[str, Tens], shards: int = 1):
+    """`shards` files `shard_00k.dseek`: u64 header len | JSON | data (src/codec.cpp:304-331); the metadata goes
+    into the first one, tensors are dealt to the files in order (convert.py writes 8 layers per shard)."""
     os.makedirs(dirname, exist_ok=True)
-    header = {"__metadata__": c.metadata()}
-    blobs, off = [], 0
+    names = list(T.keys())
+    per = -(-len(names) // max(1, shards))
+    for k in range(max(1, shards)):
+        header = {"__metadata__": c.metadata()} if k == 0 else {}
+        blobs, off = [], 0
 
-    def add(name, arr: np.ndarray, dtype: str, shape):
-        nonlocal off
-        b = np.ascontiguousarray(arr).tobytes()
-        header[name] = {"dtype": dtype, "shape": [int(s) for s in shape], "data_offsets": [off, off + len(b)]}
-        blobs.append(b)
-        off += len(b)
+        def add(name, arr: np.ndarray, dtype: str, shape):
+            nonlocal off
+            b = np.ascontiguousarray(arr).tobytes()
+            header[name] = {"dtype": dtype, "shape": [int(s) for s in shape], "data_offsets": [off, off + len(b)]}
+            blobs.append(b)
+            off += len(b)
 
-    for name, t in T.items():
-        if t.quant == QUANT_IDS["f8e5m2"]:
-            add(name, t.data, "F8_E5M2", t.data.shape)
-            add(name.rsplit(".", 1)[0] + ".scale", t.scale, "F32", t.scale.shape)
-        else:
-            add(name, t.data, _DT[t.data.dtype], t.data.shape)
-    hj = json.dumps(header).encode()
-    with open(os.path.join(dirname, "shard_000.dseek"), "wb") as f:
-        f.write(struct.pack("<Q", len(hj)))
-        f.write(hj)
-        for b in blobs:
-            f.write(b)
+        for name in names[k * per:(k + 1) * per]:
+            t = T[name]
+            if t.quant == QUANT_IDS["f8e5m2"]:
+                add(name, t.data, "F8_E5M2", t.data.shape)
+                add(name.rsplit(".", 1)[0] + ".scale", t.scale, "F32", t.scale.shape)
+            else:
+                add(name, t.data, _DT[t.data.dtype], t.data.shape)
+        hj = json.dumps(header).encode()
+        with open(os.path.join(dirname, "shard_%03d.dseek" % k), "wb") as f:
+            f.write(struct.pack("<Q", len(hj)))
+            f.write(hj)
+            for b in blobs:
+                f.write(b)
 
 
 def random_block_model(c: Cfg, seed: int = 0, tile_blocks: int = 0) -> Dict[str, "Tens"]:
