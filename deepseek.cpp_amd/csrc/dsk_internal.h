@@ -133,7 +133,8 @@ int gemv_launch(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& host);
 
 // per-token parameters living in device memory so that a captured graph can be replayed
 struct StepParams {
-  int token, pos, kv_sink, kv_pos, kv_len, pad[3];
+  int token, pos, kv_sink, kv_pos, kv_len;
+  float temperature, top_p, coin;  // dsk_forward_sample (Sampler::sample's arguments + its one random draw)
   float rope_cs[2 * 64];   // cos,sin for pair j at `pos` (host libm: powf/cosf/sinf, src/infer.cpp:655-658)
   float rope_cs1[2 * 64];  // same for pos = 1 (attention-sink rotation, src/infer.cpp:1015)
 };
@@ -286,6 +287,10 @@ int launch_fill_tensor(hipStream_t st, const DTensor& t, uint64_t seed, float ws
 int launch_fill_f32(hipStream_t st, float* p, size_t n, uint64_t seed, float mean, float std);
 int launch_read_bw(hipStream_t st, const void* p, size_t bytes, float* sink);
 int launch_argmax(hipStream_t st, const float* x, int n, int* out);  // first maximum (strict >), src/sampler.cpp:28-39
+// Sampler::sample (src/sampler.cpp:41-75) for temperature != 0; sp != nullptr: temperature / top_p / coin come from *sp;
+// scratch: sample_scratch_bytes() of device memory, ZEROED once (the kernel re-arms its counter)
+size_t sample_scratch_bytes();
+int launch_sample(hipStream_t st, const float* logits, int n, const StepParams* sp, float temperature, float top_p, float coin, float* scratch, int* out);
 
 // ---- engine.cpp helpers shared with ops_api.cpp ----------------------------------
 struct dsk_ctx;

@@ -585,6 +585,8 @@ extern "C" int dsk_model_finalize(dsk_model* m) {
     }
   }
   HIP_TRY(hipMalloc((void**)&m->argmax_dev, 64));
+  HIP_TRY(hipMalloc((void**)&m->sample_scratch, sample_scratch_bytes()));
+  HIP_TRY(hipMemset(m->sample_scratch, 0, sample_scratch_bytes()));
   HIP_TRY(hipHostMalloc((void**)&m->argmax_host, 64, hipHostMallocDefault));
   HIP_TRY(hipMalloc((void**)&m->router_counter, 64));
   HIP_TRY(hipMemset(m->router_counter, 0, 64));
@@ -611,11 +613,12 @@ extern "C" int dsk_model_destroy(dsk_model* m) {
   if (!m) return DSK_OK;
   hipSetDevice(m->ctx->device);
   hipStreamSynchronize(m->ctx->stream);
-  for (int i = 0; i < 6; ++i)
+  for (int i = 0; i < 8; ++i)
     if (m->graph[i]) hipGraphExecDestroy(m->graph[i]);
   if (m->fl_part_o) hipFree(m->fl_part_o);
   if (m->fl_part_ml) hipFree(m->fl_part_ml);
   if (m->argmax_dev) hipFree(m->argmax_dev);
+  if (m->sample_scratch) hipFree(m->sample_scratch);
   if (m->argmax_host) hipHostFree(m->argmax_host);
   for (int i = 0; i < 3; ++i)
     if (!(i == DSK_ROLE_OUTPUT && m->tied && m->finalized)) free_tensor(m->g[i]);

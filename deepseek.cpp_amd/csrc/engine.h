@@ -87,10 +87,11 @@ struct dsk_model {
   int n_slots = 0;  // routed slots (K) + 1 if shared experts
   // graphs
   bool use_graph = true, trace = false;
-  hipGraphExec_t graph[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // (hydrate, logits, argmax) x (short, long-context MLA)
+  hipGraphExec_t graph[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // (hydrate, logits, argmax, sample) x (short, long context)
   float* fl_part_o = nullptr;   // MLA long-context partials (n_chunks, H, lora) / (n_chunks, H, 2)
   float* fl_part_ml = nullptr;
   std::vector<MlaFlashArgs> mla_flash;
+  float* sample_scratch = nullptr;  // segment sums / local maxima / arrival counter of dsk_forward_sample
   int* argmax_dev = nullptr;
   int* argmax_host = nullptr;
   // GEMV launch descriptors (forward.cpp): host copies + one device array
@@ -101,7 +102,7 @@ struct dsk_model {
   std::vector<MlaHeadArgs> mla_head;   // per layer (MLA path)
   std::vector<double> head_attn_bytes;
   std::vector<HeadAttnArgs> head_attn;  // per layer (MHA path): second-stage projections + attention, one launch
-  bool graph_primed[6] = {false, false, false, false, false, false};
+  bool graph_primed[8] = {false, false, false, false, false, false, false, false};
   const char* class_filter = nullptr;  // dsk_time_kernel_class
   int class_launches = 0;
   double class_bytes = 0;

@@ -480,7 +480,7 @@ static int ffn(dsk_model* m, int l) {
   return DSK_OK;
 }
 
-enum { MODE_ARGMAX = 2 };  // internal: OUTPUT_LOGITS + device argmax (dsk_forward_argmax)
+enum { MODE_ARGMAX = 2, MODE_SAMPLE = 3 };  // internal: OUTPUT_LOGITS + device argmax / sampling (dsk_forward_argmax, dsk_forward_sample)
 // enqueue one whole token on the stream (no host synchronisation inside)
 static int enqueue_forward(dsk_model* m, int mode, int max_kv) {
   const dsk_config& c = m->c;
@@ -498,6 +498,11 @@ static int enqueue_forward(dsk_model* m, int mode, int max_kv) {
   DSK_TRY(run_plan(m, "gemv_lm_head", m->lp_head));
   if (mode == MODE_ARGMAX) {  // greedy step: the token id is all that leaves the device
     PROFILED("argmax", (double)c.vocab_size * 4, launch_argmax(st, m->logits, c.vocab_size, m->argmax_dev));
+    if (!m->class_filter) HIP_TRY(hipMemcpyAsync(m->argmax_host, m->argmax_dev, 4, hipMemcpyDeviceToHost, st));
+    return DSK_OK;
+  }
+  if (mode == MODE_SAMPLE) {  // Sampler::sample with temperature != 0: parameters and the random draw travel in StepParams
+    PROFILED("sample", (double)c.vocab_size * 12, launch_sample(st, m->logits, c.vocab_size, m->sp_dev, 0.f, 0.f, 0.f, m->sample_scratch, m->argmax_dev));
     if (!m->class_filter) HIP_TRY(hipMemcpyAsync(m->argmax_host, m->argmax_dev, 4, hipMemcpyDeviceToHost, st));
     return DSK_OK;
   }
@@ -529,7 +534,7 @@ static int run_token(dsk_model* m, int token, int pos, int mode) {
   const bool long_mla = m->fl_part_o && m->sp_host->kv_len >= MLA_FLASH_MIN_KV;
   // ... and so does the long-context MHA regime (split contexts: a different grid)
   const bool long_mha = !m->c.use_mla && m->mha_split > 1 && m->sp_host->kv_len >= m->mha_split_min;
-  const int gi = mode + (long_mla || long_mha ? 3 : 0);  // 0 hydrate, 1 logits, 2 argmax
+  const int gi = mode + (long_mla || long_mha ? 4 : 0);  // 0 hydrate, 1 logits, 2 argmax, 3 sample
   if (graphable && !m->graph_primed[gi]) {
     m->graph_primed[gi] = true;  // first token of a mode runs eagerly (first-use initialisation), the second is captured
     DSK_TRY(enqueue_forward(m, mode, max_kv));
@@ -569,6 +574,21 @@ extern "C" int dsk_forward_argmax(dsk_model* m, int token, int pos, int32_t* nex
   DSK_TRY(check_forward_args(m, token, pos, DSK_MODE_OUTPUT_LOGITS, m ? m->logits_host : nullptr));
   if (!next_token) DSK_FAIL(DSK_ERR_INVALID, "forward_argmax: null output");
   DSK_TRY(run_token(m, token, pos, MODE_ARGMAX));
+  *next_token = *m->argmax_host;
+  return DSK_OK;
+}
+
+// Sampler::sample (src/sampler.cpp:41-75) on the device: temperature == 0 is the argmax step; otherwise softmax with
+// temperature and the first index whose cumulative probability reaches coin * top_p.  `coin` = the caller's
+// std::rand() / (float)RAND_MAX, so the host's random stream stays the reference's.
+extern "C" int dsk_forward_sample(dsk_model* m, int token, int pos, float temperature, float top_p, float coin, int32_t* next_token) {
+  if (temperature == 0.0f) return dsk_forward_argmax(m, token, pos, next_token);
+  DSK_TRY(check_forward_args(m, token, pos, DSK_MODE_OUTPUT_LOGITS, m ? m->logits_host : nullptr));
+  if (!next_token) DSK_FAIL(DSK_ERR_INVALID, "forward_sample: null output");
+  m->sp_host->temperature = temperature;
+  m->sp_host->top_p = top_p;
+  m->sp_host->coin = coin;
+  DSK_TRY(run_token(m, token, pos, MODE_SAMPLE));
   *next_token = *m->argmax_host;
   return DSK_OK;
 }

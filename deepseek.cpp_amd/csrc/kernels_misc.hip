@@ -122,9 +122,33 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
   const int tid = threadIdx.x;
   float best = -3.402823466e+38f;
   int bi = 0x7fffffff;
-  for (int i = tid; i < n; i += 1024) {
-    const float v = x[i];
-    if (v > best) { best = v; bi = i; }  // ascending i per thread: strict > keeps the first
+  if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    // 8 coalesced 16-byte loads in flight per thread: one workgroup reads the vector, the loop is latency x steps
+    const int n4 = n >> 2;
+    for (int j0 = tid; j0 < n4; j0 += 8 * 1024) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (j0 + u * 1024 < n4) v[u] = reinterpret_cast<const f32x4*>(x)[j0 + u * 1024];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (j0 + u * 1024 >= n4) continue;
+        const int i = (j0 + u * 1024) << 2;  // ascending i per thread: strict > keeps the first
+        if (v[u].x > best) { best = v[u].x; bi = i; }
+        if (v[u].y > best) { best = v[u].y; bi = i + 1; }
+        if (v[u].z > best) { best = v[u].z; bi = i + 2; }
+        if (v[u].w > best) { best = v[u].w; bi = i + 3; }
+      }
+    }
+    for (int i = (n4 << 2) + tid; i < n; i += 1024) {
+      const float v = x[i];
+      if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    }
+  } else {
+    for (int i = tid; i < n; i += 1024) {
+      const float v = x[i];
+      if (v > best) { best = v; bi = i; }
+    }
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
@@ -142,6 +166,184 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
 }
 int launch_argmax(hipStream_t st, const float* x, int n, int* out) {
   hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, st, x, n, out);
+  return DSK_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// Sampler::sample for temperature != 0 (src/sampler.cpp:41-75): softmax with temperature, r = rand()/RAND_MAX * top_p,
+// the first index (in VOCABULARY order: the reference sorts an index array for top_p < 1 but then walks logits[i]
+// itself, :58-72) whose running sum of probabilities reaches r; vocab_size - 1 if none does.  `coin` is the caller's
+// rand() / (float)RAND_MAX, so the host's random stream stays the reference's.
+// One launch of ceil(n / 1024) 4-wave workgroups.  Wave w of workgroup g owns SEGMENT 4g + w = 256 consecutive indices:
+// the workgroup takes its local maximum m_g, every wave leaves the sum of expf((l - m_g) / T) over its segment, and the
+// LAST workgroup to arrive (write-through stores, one counter) finishes: global maximum M, segment sums rescaled by
+// expf((m_g - M) / T), their total S, a scan of the 505 segment masses to find the segment where the cumulative
+// probability reaches r, and a scan inside that segment with the reference's own per-element formula
+// expf((l - M) / T) / S.  Every sum has a fixed order: deterministic.  The reference adds 129 280 terms strictly left
+// to right in f32, which no parallel sum reproduces: both are the inverse CDF at the same r, each with its own rounding
+// (~3e-5 of cumulative probability at this vocabulary size), so the tokens agree whenever r is further than that from
+// a boundary of the distribution and are neighbours in the CDF otherwise (tests/test_ops_gpu.py).
+// scratch: [0, nseg) segment sums, [SAMPLE_MAX_SEG, +n_wg) local maxima, then one arrival counter.
+// ------------------------------------------------------------------------------------
+#define SAMPLE_MAX_SEG 2048
+__global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ logits, int n, const StepParams* __restrict__ sp,
+                                                     float temperature, float top_p, float coin, float* __restrict__ scratch,
+                                                     int* __restrict__ out) {
+  __shared__ float red[4];
+  __shared__ float seg[SAMPLE_MAX_SEG];
+  __shared__ int s_last, s_seg;
+  __shared__ float s_base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (sp) { temperature = sp->temperature; top_p = sp->top_p; coin = sp->coin; }
+  const int nseg = (n + 255) >> 8, nwg = gridDim.x;
+  float* g_seg = scratch;
+  float* g_max = scratch + SAMPLE_MAX_SEG;
+  unsigned* counter = reinterpret_cast<unsigned*>(scratch + SAMPLE_MAX_SEG + SAMPLE_MAX_SEG / 4);
+  // 4 consecutive elements of segment sg for this lane; out-of-range elements read as `fill`
+  auto load4 = [&](int sg, float fill, float (&v)[4]) {
+    const int i0 = (sg << 8) + 4 * lane;
+    if (sg < nseg && i0 + 3 < n && (reinterpret_cast<uintptr_t>(logits) & 15) == 0) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(logits + i0);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = sg < nseg && i0 + k < n ? logits[i0 + k] : fill;
+    }
+  };
+  auto wave_sum_x = [&](float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+  };
+  const float NEG = -3.402823466e+38f;  // -FLT_MAX, :47
+  const int sg_own = blockIdx.x * 4 + wave;
+  float v[4];
+  load4(sg_own, NEG, v);
+  float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  {
+    const int i0 = (sg_own << 8) + 4 * lane;
+    float es = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) es += sg_own < nseg && i0 + k < n ? expf((v[k] - mx) / temperature) : 0.f;
+    es = wave_sum_x(es);
+    if (lane == 0 && sg_own < nseg) __hip_atomic_store(g_seg + sg_own, es, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(g_max + blockIdx.x, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = old == (unsigned)nwg - 1;
+    if (s_last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+    }
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // ---- the last workgroup: global maximum, rescaled segment masses, total
+  float M = NEG;
+  for (int g = tid; g < nwg; g += 256) M = fmaxf(M, __hip_atomic_load(g_max + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) M = fmaxf(M, __shfl_xor(M, off));
+  __syncthreads();
+  if (lane == 0) red[wave] = M;
+  __syncthreads();
+  M = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float acc = 0.f;
+  for (int sg = tid; sg < nseg; sg += 256) {
+    const float mg = __hip_atomic_load(g_max + (sg >> 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float es = __hip_atomic_load(g_seg + sg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * expf((mg - M) / temperature);
+    seg[sg] = es;
+    acc += es;
+  }
+  acc = wave_sum_x(acc);
+  __syncthreads();
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  const float S = (red[0] + red[1]) + (red[2] + red[3]);  // :53-56
+  if (wave != 0) return;
+  const float r = coin * top_p;  // :65
+  // which segment: lane l owns segments [l * SPL, +SPL)
+  const int SPL = (nseg + 63) >> 6;
+  float mine = 0.f;
+  for (int k = 0; k < SPL; ++k) {
+    const int sg = lane * SPL + k;
+    if (sg < nseg) mine += seg[sg] / S;
+  }
+  float inc = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float o = __shfl_up(inc, off);
+    if (lane >= off) inc += o;
+  }
+  const unsigned long long hit = __ballot(lane * SPL < nseg && inc >= r);
+  if (hit == 0ull) {
+    if (lane == 0) *out = n - 1;  // :74
+    return;
+  }
+  const int l0 = __ffsll((long long)hit) - 1;
+  if (lane == l0) {
+    float cum = inc - mine;
+    int sel = min(nseg - 1, (l0 + 1) * SPL - 1);
+    float base = cum;
+    for (int k = 0; k < SPL; ++k) {
+      const int sg = l0 * SPL + k;
+      if (sg >= nseg) break;
+      const float ps = seg[sg] / S;
+      if (cum + ps >= r) { sel = sg; base = cum; break; }
+      cum += ps;
+      base = cum;
+      sel = min(nseg - 1, sg + 1);  // rounding left the crossing to the next segment
+    }
+    s_seg = sel;
+    s_base = base;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  const int sg = s_seg;
+  const float base = s_base;
+  float pv[4];
+  load4(sg, 0.f, v);
+  const int i0 = (sg << 8) + 4 * lane;
+  float lsum = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    pv[k] = i0 + k < n ? expf((v[k] - M) / temperature) / S : 0.f;  // :68
+    lsum += pv[k];
+  }
+  float linc = lsum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float o = __shfl_up(linc, off);
+    if (lane >= off) linc += o;
+  }
+  const unsigned long long hit2 = __ballot(i0 < n && base + linc >= r);
+  if (hit2 == 0ull) {
+    if (lane == 0) *out = min(n - 1, (sg + 1) << 8);
+    return;
+  }
+  const int l1 = __ffsll((long long)hit2) - 1;
+  if (lane == l1) {
+    float cum = base + (linc - lsum);
+    int pick = min(n - 1, i0 + 3);
+    for (int k = 0; k < 4; ++k) {
+      cum += pv[k];
+      if (cum >= r && i0 + k < n) { pick = i0 + k; break; }
+    }
+    *out = pick;
+  }
+}
+size_t sample_scratch_bytes() { return (size_t)(SAMPLE_MAX_SEG + SAMPLE_MAX_SEG / 4 + 16) * 4; }
+int launch_sample(hipStream_t st, const float* logits, int n, const StepParams* sp, float temperature, float top_p, float coin, float* scratch, int* out) {
+  if (n < 1 || n > SAMPLE_MAX_SEG * 256) DSK_FAIL(DSK_ERR_UNSUPPORTED, "sample: vocabulary of %d (max %d)", n, SAMPLE_MAX_SEG * 256);
+  const int nseg = (n + 255) >> 8;
+  hipLaunchKernelGGL(sample_kernel, dim3((nseg + 3) / 4), dim3(256), 0, st, logits, n, sp, temperature, top_p, coin, scratch, out);
   return DSK_OK;
 }
 

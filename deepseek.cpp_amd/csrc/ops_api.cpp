@@ -177,6 +177,23 @@ extern "C" int dsk_rmsnorm(dsk_ctx* ctx, const float* x, const float* weight, in
   return finish(ctx);
 }
 
+// Sampler::sample / sample_argmax on a host logits vector (the op behind dsk_forward_sample / dsk_forward_argmax)
+extern "C" int dsk_sample(dsk_ctx* ctx, const float* logits, int vocab_size, float temperature, float top_p, float coin, int32_t* token) {
+  DSK_TRY(begin(ctx));
+  if (!logits || !token || vocab_size <= 0) DSK_FAIL(DSK_ERR_INVALID, "sample: bad argument");
+  hipStream_t st = ctx_stream(ctx);
+  DevBuf dl, dout, dscr;
+  DSK_TRY(dl.alloc((size_t)vocab_size * 4));
+  DSK_TRY(dscr.alloc(sample_scratch_bytes()));
+  HIP_TRY(hipMemsetAsync(dscr.p, 0, sample_scratch_bytes(), st));
+  DSK_TRY(dout.alloc(16));
+  HIP_TRY(hipMemcpyAsync(dl.p, logits, (size_t)vocab_size * 4, hipMemcpyHostToDevice, st));
+  if (temperature == 0.0f) DSK_TRY(launch_argmax(st, dl.as<float>(), vocab_size, dout.as<int>()));
+  else DSK_TRY(launch_sample(st, dl.as<float>(), vocab_size, nullptr, temperature, top_p, coin, dscr.as<float>(), dout.as<int>()));
+  HIP_TRY(hipMemcpyAsync(token, dout.p, 4, hipMemcpyDeviceToHost, st));
+  return finish(ctx);
+}
+
 extern "C" int dsk_moe_gate(dsk_ctx* ctx, const float* scores, const float* bias, int n_routed, int n_active, int norm_topk_prob,
                             float routed_scaling_factor, int scoring_func, int topk_method, int n_group, int topk_group,
                             int32_t* active_experts, float* active_weights) {

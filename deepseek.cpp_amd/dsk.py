@@ -178,6 +178,14 @@ class Ctx:
             self.h = C.c_void_p()
 
     # ---- op-level entry points (host buffers) ----
+    def sample(self, logits, temperature: float, top_p: float, coin: float) -> int:
+        l = _fa(logits)
+        tok = C.c_int32()
+        f = lib().dsk_sample
+        f.argtypes = [C.c_void_p, c_f, C.c_int, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_int32)]
+        check(f(self.h, _f(l), l.size, temperature, top_p, coin, C.byref(tok)))
+        return tok.value
+
     def q8k_quantize(self, x):
         x = _fa(x)
         n = x.size
@@ -330,6 +338,13 @@ class Model:
         x = np.zeros(self.cfg.dim, np.float32)
         check(lib().dsk_model_get_trace_x(self.h, layer, _f(x)))
         return x
+
+    def forward_sample(self, token: int, pos: int, temperature: float, top_p: float, coin: float) -> int:
+        nxt = C.c_int32()
+        f = lib().dsk_forward_sample
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_int32)]
+        check(f(self.h, token, pos, temperature, top_p, coin, C.byref(nxt)))
+        return nxt.value
 
     def forward_argmax(self, token: int, pos: int) -> int:
         nxt = C.c_int32()

@@ -201,6 +201,14 @@ float* dsk_model_host_logits(dsk_model* m);
    argmax of the logits is taken on the device with Sampler::sample_argmax's tie rule (strict >: the lowest index
    among equal maxima, src/sampler.cpp:28-39) and only the token id crosses PCIe (4 bytes instead of vocab * 4). */
 int dsk_forward_argmax(dsk_model* m, int token, int pos, int32_t* next_token);
+/* The sampler's other branch on the device (Sampler::sample, src/sampler.cpp:41-75): softmax with `temperature`, then
+   the first token in vocabulary order whose cumulative probability reaches coin * top_p (vocab_size - 1 if none);
+   temperature == 0 is dsk_forward_argmax.  `coin` is the caller's std::rand() / (float)RAND_MAX: the random stream
+   stays the host's, only the 129 280-wide softmax and the scan move to the GPU (the reference spends two expf passes
+   over the vocabulary per token on one core here).  The reference adds the vocabulary left to right in f32; the
+   device sums in a fixed tree, so the token equals the reference's unless coin * top_p falls within ~1e-5 of a
+   boundary of the cumulative distribution. */
+int dsk_forward_sample(dsk_model* m, int token, int pos, float temperature, float top_p, float coin, int32_t* next_token);
 int dsk_model_set_graph(dsk_model* m, int enable);
 
 /* Algorithmic HBM bytes one forward at `pos` must touch, with true block sizes
@@ -250,6 +258,8 @@ int dsk_embed_row(dsk_ctx* ctx, int quant, const void* w, size_t w_bytes, const 
                   const int32_t block_size[2], int vocab, int dim, int token, float* out);
 /* rmsnorm (src/infer.cpp:601-611) */
 int dsk_rmsnorm(dsk_ctx* ctx, const float* x, const float* weight, int size, float eps, float* out);
+/* Sampler::sample / sample_argmax (src/sampler.cpp:28-75) on a host logits vector; see dsk_forward_sample */
+int dsk_sample(dsk_ctx* ctx, const float* logits, int vocab_size, float temperature, float top_p, float coin, int32_t* token);
 /* moe_gate (src/infer.cpp:493-599): scores are the raw router logits (modified in place in the
  * reference; here read-only).  bias may be NULL. */
 int dsk_moe_gate(dsk_ctx* ctx, const float* scores, const float* bias, int n_routed, int n_active,

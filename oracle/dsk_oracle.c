@@ -516,6 +516,29 @@ void orc_softmax(float* o, const float* x, int size) { /* src/infer.cpp:472-487 
   for (int i = 0; i < size; ++i) o[i] /= score_sum;
 }
 
+/*
+ * Sampler::sample (src/sampler.cpp:41-75) and sample_argmax (:28-39).  temperature == 0: the first maximum (strict >).
+ * Otherwise: max, sum of expf((l - max) / T) left to right, r = coin * top_p with coin = rand() / (float)RAND_MAX,
+ * then the first i IN VOCABULARY ORDER with cumsum >= r -- for top_p < 1 the reference sorts an index array (:58-63)
+ * but its loop (:67-72) still walks logits[i], so the sort has no effect on the result; vocab_size - 1 if none.
+ */
+int orc_sample(const float* logits, int vocab_size, float temperature, float top_p, float coin) {
+  float max_val = -FLT_MAX;
+  int argmax = 0;
+  for (int i = 0; i < vocab_size; ++i)
+    if (logits[i] > max_val) { max_val = logits[i]; argmax = i; }
+  if (temperature == 0.0f) return argmax;
+  float sum = 0.0f;
+  for (int i = 0; i < vocab_size; ++i) sum += expf((logits[i] - max_val) / temperature);
+  const float r = coin * top_p;
+  float cumsum = 0.0f;
+  for (int i = 0; i < vocab_size; ++i) {
+    cumsum += expf((logits[i] - max_val) / temperature) / sum;
+    if (cumsum >= r) return i;
+  }
+  return vocab_size - 1;
+}
+
 static inline float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); } /* src/infer.cpp:489-491 */
 static inline float siluf(float x) { return x / (1.0f + expf(-x)); }       /* src/infer.cpp:640-642 */
 static inline float geluf(float x) {                                       /* src/infer.cpp:636-638 */

@@ -41,6 +41,8 @@ int orc_embed_row(int quant, const void* w, const float* scale, const int32_t* b
                   int dim, int token, float* out);
 void orc_rmsnorm(float* o, const float* x, const float* weight, int size, float eps);
 void orc_softmax(float* o, const float* x, int size);
+/* Sampler::sample / sample_argmax (src/sampler.cpp:28-75); coin = rand() / (float)RAND_MAX */
+int orc_sample(const float* logits, int vocab_size, float temperature, float top_p, float coin);
 void orc_moe_gate(const float* scores_in, const float* bias, int n_routed, int n_active,
                   int norm_topk_prob, float routed_scaling_factor, int scoring_func,
                   int topk_method, int n_group, int topk_group,

@@ -161,6 +161,13 @@ class Oracle(_Lib):
         self.lib.orc_rmsnorm(fp(o), fp(x), fp(w), x.size, eps)
         return o
 
+    def sample(self, logits, temperature, top_p, coin):
+        """Sampler::sample / sample_argmax restated (src/sampler.cpp:28-75)."""
+        l = np.ascontiguousarray(logits, np.float32)
+        f = self.lib.orc_sample
+        f.argtypes, f.restype = [c_f, C.c_int, C.c_float, C.c_float, C.c_float], C.c_int
+        return int(f(fp(l), l.size, temperature, top_p, coin))
+
     def moe_gate(self, scores, bias, n_active, norm_topk_prob, scaling, scoring_func, topk_method, n_group, topk_group):
         s = np.ascontiguousarray(scores, np.float32)
         E = s.size
@@ -401,6 +408,17 @@ class RefSession:
 
     def active_bytes(self, pos):
         return self.ref.lib.ref_active_bytes(self.h, pos)
+
+    def sample(self, logits, temperature, top_p, seed):
+        """The reference's own Sampler::sample on `logits` (vocab_size floats), seeded with `seed`;
+        returns (token, coin) with coin = the rand() / RAND_MAX it drew."""
+        l = np.ascontiguousarray(logits, np.float32)
+        assert l.size == self.cfg.vocab_size
+        f = self.ref.lib.ref_sample
+        f.argtypes, f.restype = [C.c_void_p, c_f, C.c_float, C.c_float, C.c_uint, C.POINTER(C.c_float)], C.c_int
+        coin = C.c_float()
+        tok = f(self.h, fp(l), temperature, top_p, seed, C.byref(coin))
+        return int(tok), float(coin.value)
 
     def close(self):
         if self.h:

@@ -34,6 +34,7 @@
 #undef protected
 
 #include "infer.cpp"  // the reference hot path itself (file-static functions included)
+#include "sampler.h"
 
 namespace {
 struct RefSession {
@@ -232,6 +233,18 @@ void ref_get_gate_scores(void* h, int layer, float* out) {
   int E = s->model->config->n_routed_experts;
   std::memcpy(out, &s->gate_scores[(size_t)layer * E], sizeof(float) * E);
 }
+// Sampler::sample as shipped (src/sampler.cpp:41-75) on a given logits vector.  The sampler seeds std::rand in its
+// constructor and draws once per call: *coin_out is that draw (rand() / (float)RAND_MAX after srand(seed)).
+int ref_sample(void* h, const float* logits, float temperature, float top_p, unsigned seed, float* coin_out) {
+  auto* s = static_cast<RefSession*>(h);
+  const int V = s->model->config->vocab_size;
+  std::memcpy(s->state->logits(), logits, sizeof(float) * V);
+  std::srand(seed);
+  if (coin_out) *coin_out = std::rand() / (float)RAND_MAX;
+  Sampler smp(s->model->config, seed);
+  return smp.sample(*s->state, temperature, top_p);
+}
+
 double ref_active_bytes(void* h, int pos) { return static_cast<RefSession*>(h)->model->active_bytes(pos); }
 
 }  // extern "C"

@@ -392,3 +392,27 @@ def test_dseek_loader_errors(ctx, tmp_path):
     M = dsk.Model.from_dseek(ctx, str(tmp_path / "c"))
     assert np.all(np.isfinite(M.forward(5, 0)))
     M.close()
+
+
+def test_forward_sample_is_forward_plus_sampler(ctx, oracle):
+    """dsk_forward_sample = dsk_forward + Sampler::sample (src/sampler.cpp:41-75) with the caller's random draw:
+    the same token as the op on the model's own logits (eager, then captured graph; parameters change per token),
+    the oracle's token on those logits, and temperature 0 is the argmax step."""
+    import dsk
+    c = synth.preset("tiny_v3", "q2_k", False)
+    T = synth.synth_model(c, seed=14)
+    A, B = dsk.Model(ctx, c, T), dsk.Model(ctx, c, T)
+    rng = np.random.default_rng(2)
+    tok = 17
+    for pos in range(8):
+        t = [1.0, 0.7, 0.0, 1.3][pos % 4]
+        p = [0.95, 1.0, 0.9, 0.5][pos % 4]
+        coin = float(np.float32(rng.uniform()))
+        lg = A.forward(tok, pos)
+        nxt = B.forward_sample(tok, pos, t, p, coin)
+        assert nxt == ctx.sample(lg, t, p, coin), pos
+        want = oracle.sample(lg, t, p, coin)
+        assert nxt == want or t > 0, (pos, nxt, want)  # (near-ties: tests/test_ops_gpu.py)
+        tok = nxt
+    A.close()
+    B.close()

@@ -245,3 +245,62 @@ def test_attn_mla_long_context_matrix_core_path(ctx, oracle, kv_len):
     got = ctx.attn_mla(q_c, q_r, ckv.view(np.uint16), kr.view(np.uint16), H, hd, lora, rope, kv_len)
     ref = oracle.attn_mla(q_c, q_r, ckv.view(np.uint16), kr.view(np.uint16), H, hd, lora, rope, kv_len)
     assert np.max(np.abs(got - ref)) < 2e-5 * max(1.0, float(np.max(np.abs(ref)))), float(np.max(np.abs(got - ref)))
+
+
+# --------------------------------------------------------------------------- the sampler on the device
+def _cdf_distance(logits, t, p, coin, tok):
+    """How far (in cumulative probability, f64) r = coin * top_p lies outside token `tok`'s CDF interval; 0 if inside."""
+    z = (logits.astype(np.float64) - logits.max()) / t
+    cdf = np.cumsum(np.exp(z) / np.exp(z).sum())
+    r = float(np.float32(coin) * np.float32(p))
+    lo = cdf[tok - 1] if tok > 0 else 0.0
+    return max(0.0, lo - r, r - cdf[tok])
+
+
+def _near_tie(logits, t, p, coin, a, b):
+    """Both tokens are the inverse CDF at r up to the f32 rounding of a 129k-term running sum."""
+    return _cdf_distance(logits, t, p, coin, a) < 1e-4 and _cdf_distance(logits, t, p, coin, b) < 1e-4
+
+
+def test_sampler_golden_cases(ctx, oracle):
+    """dsk_sample against the reference's own Sampler::sample outputs (tests/golden/sampler.npz)."""
+    import os
+    from tools.make_golden import sampler_cases
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sampler.npz"))
+    V, cases = sampler_cases()
+    for k, (logits, t, p, seed) in enumerate(cases):
+        if int(np.sum(logits.view(np.uint32) % 65521)) != int(g["logits_crc"][k]):
+            pytest.skip("numpy generates different logits than when the fixture was made")
+        tok = ctx.sample(logits, float(t), float(p), float(g["coin"][k]))
+        assert tok == int(g["token"][k]) or (t > 0 and _near_tie(logits, float(t), float(p), float(g["coin"][k]), tok, int(g["token"][k]))), k
+
+
+def test_sampler_full_vocabulary_vs_oracle(ctx, oracle):
+    """129 280 logits (DeepSeek-V3's vocabulary).  The reference's left-to-right f32 running sums (oracle/dsk_oracle.c
+    orc_sample, pinned to the reference) and the device's fixed-tree sums are both the inverse CDF at r = coin * top_p,
+    each with its own rounding: r must lie within 1e-4 of cumulative probability of BOTH tokens' CDF intervals (the exact
+    f64 CDF is the yardstick; the oracle itself is up to ~3e-5 away from it), and on peaked distributions - what a
+    language model emits - the tokens are the same."""
+    rng = np.random.default_rng(5)
+    V = 129280
+    same_peaked = n_peaked = 0
+    for k in range(60):
+        spread = float(rng.uniform(0.5, 8.0))
+        logits = (rng.standard_normal(V) * spread).astype(np.float32)
+        t = float(rng.choice([0.6, 1.0, 1.4]))
+        p = float(rng.choice([0.5, 0.95, 1.0]))
+        coin = float(np.float32(rng.uniform()))
+        a, b = ctx.sample(logits, t, p, coin), oracle.sample(logits, t, p, coin)
+        assert a == b or _near_tie(logits, t, p, coin, a, b), (k, a, b, _cdf_distance(logits, t, p, coin, a), _cdf_distance(logits, t, p, coin, b))
+        assert _cdf_distance(logits, t, p, coin, a) < 1e-4, k
+        assert ctx.sample(logits, t, p, coin) == a  # deterministic
+        if spread / t > 5.0:  # a few hundred tokens hold the mass
+            n_peaked += 1
+            same_peaked += int(a == b)
+    assert n_peaked >= 5 and same_peaked >= n_peaked - 1, (same_peaked, n_peaked)
+    # edges: temperature 0 = first maximum; coin 0 -> token 0 (cumsum >= 0 at once); coin * top_p beyond the total mass -> V - 1
+    logits = rng.standard_normal(V).astype(np.float32)
+    logits[[77, 5000, 129279]] = logits.max() + 1.0
+    assert ctx.sample(logits, 0.0, 0.95, 0.3) == 77 == oracle.sample(logits, 0.0, 0.95, 0.3)
+    assert ctx.sample(logits, 1.0, 0.95, 0.0) == 0 == oracle.sample(logits, 1.0, 0.95, 0.0)
+    assert ctx.sample(logits, 1.0, 1.0, 1.01) == V - 1 == oracle.sample(logits, 1.0, 1.0, 1.01)

@@ -8,11 +8,15 @@ Three layers of evidence, all CPU-only:
 Integer work (Q8_K ints, top-k indices, codecs) must be bit-exact; the AVX2-lane-exact GEMVs are
 bit-exact too; stages whose float order the reference leaves to -ffast-math are by tolerance.
 """
+import os
+
 import numpy as np
 import pytest
 
 from tests.util import MODEL_CASES, assert_model_parity, case_id, is_kquant, load_case, model_parity_stats, rel_inf
 from tools import synth
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 # --------------------------------------------------------------------------- 1. reference KATs
 KAT_X = np.array([2.0624e-01, 1.6975e+00, 8.4918e-01, -1.7186e-01, -9.0164e-01, 6.1108e-01, 2.2116e-01, 1.0412e+00,
@@ -142,3 +146,34 @@ def test_live_router_gate_exact(oracle, ref):
         eo, wo, _ = oracle.moe_gate(s, b, 8, True, 2.5, 1, 1, 8, 4)
         er, wr, _ = ref.moe_gate(s, b, 8, True, 2.5, 1, 1, 8, 4)
         assert np.array_equal(eo, er) and rel_inf(wo, wr) < 1e-6
+
+
+# --------------------------------------------------------------------------- 4. the sampler
+def test_golden_sampler(oracle):
+    """orc_sample against Sampler::sample / sample_argmax of the reference itself (tests/golden/sampler.npz, made by
+    tools/make_golden.py gen_sampler through oracle/ref_shim.cpp ref_sample): same token for every case - flat and peaked
+    distributions, ties of the maximum, temperature 0 / 0.7 / 1 / 1.5, top_p 0.5 ... 1."""
+    from tools.make_golden import sampler_cases
+    g = np.load(os.path.join(GOLD, "sampler.npz"))
+    V, cases = sampler_cases()
+    assert len(cases) == len(g["token"])
+    for k, (logits, t, p, seed) in enumerate(cases):
+        if int(np.sum(logits.view(np.uint32) % 65521)) != int(g["logits_crc"][k]):
+            pytest.skip("numpy generates different logits than when the fixture was made")
+        assert (t, p, seed) == (g["temperature"][k], g["top_p"][k], g["seed"][k])
+        assert oracle.sample(logits, float(t), float(p), float(g["coin"][k])) == int(g["token"][k]), k
+
+
+def test_live_sampler(oracle, ref, tmp_path):
+    c = synth.preset("tiny_v3", "fp16", False)
+    d = str(tmp_path / "m")
+    synth.write_dseek(d, c, synth.synth_model(c, seed=1))
+    S = ref.session(d, c)
+    rng = np.random.default_rng(12)
+    for k in range(300):
+        logits = (rng.standard_normal(c.vocab_size) * rng.uniform(0.3, 10)).astype(np.float32)
+        t = float(rng.choice([0.0, 0.5, 1.0, 1.3]))
+        p = float(rng.choice([0.5, 0.9, 0.95, 1.0]))
+        tok, coin = S.sample(logits, t, p, 100 + k)
+        assert oracle.sample(logits, t, p, coin) == tok, (k, t, p, coin)
+    S.close()

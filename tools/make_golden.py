@@ -167,10 +167,49 @@ def gen_ops(R):
     print("ops ok")
 
 
+def sampler_cases():
+    """(logits, temperature, top_p, seed) of the sampler fixture: the logits are functions of the seed only."""
+    V = synth.preset("tiny_v3", "fp16", False).vocab_size
+    cases = []
+    for k in range(48):
+        rng = np.random.default_rng(1000 + k)
+        spread = [0.5, 2.0, 6.0, 12.0][k % 4]  # flat ... peaked distributions
+        logits = (rng.standard_normal(V) * spread).astype(np.float32)
+        if k % 8 == 7:
+            logits[rng.integers(0, V, 3)] = logits.max()  # ties of the maximum
+        temperature = [1.0, 0.7, 1.5, 0.0][k % 4 if k % 12 else 3]
+        top_p = [0.95, 1.0, 0.5, 0.9][(k // 4) % 4]
+        cases.append((logits, np.float32(temperature), np.float32(top_p), 7 + k))
+    return V, cases
+
+
+def gen_sampler(R):
+    """Sampler::sample / sample_argmax of the reference itself (oracle/ref_shim.cpp ref_sample) -> tests/golden/sampler.npz."""
+    V, cases = sampler_cases()
+    c = synth.preset("tiny_v3", "fp16", False)
+    d = tempfile.mkdtemp(prefix="dsk_gold_sampler_")
+    synth.write_dseek(d, c, synth.synth_model(c, seed=1))
+    S = R.session(d, c)
+    toks, coins = [], []
+    for logits, t, p, seed in cases:
+        tok, coin = S.sample(logits, float(t), float(p), int(seed))
+        toks.append(tok)
+        coins.append(coin)
+    S.close()
+    np.savez_compressed(os.path.join(GOLD, "sampler.npz"), token=np.array(toks, np.int32), coin=np.array(coins, np.float32),
+                        temperature=np.array([c_[1] for c_ in cases], np.float32), top_p=np.array([c_[2] for c_ in cases], np.float32),
+                        seed=np.array([c_[3] for c_ in cases], np.int32), logits_crc=np.array([int(np.sum(c_[0].view(np.uint32) % 65521)) for c_ in cases], np.int64))
+    print("sampler ok", toks[:8])
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     orc.build()
     R = orc.Ref()
     R.set_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == "sampler":
+        gen_sampler(R)
+        sys.exit(0)
     gen_ops(R)
     gen_models(R)
+    gen_sampler(R)
