@@ -135,6 +135,7 @@ int gemv_launch(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& host);
 struct StepParams {
   int token, pos, kv_sink, kv_pos, kv_len;
   float temperature, top_p, coin;  // dsk_forward_sample (Sampler::sample's arguments + its one random draw)
+  int prob_index;                  // >= 0: dsk_forward_prob (Sampler::sample_prob of this index) instead of sampling
   float rope_cs[2 * 64];   // cos,sin for pair j at `pos` (host libm: powf/cosf/sinf, src/infer.cpp:655-658)
   float rope_cs1[2 * 64];  // same for pos = 1 (attention-sink rotation, src/infer.cpp:1015)
 };

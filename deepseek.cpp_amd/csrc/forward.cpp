@@ -588,8 +588,23 @@ extern "C" int dsk_forward_sample(dsk_model* m, int token, int pos, float temper
   m->sp_host->temperature = temperature;
   m->sp_host->top_p = top_p;
   m->sp_host->coin = coin;
+  m->sp_host->prob_index = -1;
   DSK_TRY(run_token(m, token, pos, MODE_SAMPLE));
   *next_token = *m->argmax_host;
+  return DSK_OK;
+}
+
+// Sampler::sample_prob (src/sampler.cpp:12-26) on the device: the softmax probability of `index` under the logits of
+// this step -- what run_perplexity accumulates per token (src/main.cpp:386-401) -- without the logits leaving the GPU.
+extern "C" int dsk_forward_prob(dsk_model* m, int token, int pos, int index, float* prob) {
+  DSK_TRY(check_forward_args(m, token, pos, DSK_MODE_OUTPUT_LOGITS, m ? m->logits_host : nullptr));
+  if (!prob || index < 0 || index >= m->c.vocab_size) DSK_FAIL(DSK_ERR_INVALID, "forward_prob: bad index %d", index);
+  m->sp_host->temperature = 1.0f;
+  m->sp_host->top_p = 1.0f;
+  m->sp_host->coin = 0.0f;
+  m->sp_host->prob_index = index;
+  DSK_TRY(run_token(m, token, pos, MODE_SAMPLE));
+  memcpy(prob, m->argmax_host, 4);
   return DSK_OK;
 }
 

@@ -268,6 +268,10 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
   __syncthreads();
   const float S = (red[0] + red[1]) + (red[2] + red[3]);  // :53-56
   if (wave != 0) return;
+  if (sp ? sp->prob_index >= 0 : false) {  // Sampler::sample_prob (:12-26): softmax probability of one index (temperature 1)
+    if (lane == 0) reinterpret_cast<float*>(out)[0] = expf((logits[sp->prob_index] - M) / temperature) / S;
+    return;
+  }
   const float r = coin * top_p;  // :65
   // which segment: lane l owns segments [l * SPL, +SPL)
   const int SPL = (nseg + 63) >> 6;

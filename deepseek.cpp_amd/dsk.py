@@ -346,6 +346,13 @@ class Model:
         check(f(self.h, token, pos, temperature, top_p, coin, C.byref(nxt)))
         return nxt.value
 
+    def forward_prob(self, token: int, pos: int, index: int) -> float:
+        pr = C.c_float()
+        f = lib().dsk_forward_prob
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
+        check(f(self.h, token, pos, index, C.byref(pr)))
+        return float(pr.value)
+
     def forward_argmax(self, token: int, pos: int) -> int:
         nxt = C.c_int32()
         check(lib().dsk_forward_argmax(self.h, token, pos, C.byref(nxt)))

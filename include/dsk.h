@@ -209,6 +209,9 @@ int dsk_forward_argmax(dsk_model* m, int token, int pos, int32_t* next_token);
    device sums in a fixed tree, so the token equals the reference's unless coin * top_p falls within ~1e-5 of a
    boundary of the cumulative distribution. */
 int dsk_forward_sample(dsk_model* m, int token, int pos, float temperature, float top_p, float coin, int32_t* next_token);
+/* Sampler::sample_prob (src/sampler.cpp:12-26) on the device: softmax probability of `index` under this step's logits,
+   i.e. what run_perplexity sums per token (src/main.cpp:386-401); 4 bytes cross PCIe. */
+int dsk_forward_prob(dsk_model* m, int token, int pos, int index, float* prob);
 int dsk_model_set_graph(dsk_model* m, int enable);
 
 /* Algorithmic HBM bytes one forward at `pos` must touch, with true block sizes
