@@ -42,6 +42,13 @@ def test_config_struct_layout_matches_header():
     assert dsk.DskConfig.rs_original_max_position_embeddings.offset == off_rs
     from oracle import orc
     assert C.sizeof(orc.DskConfig) == size
+    prog = '#include <stdio.h>\n#include "dsk.h"\nint main(){printf("%zu %zu %zu", sizeof(dsk_load_stats), ' \
+           '__builtin_offsetof(dsk_load_stats, seconds), __builtin_offsetof(dsk_load_stats, n_tensors));}'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(prog)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
+        size, off_s, off_n = map(int, subprocess.check_output([os.path.join(d, "t")]).split())
+    assert (C.sizeof(dsk.LoadStats), dsk.LoadStats.seconds.offset, dsk.LoadStats.n_tensors.offset) == (size, off_s, off_n)
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
