@@ -439,3 +439,20 @@ def test_forward_prob_is_the_softmax_probability_of_the_index(ctx):
         B.forward_prob(3, 0, c.vocab_size)
     A.close()
     B.close()
+
+
+@pytest.mark.parametrize("quant,mla", [("fp16", False), ("f8e5m2", True)], ids=["fp16-mha", "f8e5m2-mla"])
+def test_dseek_loader_vs_the_reference_reading_the_same_files(ctx, ref, tmp_path, quant, mla):
+    """The same checkpoint directory read by the reference (YALMData + Model, oracle/_ref) and by dsk_model_load_dseek:
+    float paths, logits within 1e-3, identical routing, token by token."""
+    import dsk
+    c = synth.preset("tiny_v3", quant, mla)
+    d = str(tmp_path / "ckpt")
+    synth.write_dseek(d, c, synth.synth_model(c, seed=24), shards=2)
+    M, S = dsk.Model.from_dseek(ctx, d), ref.session(d, c)
+    for pos, tok in enumerate([11, 250, 3, 77, 512]):
+        lh, lr = M.forward(tok, pos), S.forward(tok, pos)
+        assert rel_inf(lh, lr) < 1e-3, pos
+        assert np.array_equal(M.routing()[0], S.routing()[0]), pos
+    M.close()
+    S.close()
