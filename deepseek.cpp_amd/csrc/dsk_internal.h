@@ -192,6 +192,10 @@ struct RouterArgs {       // F32 router GEMV (+ optional rmsnorm prologue) + moe
   int dbg;                // micro-benchmark only: 1 = skip the gate, 2 = skip the weight stream, 4 = skip the norm
 };
 int launch_router_gate(hipStream_t st, const RouterArgs& a);
+struct GemvLaunch;
+// the router launch that also runs the shared expert's w1/w3 GLU (kernels_gemv.hip router_shared_kernel)
+bool router_shared_supported(const RouterArgs& a, const GemvLaunch& h);
+int launch_router_shared(hipStream_t st, const RouterArgs& a, const GemvLaunch* dev, const GemvLaunch& h);
 int launch_gate(hipStream_t st, const float* partial, int ksplit, const float* bias, int n_routed, int n_active,
                 int norm_topk_prob, float scaling, int scoring, int topk_method, int n_group, int topk_group,
                 int* active_experts, float* active_weights, float* scores_out);

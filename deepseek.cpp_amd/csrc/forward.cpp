@@ -133,7 +133,7 @@ int build_plans(dsk_model* m) {
   const int shared_n = c.n_shared_experts * mi;
   const int hb_stride = std::max(std::max(mi, shared_n), 1);
   m->lp_qkv_a.assign(nl, -1); m->lp_qkv_b.assign(nl, -1); m->lp_wv_b.assign(nl, -1); m->lp_wo.assign(nl, -1);
-  m->lp_w13.assign(nl, -1); m->lp_w2.assign(nl, -1);
+  m->lp_w13.assign(nl, -1); m->lp_w2.assign(nl, -1); m->lp_sh13.assign(nl, -1);
   m->plans.clear();
   m->head_attn.assign(nl, HeadAttnArgs());
   m->mla_head.assign(nl, MlaHeadArgs());
@@ -296,7 +296,29 @@ int build_plans(dsk_model* m) {
         task_out_hb(m, T, l, (size_t)k * hb_stride);
       }
       double bytes = K * e13 + c.dim * 8.0 + 4.0 * K * mi;
-      if (c.n_shared_experts > 0) {
+      // 1 GPU, K-quants: the shared expert's w1/w3 rides in the router launch (router_shared_kernel) instead
+      bool ride = false;
+      if (c.n_shared_experts > 0 && kq && c.dim % 256 == 0 && m->ctx->world == 1 && !getenv("DSK_NO_FUSE_SHARED")) {
+        GemvLaunch hs;
+        memset(&hs, 0, sizeof hs);
+        hs.quant = wq; hs.glu = 1; hs.force_NW = 16;
+        GemvTask& T = hs.t[hs.n_tasks++];
+        task_weights(T, L.t[DSK_ROLE_SHARED_W1]);
+        task_weights2(T, L.t[DSK_ROLE_SHARED_W3]);
+        task_act_norm(T, m->x, L.t[DSK_ROLE_FFN_NORM], c.norm_eps);
+        task_out_hb(m, T, l, (size_t)K * hb_stride);
+        hs.algo_bytes = 2 * weight_bytes_2d(m, wq, shared_n, c.dim) + 4.0 * shared_n + c.dim * 8.0;
+        RouterArgs probe;
+        memset(&probe, 0, sizeof probe);
+        probe.ksplit = m->router_ksplit; probe.dim = c.dim; probe.norm_w = reinterpret_cast<const float*>(L.t[DSK_ROLE_FFN_NORM].qs);
+        GemvLaunch trial = hs;
+        trial.b0 = std::max(1, c.block_size[0]); trial.b1 = std::max(1, c.block_size[1]); trial.act = c.act;
+        if (gemv_plan(trial, m->target_wgs) == DSK_OK && router_shared_supported(probe, trial)) {
+          DSK_TRY(add_plan(m, hs, &m->lp_sh13[l]));
+          ride = true;
+        }
+      }
+      if (c.n_shared_experts > 0 && !ride) {
         GemvTask& T = h.t[h.n_tasks++];
         task_weights(T, L.t[DSK_ROLE_SHARED_W1]);
         task_weights2(T, L.t[DSK_ROLE_SHARED_W3]);
@@ -464,7 +486,12 @@ static int ffn(dsk_model* m, int l) {
   r.active_weights = m->route_w + (size_t)l * K;
   r.scores_out = m->gate_scores + (size_t)l * E;
   if (is_kq(c.weight_quant) && c.dim % 256 == 0) { r.q_qs = m->a_xb.qs; r.q_d = m->a_xb.d; r.q_bsums = m->a_xb.bsums; }
-  PROFILED("router_gate", (double)E * c.dim * 4 + c.dim * 8.0, launch_router_gate(st, r));
+  if (m->lp_sh13[l] >= 0) {
+    const GemvLaunch& hs = m->plans[m->lp_sh13[l]];
+    PROFILED("router_gate", (double)E * c.dim * 4 + c.dim * 8.0 + hs.algo_bytes, launch_router_shared(st, r, m->plans_dev + m->lp_sh13[l], hs));
+  } else {
+    PROFILED("router_gate", (double)E * c.dim * 4 + c.dim * 8.0, launch_router_gate(st, r));
+  }
   const bool exchange = m->ctx->world > 1 && !m->class_filter;  // (class timing enqueues one kernel class only)
   DSK_TRY(run_plan(m, "gemv_experts_w13", m->lp_w13[l]));
   DSK_TRY(run_plan(m, "gemv_experts_w2", m->lp_w2[l]));

@@ -25,6 +25,7 @@
 //   * all reductions are fixed-order shuffles: no atomics, bit-reproducible run to run.
 #include "dsk_internal.h"
 #include "attn_device.h"
+#include "router_device.h"
 #include <cstdlib>
 #include <type_traits>
 #include <hip/hip_ext.h>
@@ -295,7 +296,10 @@ struct ActSrc {
   const float* a_f32;
   const float* norm_w;
   float eps;
+  float pre_scale;  // > 0: the rmsnorm scale is already known (router_shared_kernel passes the router's own bits)
 };
+DEV float pre_scale_of(const ActSrc& s) { return s.pre_scale; }
+DEV float pre_scale_of(const GemvTask&) { return 0.f; }
 
 template <bool Q2META, int NW, typename SRC>
 DEV void stage_q8(const SRC& T, uint8_t* lds, int tid, float* scratch, unsigned long long* tl = nullptr) {
@@ -350,7 +354,8 @@ DEV void stage_q8(const SRC& T, uint8_t* lds, int tid, float* scratch, unsigned 
     if (lane == 0) scratch[wave] = ss;
     __syncthreads();
     const float total = scratch_total<NW>(scratch);
-    const float scale = 1.0f / sqrtf(total / (float)n + T.eps);
+    const float pre = pre_scale_of(T);
+    const float scale = pre > 0.f ? pre : 1.0f / sqrtf(total / (float)n + T.eps);
     if (tl && tid == 0) tl[5] = wall_clock64();
 #pragma unroll
     for (int k = 0; k < KB1; ++k) {
@@ -703,10 +708,11 @@ DEV void rows_dot_f(const WPtr& P, int n, int b0, int b1, int lpr_log2, int lane
 // the kernel.  A workgroup belongs to one activation group (tasks sharing an input vector), stages that
 // vector once, and walks its even share of the group's concatenated rows.
 // ------------------------------------------------------------------------------------
+// (a device function: router_shared_kernel below runs it for the shared expert next to the router's workgroups;
+// bid = the workgroup's index within THIS gemv's grid, h_pre_scale > 0 = a known rmsnorm scale for the hinted staging)
 template <int QT, int R, int U, bool GLU, int NW>
-__global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvLaunch* __restrict__ Lp, const void* h_a0, const void* h_a1,
-                                                         const void* h_a2, int h_n, int h_mode, float h_eps, int h_gwgs,
-                                                         int h_gstride) {
+DEV void gemv_body(const GemvLaunch* __restrict__ Lp, const void* h_a0, const void* h_a1, const void* h_a2, int h_n, int h_mode,
+                   float h_eps, int h_gwgs, int h_gstride, const int bid, const float h_pre_scale) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ float scratch[16];
   __shared__ bool comb_last;
@@ -721,33 +727,33 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvLaunch* __restr
   const bool hinted = h_n > 0;  // one activation group: its source came with the kernel arguments
   if (hinted) {
     ActSrc S;
-    S.act_mode = h_mode; S.n = h_n; S.eps = h_eps;
+    S.act_mode = h_mode; S.n = h_n; S.eps = h_eps; S.pre_scale = h_pre_scale;
     S.a_qs = static_cast<const int8_t*>(h_a0); S.a_d = static_cast<const float*>(h_a1); S.a_bsums = static_cast<const int16_t*>(h_a2);
     S.a_f32 = static_cast<const float*>(h_a0); S.norm_w = static_cast<const float*>(h_a1);
-    if (h_gwgs > 0) S.a_f32 += (size_t)((int)blockIdx.x / h_gwgs) * h_gstride;  // equal groups, equally spaced f32 vectors
+    if (h_gwgs > 0) S.a_f32 += (size_t)(bid / h_gwgs) * h_gstride;  // equal groups, equally spaced f32 vectors
     if (KQ) stage_q8<QT == DSK_QUANT_Q2_K, NW>(S, smem, tid, scratch);
     else stage_f32<NW>(S, reinterpret_cast<float*>(smem), tid, scratch);
   }
   const int RPW = 64 >> lpr_log2;
   const int rloc = lane >> lpr_log2, sub = lane & ((1 << lpr_log2) - 1);
   const int RG = NW * RPW * R;  // rows per workgroup step
-  unsigned long long* tl = L.timeline ? L.timeline + (size_t)blockIdx.x * 8 : nullptr;
+  unsigned long long* tl = L.timeline ? L.timeline + (size_t)bid * 8 : nullptr;
   if (tl && tid == 0) tl[0] = t_entry;
 
   int t0 = 0, t1 = 1, wi, nwg, head = 0;
   const bool bd = L.bd_heads > 0;
   if (bd) {  // block-diagonal stack: workgroup -> head
-    head = blockIdx.x / L.bd_wgs;
-    wi = blockIdx.x - head * L.bd_wgs;
+    head = bid / L.bd_wgs;
+    wi = bid - head * L.bd_wgs;
     nwg = L.bd_wgs;
   } else {
     int g = 0, wg0 = 0;
 #pragma unroll
     for (int k = 0; k < GEMV_MAX_TASKS - 1; ++k)
-      if (k + 1 < n_groups && (int)blockIdx.x >= L.grp_wg_end[k]) { g = k + 1; wg0 = L.grp_wg_end[k]; }
+      if (k + 1 < n_groups && bid >= L.grp_wg_end[k]) { g = k + 1; wg0 = L.grp_wg_end[k]; }
     t0 = L.grp_t0[g];
     t1 = L.grp_t0[g + 1];
-    wi = blockIdx.x - wg0;
+    wi = bid - wg0;
     nwg = L.grp_wg_end[g] - wg0;
   }
   auto task_of = [&](int ti) {
@@ -875,6 +881,32 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvLaunch* __restr
     }
   }
   if (tl && tid == 0) tl[3] = wall_clock64();
+}
+
+template <int QT, int R, int U, bool GLU, int NW>
+__global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvLaunch* __restrict__ Lp, const void* h_a0, const void* h_a1,
+                                                         const void* h_a2, int h_n, int h_mode, float h_eps, int h_gwgs,
+                                                         int h_gstride) {
+  gemv_body<QT, R, U, GLU, NW>(Lp, h_a0, h_a1, h_a2, h_n, h_mode, h_eps, h_gwgs, h_gstride, (int)blockIdx.x, 0.f);
+}
+
+// ------------------------------------------------------------------------------------
+// The router launch with the shared expert riding along (K-quant models, 1 GPU).  The router keeps E / 2 = 128 CUs busy
+// for ~10 us (a latency chain: norm, 7 MB of F32 rows, arrival, gate); the shared expert's w1/w3 GLU depends only on
+// the FFN-normed x - not on the routing - so its 64 workgroups run HERE, on CUs that would idle, instead of being the
+// ninth task of the experts' w1/w3 launch.  Workgroups [0, n_router) run router_body, the others gemv_body over the
+// one-task GLU descriptor; they normalise x with the router's own scale routine (same bits as the Q8_K vector the router
+// leaves for the routed experts), so the result is bit-identical to the unfused path.
+// ------------------------------------------------------------------------------------
+template <int QT, int U>
+__global__ __launch_bounds__(1024) void router_shared_kernel(const RouterArgs a, int n_router, const GemvLaunch* __restrict__ Lp) {
+  if ((int)blockIdx.x < n_router) {
+    rd::router_body<2>(a, (int)blockIdx.x, n_router);
+    return;
+  }
+  __shared__ float nscratch[16];
+  const float scale = rd::router_norm_scale(a, threadIdx.x, nscratch);
+  gemv_body<QT, 1, U, true, 16>(Lp, a.x, a.norm_w, nullptr, a.dim, ACT_F32_NORM, a.eps, 0, 0, (int)blockIdx.x - n_router, scale);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1353,6 +1385,33 @@ static int launch_q(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& h) 
 template <int QT>
 static int launch_nw(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& h) {
   return h.NW == 16 ? launch_q<QT, 16>(st, dev, h) : launch_q<QT, 4>(st, dev, h);
+}
+
+// router + shared expert in one launch; h = the planned one-task GLU descriptor of the shared expert's w1/w3
+bool router_shared_supported(const RouterArgs& a, const GemvLaunch& h) {
+  const bool q2 = h.quant == DSK_QUANT_Q2_K, q3 = h.quant == DSK_QUANT_Q3_K;
+  return (q2 || q3) && a.ksplit >= 8 && a.norm_w && h.glu && h.n_tasks == 1 && h.n_groups == 1 && h.bd_heads == 0 && h.NW == 16 && h.R == 1 &&
+         (h.U == 2 || (q2 && h.U == 4)) && h.t[0].act_mode == ACT_F32_NORM && h.t[0].n == a.dim && (a.dim >> 8) <= 32 && !h.comb_x;
+}
+int launch_router_shared(hipStream_t st, const RouterArgs& a, const GemvLaunch* dev, const GemvLaunch& h) {
+  if (!router_shared_supported(a, h)) DSK_FAIL(DSK_ERR_INVALID, "router_shared: unsupported plan");
+  const int n_router = (a.n_routed + 1) / 2;
+  dim3 grid(n_router + h.grid), block(1024);
+  const size_t lds = h.lds_bytes;
+#define RS_LAUNCH(QT, U)                                                                                             \
+  do {                                                                                                               \
+    auto k = router_shared_kernel<QT, U>;                                                                            \
+    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+    hipLaunchKernelGGL(k, grid, block, lds, st, a, n_router, dev);                                                   \
+  } while (0)
+  if (h.quant == DSK_QUANT_Q2_K) {
+    if (h.U == 4) RS_LAUNCH(DSK_QUANT_Q2_K, 4);
+    else RS_LAUNCH(DSK_QUANT_Q2_K, 2);
+  } else {
+    RS_LAUNCH(DSK_QUANT_Q3_K, 2);  // (4 column steps in flight spill at 16 waves, like the plain GLU variant)
+  }
+#undef RS_LAUNCH
+  return DSK_OK;
 }
 
 int gemv_launch(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& h) {

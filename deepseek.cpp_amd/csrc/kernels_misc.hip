@@ -3,6 +3,7 @@
 // decode attention (MHA and latent MLA), the MoE router + top-k gate, embedding-row dequant,
 // upload-time re-layout of K-quant blocks, synthetic-weight fills and the bandwidth probe.
 #include "dsk_internal.h"
+#include "router_device.h"
 #include <math.h>
 
 typedef unsigned int u32;
@@ -560,115 +561,7 @@ int launch_embed(hipStream_t st, const DTensor& t, const StepParams* sp, int tok
   return DSK_OK;
 }
 
-// ------------------------------------------------------------------------------------
-// MoE router + gate in ONE launch.
-// Router: F32 GEMV (src/infer.cpp:847, 121-157) over the FFN-normed x (the rmsnorm of
-// src/infer.cpp:839 is recomputed in every workgroup's prologue: 28 KB from L2), split over K so
-// that E = 256 rows still fill the chip; partial[c][e] are summed in c order (deterministic).
-// Gate: the LAST workgroup to arrive (agent-scope release -> relaxed counter -> acquire) runs
-// moe_gate, src/infer.cpp:493-599.  The reference's k rounds of "argmax over unmasked with strict >"
-// select experts in descending score order, lowest index first among equals; that is the rank of
-// e under the order (score desc, index asc), computed by all E threads in parallel:
-//   rank(e) = #{ j : s[j] > s[e] or (s[j] == s[e] and j < e) }.
-// Group-limited (:545-588): first keep the topk_group best of every group, then rank the
-// survivors globally.  Weights: x[e_k] / wsum * scaling with wsum accumulated in k order.
-// ------------------------------------------------------------------------------------
-DEV void gate_body(int e, float v, const float* __restrict__ bias, int E, int K, int norm_topk_prob, float scaling, int scoring,
-                   int topk_method, int n_group, int topk_group, int* __restrict__ active_experts,
-                   float* __restrict__ active_weights, float* __restrict__ scores_out, float* s, int* ci, int* sel, float* scratch,
-                   int nthreads = 256) {
-  // s[256]: scores; cs (aliases scratch area passed as `s + 256`) / ci[256]: compacted candidates.
-  // Called by every thread of the workgroup (barriers inside); threads >= 256 only take part in those.
-  float* cs = s + 256;
-  if (e >= E) v = -INFINITY;
-  if (scoring == DSK_SCORE_SOFTMAX) {  // softmax, src/infer.cpp:472-487
-    const float mx = block_max(v, scratch, e, nthreads);
-    const float ex = e < E ? expf(v - mx) : 0.f;
-    const float sum = block_sum(ex, scratch, e, nthreads);
-    v = ex / sum;
-  } else {
-    v = 1.0f / (1.0f + expf(-v));  // sigmoid, src/infer.cpp:489-491
-  }
-  if (bias && e < E) v += bias[e];
-  if (e >= E) v = -INFINITY;
-  if (e < 256) {
-    s[e] = v;
-    cs[e] = -INFINITY;
-    ci[e] = 0x7fffffff;
-  }
-  if (e < E && scores_out) scores_out[e] = v;
-  __syncthreads();
-  // candidates, compacted: a wave64 VALU op takes 4 cycles, so the serial compare loops below are the
-  // critical path of the whole launch -- they must run over the candidates only, not over all E
-  int ncand = E;
-  if (topk_method == DSK_TOPK_GROUP_LIMITED_GREEDY) {
-    const int gs = E / n_group, tg = topk_group < gs ? topk_group : gs;
-    ncand = n_group * tg;
-    if (e < E) {
-      const int g = e / gs, g0 = g * gs;
-      int rank = 0;
-      if ((gs & 3) == 0) {  // group starts are multiples of 4: 16-byte LDS reads
-        for (int j = g0; j < g0 + gs; j += 4) {
-          const f32x4 sv = *reinterpret_cast<const f32x4*>(s + j);
-          rank += (sv.x > v || (sv.x == v && j + 0 < e)) ? 1 : 0;
-          rank += (sv.y > v || (sv.y == v && j + 1 < e)) ? 1 : 0;
-          rank += (sv.z > v || (sv.z == v && j + 2 < e)) ? 1 : 0;
-          rank += (sv.w > v || (sv.w == v && j + 3 < e)) ? 1 : 0;
-        }
-      } else {
-        for (int j = g0; j < g0 + gs; ++j) {
-          const float sj = s[j];
-          rank += (sj > v || (sj == v && j < e)) ? 1 : 0;
-        }
-      }
-      if (rank < tg) {  // survivor: (group, in-group rank) is a unique slot
-        cs[g * tg + rank] = v;
-        ci[g * tg + rank] = e;
-      }
-    }
-  } else if (e < E) {
-    cs[e] = v;
-    ci[e] = e;
-  }
-  __syncthreads();
-  if (e < ncand) {
-    const float v2 = cs[e];
-    const int i2 = ci[e];
-    int rank = 0;
-    for (int j0 = 0; j0 < ncand; j0 += 4) {  // arrays are padded with (-inf, INT_MAX) up to 256
-      const f32x4 sv = *reinterpret_cast<const f32x4*>(cs + j0);
-      const u32x4 iv = *reinterpret_cast<const u32x4*>(ci + j0);
-      rank += (sv.x > v2 || (sv.x == v2 && (int)iv.x < i2)) ? 1 : 0;
-      rank += (sv.y > v2 || (sv.y == v2 && (int)iv.y < i2)) ? 1 : 0;
-      rank += (sv.z > v2 || (sv.z == v2 && (int)iv.z < i2)) ? 1 : 0;
-      rank += (sv.w > v2 || (sv.w == v2 && (int)iv.w < i2)) ? 1 : 0;
-    }
-    if (rank < K && i2 < E) sel[rank] = i2;
-  }
-  __syncthreads();
-  if (K > 64) {  // (never the case for a DeepSeek config; kept for the op-level entry point)
-    if (e == 0) {
-      float wsum = 0.f;
-      for (int k = 0; k < K; ++k) wsum += s[sel[k]];
-      if (!norm_topk_prob) wsum = 1.0f;
-      for (int k = 0; k < K; ++k) {
-        active_experts[k] = sel[k];
-        active_weights[k] = s[sel[k]] / wsum * scaling;
-      }
-    }
-  } else if (e < 64) {  // weights: x[e_k] / wsum * scaling, wsum accumulated in k order (src/infer.cpp:590-598)
-    const int ek = e < K ? sel[e] : 0;
-    const float sk = e < K ? s[ek] : 0.f;
-    float wsum = 0.f;
-    for (int k = 0; k < K; ++k) wsum += __shfl(sk, k);
-    if (!norm_topk_prob) wsum = 1.0f;
-    if (e < K) {
-      active_experts[e] = ek;
-      active_weights[e] = sk / wsum * scaling;
-    }
-  }
-}
-
+// gate_body / router_body live in router_device.h (shared with kernels_gemv.hip)
 __global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ partial, int ksplit, const float* __restrict__ bias,
                                                    int E, int K, int norm_topk_prob, float scaling, int scoring, int topk_method,
                                                    int n_group, int topk_group, int* __restrict__ active_experts,
@@ -681,7 +574,7 @@ __global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ par
   float v = 0.f;
   if (e < E)
     for (int c = 0; c < ksplit; ++c) v += partial[(size_t)c * E + e];
-  gate_body(e, v, bias, E, K, norm_topk_prob, scaling, scoring, topk_method, n_group, topk_group, active_experts, active_weights,
+  rd::gate_body(e, v, bias, E, K, norm_topk_prob, scaling, scoring, topk_method, n_group, topk_group, active_experts, active_weights,
             scores_out, s, surv, sel, scratch);
 }
 int launch_gate(hipStream_t st, const float* partial, int ksplit, const float* bias, int n_routed, int n_active,
@@ -715,111 +608,9 @@ DEV float wave_sum_dpp(float v) {
   return (a + b) + (c + d);
 }
 
-// 16-wave workgroups: RW rows x (16 / RW) column slices each, slices summed in LDS in slice order, so
-// one launch is E / RW workgroups = E / RW arrivals on the counter (256 arrivals on one address cost 2 us)
 template <int RW>
 __global__ __launch_bounds__(1024) void router_gate_kernel(RouterArgs a) {
-  constexpr int SL = 16 / RW;
-  __shared__ __attribute__((aligned(16))) float s[512];
-  __shared__ __attribute__((aligned(16))) int surv[256];
-  __shared__ float scratch[16];
-  __shared__ float part[16];
-  __shared__ int sel[256];
-  __shared__ int is_last;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = wave % RW, sl = wave / RW;
-  const int row = blockIdx.x * RW + r;
-  const int dim = a.dim, E = a.n_routed;
-  float scale = 1.0f;
-  if (a.norm_w && !(a.dbg & 4)) {  // rmsnorm of the residual stream (src/infer.cpp:839, 601-611), once per workgroup
-    float ss = 0.f;
-    for (int i0 = tid * 4; i0 < dim; i0 += 4 * 4096) {
-      f32x4 v[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (i0 + k * 4096 < dim) v[k] = *reinterpret_cast<const f32x4*>(a.x + i0 + k * 4096);
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (i0 + k * 4096 < dim) {
-          ss = fmaf(v[k].x, v[k].x, ss);
-          ss = fmaf(v[k].y, v[k].y, ss);
-          ss = fmaf(v[k].z, v[k].z, ss);
-          ss = fmaf(v[k].w, v[k].w, ss);
-        }
-    }
-    ss = wave_sum_dpp(ss);
-    if (lane == 0) scratch[wave] = ss;
-    __syncthreads();
-    float total = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; i += 4) total += (scratch[i] + scratch[i + 1]) + (scratch[i + 2] + scratch[i + 3]);
-    scale = 1.0f / sqrtf(total / (float)dim + a.eps);
-    __syncthreads();
-  }
-  float acc = 0.f;
-  if (row < E && !(a.dbg & 2)) {
-    const int chunk = ((dim / 4 + SL - 1) / SL + 63) / 64 * 64 * 4;  // floats per column slice, multiple of 256
-    const int k0 = sl * chunk, k1 = min(dim, k0 + chunk);
-    const float* wr = a.w + (size_t)row * dim;
-    for (int i0 = k0 + lane * 4; i0 < k1; i0 += 8 * 256) {  // 8 weight loads in flight per lane
-      f32x4 wv[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k)
-        if (i0 + k * 256 < k1) wv[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wr + i0 + k * 256));
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int i = i0 + k * 256;
-        if (i < k1) {
-          f32x4 y = *reinterpret_cast<const f32x4*>(a.x + i);
-          if (a.norm_w) {
-            const f32x4 nw = *reinterpret_cast<const f32x4*>(a.norm_w + i);
-            y.x = y.x * scale * nw.x;
-            y.y = y.y * scale * nw.y;
-            y.z = y.z * scale * nw.z;
-            y.w = y.w * scale * nw.w;
-          }
-          acc = fmaf(wv[k].x, y.x, acc);
-          acc = fmaf(wv[k].y, y.y, acc);
-          acc = fmaf(wv[k].z, y.z, acc);
-          acc = fmaf(wv[k].w, y.w, acc);
-        }
-      }
-    }
-    acc = wave_sum_dpp(acc);
-  }
-  if (a.q_qs && a.norm_w && wave == 0) {  // Q8_K of rmsnorm(x): block b by workgroup b (src/quant.cpp:616-653)
-    for (int b = blockIdx.x; b < dim / 256; b += gridDim.x) {
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(a.x + b * 256 + lane * 4);
-      const f32x4 nw = *reinterpret_cast<const f32x4*>(a.norm_w + b * 256 + lane * 4);
-      const float v[4] = {xv.x * scale * nw.x, xv.y * scale * nw.y, xv.z * scale * nw.z, xv.w * scale * nw.w};
-      q8k_block(v, lane, a.q_qs + (size_t)b * 256, a.q_d + b, a.q_bsums + (size_t)b * 16);
-    }
-  }
-  if (lane == 0) part[wave] = acc;
-  __syncthreads();
-  if (tid < RW && blockIdx.x * RW + tid < E) {
-    float v = 0.f;
-#pragma unroll
-    for (int k = 0; k < SL; ++k) v += part[k * RW + tid];  // slice order: deterministic
-    // write-through (sc1) store: visible across XCDs once vmcnt drains, no L2 write-back fence needed
-    __hip_atomic_store(a.partial + blockIdx.x * RW + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  // ---- publish the scores; the last workgroup to arrive runs the gate ----
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) {
-    const unsigned old = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = old == gridDim.x - 1;
-    if (is_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-  __syncthreads();
-  if (!is_last) return;
-  if (a.dbg & 1) { if (tid == 0) *a.counter = 0; return; }
-  if (tid == 0) __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
-  float v = 0.f;
-  if (tid < E) v = __hip_atomic_load(a.partial + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  gate_body(tid, v, a.bias, E, a.n_active, a.norm_topk_prob, a.scaling, a.scoring, a.topk_method, a.n_group, a.topk_group,
-            a.active_experts, a.active_weights, a.scores_out, s, surv, sel, scratch, 1024);
+  rd::router_body<RW>(a, blockIdx.x, gridDim.x);
 }
 int launch_router_gate(hipStream_t st, const RouterArgs& a) {
   if (a.dim % 4) DSK_FAIL(DSK_ERR_INVALID, "router: dim %% 4 != 0");

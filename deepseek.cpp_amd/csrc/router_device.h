@@ -1,0 +1,263 @@
+// router_device.h -- the MoE router + gate as device functions, shared by kernels_misc.hip (router_gate_kernel,
+// gate_kernel) and kernels_gemv.hip (router_shared_kernel: the router launch that also carries the shared expert's
+// w1/w3 GLU on the CUs the router leaves idle).
+#pragma once
+#include "attn_device.h"
+
+namespace rd {
+using ad::q8k_block;
+using ad::wave_sum_dpp;
+typedef ad::f32x4 f32x4;
+typedef ad::u32x4 u32x4;
+#define RDEV __device__ __forceinline__
+
+// block-wide reductions through a small LDS scratch (xor-shuffle wave trees: the order the gate has always used)
+RDEV float block_sum(float v, float* scratch, int tid, int nthreads) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  const int nw = nthreads >> 6;
+  __syncthreads();
+  if ((tid & 63) == 0) scratch[tid >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += scratch[i];
+  return t;
+}
+RDEV float block_max(float v, float* scratch, int tid, int nthreads) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+  const int nw = nthreads >> 6;
+  __syncthreads();
+  if ((tid & 63) == 0) scratch[tid >> 6] = v;
+  __syncthreads();
+  float t = scratch[0];
+  for (int i = 1; i < nw; ++i) t = fmaxf(t, scratch[i]);
+  return t;
+}
+
+// ------------------------------------------------------------------------------------
+// MoE router + gate in ONE launch.
+// Router: F32 GEMV (src/infer.cpp:847, 121-157) over the FFN-normed x (the rmsnorm of
+// src/infer.cpp:839 is recomputed in every workgroup's prologue: 28 KB from L2), split over K so
+// that E = 256 rows still fill the chip; partial[c][e] are summed in c order (deterministic).
+// Gate: the LAST workgroup to arrive (agent-scope release -> relaxed counter -> acquire) runs
+// moe_gate, src/infer.cpp:493-599.  The reference's k rounds of "argmax over unmasked with strict >"
+// select experts in descending score order, lowest index first among equals; that is the rank of
+// e under the order (score desc, index asc), computed by all E threads in parallel:
+//   rank(e) = #{ j : s[j] > s[e] or (s[j] == s[e] and j < e) }.
+// Group-limited (:545-588): first keep the topk_group best of every group, then rank the
+// survivors globally.  Weights: x[e_k] / wsum * scaling with wsum accumulated in k order.
+// ------------------------------------------------------------------------------------
+RDEV void gate_body(int e, float v, const float* __restrict__ bias, int E, int K, int norm_topk_prob, float scaling, int scoring,
+                   int topk_method, int n_group, int topk_group, int* __restrict__ active_experts,
+                   float* __restrict__ active_weights, float* __restrict__ scores_out, float* s, int* ci, int* sel, float* scratch,
+                   int nthreads = 256) {
+  // s[256]: scores; cs (aliases scratch area passed as `s + 256`) / ci[256]: compacted candidates.
+  // Called by every thread of the workgroup (barriers inside); threads >= 256 only take part in those.
+  float* cs = s + 256;
+  if (e >= E) v = -INFINITY;
+  if (scoring == DSK_SCORE_SOFTMAX) {  // softmax, src/infer.cpp:472-487
+    const float mx = block_max(v, scratch, e, nthreads);
+    const float ex = e < E ? expf(v - mx) : 0.f;
+    const float sum = block_sum(ex, scratch, e, nthreads);
+    v = ex / sum;
+  } else {
+    v = 1.0f / (1.0f + expf(-v));  // sigmoid, src/infer.cpp:489-491
+  }
+  if (bias && e < E) v += bias[e];
+  if (e >= E) v = -INFINITY;
+  if (e < 256) {
+    s[e] = v;
+    cs[e] = -INFINITY;
+    ci[e] = 0x7fffffff;
+  }
+  if (e < E && scores_out) scores_out[e] = v;
+  __syncthreads();
+  // candidates, compacted: a wave64 VALU op takes 4 cycles, so the serial compare loops below are the
+  // critical path of the whole launch -- they must run over the candidates only, not over all E
+  int ncand = E;
+  if (topk_method == DSK_TOPK_GROUP_LIMITED_GREEDY) {
+    const int gs = E / n_group, tg = topk_group < gs ? topk_group : gs;
+    ncand = n_group * tg;
+    if (e < E) {
+      const int g = e / gs, g0 = g * gs;
+      int rank = 0;
+      if ((gs & 3) == 0) {  // group starts are multiples of 4: 16-byte LDS reads
+        for (int j = g0; j < g0 + gs; j += 4) {
+          const f32x4 sv = *reinterpret_cast<const f32x4*>(s + j);
+          rank += (sv.x > v || (sv.x == v && j + 0 < e)) ? 1 : 0;
+          rank += (sv.y > v || (sv.y == v && j + 1 < e)) ? 1 : 0;
+          rank += (sv.z > v || (sv.z == v && j + 2 < e)) ? 1 : 0;
+          rank += (sv.w > v || (sv.w == v && j + 3 < e)) ? 1 : 0;
+        }
+      } else {
+        for (int j = g0; j < g0 + gs; ++j) {
+          const float sj = s[j];
+          rank += (sj > v || (sj == v && j < e)) ? 1 : 0;
+        }
+      }
+      if (rank < tg) {  // survivor: (group, in-group rank) is a unique slot
+        cs[g * tg + rank] = v;
+        ci[g * tg + rank] = e;
+      }
+    }
+  } else if (e < E) {
+    cs[e] = v;
+    ci[e] = e;
+  }
+  __syncthreads();
+  if (e < ncand) {
+    const float v2 = cs[e];
+    const int i2 = ci[e];
+    int rank = 0;
+    for (int j0 = 0; j0 < ncand; j0 += 4) {  // arrays are padded with (-inf, INT_MAX) up to 256
+      const f32x4 sv = *reinterpret_cast<const f32x4*>(cs + j0);
+      const u32x4 iv = *reinterpret_cast<const u32x4*>(ci + j0);
+      rank += (sv.x > v2 || (sv.x == v2 && (int)iv.x < i2)) ? 1 : 0;
+      rank += (sv.y > v2 || (sv.y == v2 && (int)iv.y < i2)) ? 1 : 0;
+      rank += (sv.z > v2 || (sv.z == v2 && (int)iv.z < i2)) ? 1 : 0;
+      rank += (sv.w > v2 || (sv.w == v2 && (int)iv.w < i2)) ? 1 : 0;
+    }
+    if (rank < K && i2 < E) sel[rank] = i2;
+  }
+  __syncthreads();
+  if (K > 64) {  // (never the case for a DeepSeek config; kept for the op-level entry point)
+    if (e == 0) {
+      float wsum = 0.f;
+      for (int k = 0; k < K; ++k) wsum += s[sel[k]];
+      if (!norm_topk_prob) wsum = 1.0f;
+      for (int k = 0; k < K; ++k) {
+        active_experts[k] = sel[k];
+        active_weights[k] = s[sel[k]] / wsum * scaling;
+      }
+    }
+  } else if (e < 64) {  // weights: x[e_k] / wsum * scaling, wsum accumulated in k order (src/infer.cpp:590-598)
+    const int ek = e < K ? sel[e] : 0;
+    const float sk = e < K ? s[ek] : 0.f;
+    float wsum = 0.f;
+    for (int k = 0; k < K; ++k) wsum += __shfl(sk, k);
+    if (!norm_topk_prob) wsum = 1.0f;
+    if (e < K) {
+      active_experts[e] = ek;
+      active_weights[e] = sk / wsum * scaling;
+    }
+  }
+}
+
+
+// rmsnorm scale of the residual stream (src/infer.cpp:839, 601-611), computed by a whole 1024-thread workgroup; every
+// caller gets the same bits (the shared expert's launch-mates quantise x with exactly the router's scale)
+RDEV float router_norm_scale(const RouterArgs& a, int tid, float* scratch) {
+  const int lane = tid & 63, wave = tid >> 6, dim = a.dim;
+  float scale = 1.0f;
+  {
+    float ss = 0.f;
+    for (int i0 = tid * 4; i0 < dim; i0 += 4 * 4096) {
+      f32x4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (i0 + k * 4096 < dim) v[k] = *reinterpret_cast<const f32x4*>(a.x + i0 + k * 4096);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (i0 + k * 4096 < dim) {
+          ss = fmaf(v[k].x, v[k].x, ss);
+          ss = fmaf(v[k].y, v[k].y, ss);
+          ss = fmaf(v[k].z, v[k].z, ss);
+          ss = fmaf(v[k].w, v[k].w, ss);
+        }
+    }
+    ss = wave_sum_dpp(ss);
+    if (lane == 0) scratch[wave] = ss;
+    __syncthreads();
+    float total = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i += 4) total += (scratch[i] + scratch[i + 1]) + (scratch[i + 2] + scratch[i + 3]);
+    scale = 1.0f / sqrtf(total / (float)dim + a.eps);
+    __syncthreads();
+  }
+  return scale;
+}
+
+// 16-wave workgroups: RW rows x (16 / RW) column slices each, slices summed in LDS in slice order, so
+// one launch is E / RW workgroups = E / RW arrivals on the counter (256 arrivals on one address cost 2 us).
+// bid / nblocks: this workgroup's index among the router workgroups of the launch, and their number
+template <int RW>
+RDEV void router_body(const RouterArgs& a, int bid, int nblocks) {
+  constexpr int SL = 16 / RW;
+  __shared__ __attribute__((aligned(16))) float s[512];
+  __shared__ __attribute__((aligned(16))) int surv[256];
+  __shared__ float scratch[16];
+  __shared__ float part[16];
+  __shared__ int sel[256];
+  __shared__ int is_last;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = wave % RW, sl = wave / RW;
+  const int row = bid * RW + r;
+  const int dim = a.dim, E = a.n_routed;
+  const float scale = a.norm_w && !(a.dbg & 4) ? router_norm_scale(a, tid, scratch) : 1.0f;
+  float acc = 0.f;
+  if (row < E && !(a.dbg & 2)) {
+    const int chunk = ((dim / 4 + SL - 1) / SL + 63) / 64 * 64 * 4;  // floats per column slice, multiple of 256
+    const int k0 = sl * chunk, k1 = min(dim, k0 + chunk);
+    const float* wr = a.w + (size_t)row * dim;
+    for (int i0 = k0 + lane * 4; i0 < k1; i0 += 8 * 256) {  // 8 weight loads in flight per lane
+      f32x4 wv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (i0 + k * 256 < k1) wv[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wr + i0 + k * 256));
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int i = i0 + k * 256;
+        if (i < k1) {
+          f32x4 y = *reinterpret_cast<const f32x4*>(a.x + i);
+          if (a.norm_w) {
+            const f32x4 nw = *reinterpret_cast<const f32x4*>(a.norm_w + i);
+            y.x = y.x * scale * nw.x;
+            y.y = y.y * scale * nw.y;
+            y.z = y.z * scale * nw.z;
+            y.w = y.w * scale * nw.w;
+          }
+          acc = fmaf(wv[k].x, y.x, acc);
+          acc = fmaf(wv[k].y, y.y, acc);
+          acc = fmaf(wv[k].z, y.z, acc);
+          acc = fmaf(wv[k].w, y.w, acc);
+        }
+      }
+    }
+    acc = wave_sum_dpp(acc);
+  }
+  if (a.q_qs && a.norm_w && wave == 0) {  // Q8_K of rmsnorm(x): block b by workgroup b (src/quant.cpp:616-653)
+    for (int b = bid; b < dim / 256; b += nblocks) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(a.x + b * 256 + lane * 4);
+      const f32x4 nw = *reinterpret_cast<const f32x4*>(a.norm_w + b * 256 + lane * 4);
+      const float v[4] = {xv.x * scale * nw.x, xv.y * scale * nw.y, xv.z * scale * nw.z, xv.w * scale * nw.w};
+      q8k_block(v, lane, a.q_qs + (size_t)b * 256, a.q_d + b, a.q_bsums + (size_t)b * 16);
+    }
+  }
+  if (lane == 0) part[wave] = acc;
+  __syncthreads();
+  if (tid < RW && bid * RW + tid < E) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < SL; ++k) v += part[k * RW + tid];  // slice order: deterministic
+    // write-through (sc1) store: visible across XCDs once vmcnt drains, no L2 write-back fence needed
+    __hip_atomic_store(a.partial + bid * RW + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // ---- publish the scores; the last workgroup to arrive runs the gate ----
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned old = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = old == (unsigned)nblocks - 1;
+    if (is_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  if (!is_last) return;
+  if (a.dbg & 1) { if (tid == 0) *a.counter = 0; return; }
+  if (tid == 0) __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
+  float v = 0.f;
+  if (tid < E) v = __hip_atomic_load(a.partial + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  gate_body(tid, v, a.bias, E, a.n_active, a.norm_topk_prob, a.scaling, a.scoring, a.topk_method, a.n_group, a.topk_group,
+            a.active_experts, a.active_weights, a.scores_out, s, surv, sel, scratch, 1024);
+}
+}  // namespace rd

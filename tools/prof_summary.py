@@ -23,7 +23,7 @@ CLASS_KERNEL = {
     "gemv_dense_w13": "gemv_kernel<3, 1, 4, true, 16>",
     "gemv_experts_w2": "gemv_kernel<3, 2, 4, false, 4>",
     "gemv_wo": "gemv_kernel<3, 1, 4, false, 16>",
-    "router_gate": "router_gate_kernel",
+    "router_gate": "router_shared_kernel",  # router + the shared expert's w1/w3 (router_gate_kernel when not fused)
     "attn_mha": "head_attn_kernel",
 }
 READ_BW_BYTES = 4 << 30  # bench.py: ctx.measure_read_bw(4 << 30, 5)
