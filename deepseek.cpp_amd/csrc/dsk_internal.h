@@ -274,6 +274,9 @@ struct MlaKvArgs {
   int lora, rope, is_v3;
 };
 int launch_mla_kv_write(hipStream_t st, const MlaKvArgs& a, const StepParams* sp);
+// the second-stage projection launch of the MLA path with the cache write as its last workgroup (kernels_gemv.hip)
+bool gemv_kvwrite_supported(const GemvLaunch& h);
+int launch_gemv_kvwrite(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& h, const MlaKvArgs& kv, const StepParams* sp);
 struct MlaHeadArgs {
   AttnMlaArgs a;          // q_rope (un-rotated), q_c, caches; out unused
   GemvTask twv;           // the (H * v_head_dim, lora) stack; the kernel takes rows [h * v, +v)

@@ -594,6 +594,8 @@ extern "C" int dsk_model_finalize(dsk_model* m) {
   HIP_TRY(hipMemset(m->att_counter, 0, ((size_t)c.n_heads * c.v_head_dim / 256 + 2) * 4));
   HIP_TRY(hipMalloc((void**)&m->comb_counter, (size_t)c.dim * 4));
   HIP_TRY(hipMemset(m->comb_counter, 0, (size_t)c.dim * 4));
+  m->ride_shared = getenv("DSK_NO_FUSE_SHARED") == nullptr;    // A/B and test knobs: the ride-along launches can be
+  m->ride_kvwrite = getenv("DSK_NO_KVWRITE_RIDE") == nullptr;  // switched back to separate launches per model
   DSK_TRY(build_plans(m));
   HIP_TRY(hipDeviceSynchronize());
   m->finalized = true;

@@ -98,6 +98,7 @@ struct dsk_model {
   std::vector<GemvLaunch> plans;
   GemvLaunch* plans_dev = nullptr;
   std::vector<int> lp_qkv_a, lp_qkv_b, lp_wv_b, lp_wo, lp_w13, lp_w2;  // per-layer indices into plans (-1: none)
+  bool ride_shared = true, ride_kvwrite = true;  // DSK_NO_FUSE_SHARED / DSK_NO_KVWRITE_RIDE at model creation switch them off
   std::vector<int> lp_sh13;  // shared expert's w1/w3 GLU riding in the router launch (-1: it is a task of lp_w13)
   int lp_head = -1;
   std::vector<MlaHeadArgs> mla_head;   // per layer (MLA path)

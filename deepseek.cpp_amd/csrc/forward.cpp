@@ -298,7 +298,7 @@ int build_plans(dsk_model* m) {
       double bytes = K * e13 + c.dim * 8.0 + 4.0 * K * mi;
       // 1 GPU, K-quants: the shared expert's w1/w3 rides in the router launch (router_shared_kernel) instead
       bool ride = false;
-      if (c.n_shared_experts > 0 && kq && c.dim % 256 == 0 && m->ctx->world == 1 && !getenv("DSK_NO_FUSE_SHARED")) {
+      if (c.n_shared_experts > 0 && kq && c.dim % 256 == 0 && m->ctx->world == 1 && m->ride_shared) {
         GemvLaunch hs;
         memset(&hs, 0, sizeof hs);
         hs.quant = wq; hs.glu = 1; hs.force_NW = 16;
@@ -443,13 +443,20 @@ static int attention_mla(dsk_model* m, int l, int max_kv) {
   hipStream_t st = m->ctx->stream;
   const int H = c.n_heads;
   DSK_TRY(run_plan(m, "gemv_qkv_a", m->lp_qkv_a[l]));
-  DSK_TRY(run_plan(m, "gemv_qkv_b", m->lp_qkv_b[l]));
-  {  // latent norm + this position's cache entries + sink rotation: one small workgroup (src/infer.cpp:1089-1110)
+  {  // second-stage projections; latent norm + this position's cache entries + sink rotation (src/infer.cpp:1089-1110):
+     // one small workgroup, riding as the last workgroup of the projection launch when the plan allows
     MlaKvArgs kv;
     kv.kv_a = m->kv_a; kv.norm_w = reinterpret_cast<const float*>(L.t[DSK_ROLE_KV_A_NORM].qs); kv.eps = c.norm_eps;
     kv.nope_cache = L.nope_cache; kv.rope_cache = L.rope_cache; kv.lora = c.kv_lora_rank; kv.rope = c.qk_rope_head_dim;
     kv.is_v3 = c.has_moegate_bias;
-    PROFILED("rope_kv", (double)c.kv_lora_rank * 14 + c.qk_rope_head_dim * 6, launch_mla_kv_write(st, kv, m->sp_dev));
+    const GemvLaunch& hb = m->plans[m->lp_qkv_b[l]];
+    if (gemv_kvwrite_supported(hb) && !m->profiling && m->ride_kvwrite) {
+      PROFILED("gemv_qkv_b", hb.algo_bytes + (double)c.kv_lora_rank * 14 + c.qk_rope_head_dim * 6,
+               launch_gemv_kvwrite(st, m->plans_dev + m->lp_qkv_b[l], hb, kv, m->sp_dev));
+    } else {
+      DSK_TRY(run_plan(m, "gemv_qkv_b", m->lp_qkv_b[l]));
+      PROFILED("rope_kv", (double)c.kv_lora_rank * 14 + c.qk_rope_head_dim * 6, launch_mla_kv_write(st, kv, m->sp_dev));
+    }
   }
   if (m->mla_flash[l].part_o && m->sp_host->kv_len >= MLA_FLASH_MIN_KV)  // long-context regime (its own graph: dsk_forward)
     PROFILED("attn_mla_flash", (double)m->sp_host->kv_len * (c.kv_lora_rank + c.qk_rope_head_dim) * 2, launch_mla_flash(st, m->mla_flash[l], m->sp_dev, 0));

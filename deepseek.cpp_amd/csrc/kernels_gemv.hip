@@ -898,6 +898,20 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvLaunch* __restr
 // one-task GLU descriptor; they normalise x with the router's own scale routine (same bits as the Q8_K vector the router
 // leaves for the routed experts), so the result is bit-identical to the unfused path.
 // ------------------------------------------------------------------------------------
+// The MLA path's second-stage projection launch (wq_rope_b || wc) with the latent's cache write riding along: the one
+// small workgroup of mla_kv_write_kernel needs kv_a only (like this launch needs q_a only), so it runs as the LAST
+// workgroup of this launch instead of as a launch of its own (-1 launch per MLA layer).
+template <int QT, int U>
+__global__ __launch_bounds__(1024) void gemv_kvwrite_kernel(const GemvLaunch* __restrict__ Lp, const void* h_a0, const void* h_a1,
+                                                           const void* h_a2, int h_n, int h_mode, float h_eps, const MlaKvArgs kv,
+                                                           const StepParams* __restrict__ sp) {
+  if (blockIdx.x == gridDim.x - 1) {
+    rd::mla_kv_write_body(kv, sp, threadIdx.x, 1024);
+    return;
+  }
+  gemv_body<QT, 1, U, false, 16>(Lp, h_a0, h_a1, h_a2, h_n, h_mode, h_eps, 0, 0, (int)blockIdx.x, 0.f);
+}
+
 template <int QT, int U>
 __global__ __launch_bounds__(1024) void router_shared_kernel(const RouterArgs a, int n_router, const GemvLaunch* __restrict__ Lp) {
   if ((int)blockIdx.x < n_router) {
@@ -1411,6 +1425,35 @@ int launch_router_shared(hipStream_t st, const RouterArgs& a, const GemvLaunch* 
     RS_LAUNCH(DSK_QUANT_Q3_K, 2);  // (4 column steps in flight spill at 16 waves, like the plain GLU variant)
   }
 #undef RS_LAUNCH
+  return DSK_OK;
+}
+
+bool gemv_kvwrite_supported(const GemvLaunch& h) {
+  const bool kq = h.quant == DSK_QUANT_Q2_K || h.quant == DSK_QUANT_Q3_K;
+  return kq && !h.glu && h.n_groups == 1 && h.bd_heads == 0 && h.NW == 16 && h.R == 1 && (h.U == 4 || h.U == 2) && !h.comb_x && !h.timeline;
+}
+int launch_gemv_kvwrite(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& h, const MlaKvArgs& kv, const StepParams* sp) {
+  if (!gemv_kvwrite_supported(h)) DSK_FAIL(DSK_ERR_INVALID, "gemv_kvwrite: unsupported plan");
+  if (kv.rope > 128 || (kv.rope & 1)) DSK_FAIL(DSK_ERR_UNSUPPORTED, "rope dim %d (max 128, even)", kv.rope);
+  const GemvTask& T = h.t[h.grp_t0[0]];  // one activation group: the hint of launch_one
+  const void *a0 = T.a_f32, *a1 = T.norm_w, *a2 = nullptr;
+  if (T.act_mode == ACT_Q8) { a0 = T.a_qs; a1 = T.a_d; a2 = T.a_bsums; }
+  dim3 grid(h.grid + 1), block(1024);
+  const size_t lds = h.lds_bytes;
+#define KV_LAUNCH(QT, U)                                                                                             \
+  do {                                                                                                               \
+    auto k = gemv_kvwrite_kernel<QT, U>;                                                                             \
+    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+    hipLaunchKernelGGL(k, grid, block, lds, st, dev, a0, a1, a2, T.n, T.act_mode, T.eps, kv, sp);                    \
+  } while (0)
+  if (h.quant == DSK_QUANT_Q2_K) {
+    if (h.U == 4) KV_LAUNCH(DSK_QUANT_Q2_K, 4);
+    else KV_LAUNCH(DSK_QUANT_Q2_K, 2);
+  } else {
+    if (h.U == 4) KV_LAUNCH(DSK_QUANT_Q3_K, 4);
+    else KV_LAUNCH(DSK_QUANT_Q3_K, 2);
+  }
+#undef KV_LAUNCH
   return DSK_OK;
 }
 

@@ -884,50 +884,7 @@ __global__ __launch_bounds__(256) void rope_kv_mla_kernel(AttnMlaArgs a, const S
 // MLA model path, one workgroup: rmsnorm of the latent (src/infer.cpp:1089), f16 cache entries of this position
 // (:1092-1097), rotation of the sink keys (:1103-1110).
 __global__ __launch_bounds__(256) void mla_kv_write_kernel(MlaKvArgs a, const StepParams* __restrict__ sp) {
-  __shared__ float scratch[4];
-  const int tid = threadIdx.x, rope = a.rope, lora = a.lora;
-  const int kv_pos = sp->kv_pos, kv_sink = sp->kv_sink;
-  float ss = 0.f;
-  for (int i = tid; i < lora; i += 256) ss = fmaf(a.kv_a[i], a.kv_a[i], ss);
-  ss = block_sum(ss, scratch, tid, 256);
-  const float scale = 1.0f / sqrtf(ss / (float)lora + a.eps);
-  uint16_t* nc = a.nope_cache + (size_t)kv_pos * lora;
-  uint16_t* rc = a.rope_cache + (size_t)kv_pos * rope;
-  for (int i = tid; i < lora; i += 256) nc[i] = f2h(a.kv_a[i] * scale * a.norm_w[i]);
-  if (tid < rope / 2) {
-    const float* kr = a.kv_a + lora;
-    const float v0 = kr[2 * tid], v1 = kr[2 * tid + 1];
-    const float c = sp->rope_cs[2 * tid], s = sp->rope_cs[2 * tid + 1];
-    const float re = v0 * c - v1 * s, im = v0 * s + v1 * c;
-    if (a.is_v3) {
-      rc[2 * tid] = f2h(re);
-      rc[2 * tid + 1] = f2h(im);
-    } else {
-      rc[tid] = f2h(re);
-      rc[tid + rope / 2] = f2h(im);
-    }
-  }
-  for (int r = 0; r < kv_sink; ++r) {
-    uint16_t* kh = a.rope_cache + (size_t)r * rope;
-    float re = 0.f, im = 0.f;
-    if (tid < rope / 2) {
-      const float v0 = h2f(kh[2 * tid]), v1 = h2f(kh[2 * tid + 1]);
-      const float c = sp->rope_cs1[2 * tid], s = sp->rope_cs1[2 * tid + 1];
-      re = v0 * c - v1 * s;
-      im = v0 * s + v1 * c;
-    }
-    __syncthreads();
-    if (tid < rope / 2) {
-      if (a.is_v3) {
-        kh[2 * tid] = f2h(re);
-        kh[2 * tid + 1] = f2h(im);
-      } else {
-        kh[tid] = f2h(re);
-        kh[tid + rope / 2] = f2h(im);
-      }
-    }
-    __syncthreads();
-  }
+  rd::mla_kv_write_body(a, sp, threadIdx.x, 256);
 }
 int launch_mla_kv_write(hipStream_t st, const MlaKvArgs& a, const StepParams* sp) {
   if (a.rope > 128 || (a.rope & 1)) DSK_FAIL(DSK_ERR_UNSUPPORTED, "rope dim %d (max 128, even)", a.rope);

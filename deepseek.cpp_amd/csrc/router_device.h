@@ -260,4 +260,57 @@ RDEV void router_body(const RouterArgs& a, int bid, int nblocks) {
   gate_body(tid, v, a.bias, E, a.n_active, a.norm_topk_prob, a.scaling, a.scoring, a.topk_method, a.n_group, a.topk_group,
             a.active_experts, a.active_weights, a.scores_out, s, surv, sel, scratch, 1024);
 }
+// MLA model path, the work of ONE small workgroup: rmsnorm of the latent (src/infer.cpp:1089), f16 cache entries of
+// this position (:1092-1097), rotation of the sink keys (:1103-1110).  Runs either as mla_kv_write_kernel (256 threads)
+// or as the last workgroup of the second-stage projection launch (gemv_kvwrite_kernel, 1024 threads): only the first
+// 256 threads index the data and the extra waves add exact zeros to the block sum, so both give the same bits.
+RDEV void mla_kv_write_body(const MlaKvArgs& a, const StepParams* __restrict__ sp, int tid, int nthreads) {
+  __shared__ float scratch[16];
+  const int rope = a.rope, lora = a.lora;
+  const int kv_pos = sp->kv_pos, kv_sink = sp->kv_sink;
+  const bool work = tid < 256;
+  float ss = 0.f;
+  if (work)
+    for (int i = tid; i < lora; i += 256) ss = fmaf(a.kv_a[i], a.kv_a[i], ss);
+  ss = block_sum(ss, scratch, tid, nthreads);
+  const float scale = 1.0f / sqrtf(ss / (float)lora + a.eps);
+  uint16_t* nc = a.nope_cache + (size_t)kv_pos * lora;
+  uint16_t* rc = a.rope_cache + (size_t)kv_pos * rope;
+  if (work)
+    for (int i = tid; i < lora; i += 256) nc[i] = ad::f2h(a.kv_a[i] * scale * a.norm_w[i]);
+  if (tid < rope / 2) {
+    const float* kr = a.kv_a + lora;
+    const float v0 = kr[2 * tid], v1 = kr[2 * tid + 1];
+    const float c = sp->rope_cs[2 * tid], s = sp->rope_cs[2 * tid + 1];
+    const float re = v0 * c - v1 * s, im = v0 * s + v1 * c;
+    if (a.is_v3) {
+      rc[2 * tid] = ad::f2h(re);
+      rc[2 * tid + 1] = ad::f2h(im);
+    } else {
+      rc[tid] = ad::f2h(re);
+      rc[tid + rope / 2] = ad::f2h(im);
+    }
+  }
+  for (int r = 0; r < kv_sink; ++r) {
+    uint16_t* kh = a.rope_cache + (size_t)r * rope;
+    float re = 0.f, im = 0.f;
+    if (tid < rope / 2) {
+      const float v0 = ad::h2f(kh[2 * tid]), v1 = ad::h2f(kh[2 * tid + 1]);
+      const float c = sp->rope_cs1[2 * tid], s = sp->rope_cs1[2 * tid + 1];
+      re = v0 * c - v1 * s;
+      im = v0 * s + v1 * c;
+    }
+    __syncthreads();
+    if (tid < rope / 2) {
+      if (a.is_v3) {
+        kh[2 * tid] = ad::f2h(re);
+        kh[2 * tid + 1] = ad::f2h(im);
+      } else {
+        kh[tid] = ad::f2h(re);
+        kh[tid + rope / 2] = ad::f2h(im);
+      }
+    }
+    __syncthreads();
+  }
+}
 }  // namespace rd
