@@ -338,6 +338,7 @@ extern "C" int dsk_bench_gemv(dsk_ctx* ctx, int quant, int rows, int n, int n_ta
   int copies = (int)(600e6 / wbytes) + 1;
   if (copies > 48) copies = 48;
   if (copies < 2) copies = 2;
+  if (getenv("DSK_BENCH_COPIES")) copies = std::max(1, atoi(getenv("DSK_BENCH_COPIES")));  // 1: the Infinity Cache serves the weights
   std::vector<TensorGuard> W((size_t)copies * mats);
   for (size_t i = 0; i < W.size(); ++i) {
     DSK_TRY(alloc_tensor(128, 128, W[i].t, quant, 0, rows, n, 1, 0));
