@@ -113,3 +113,29 @@ def test_defaults_of_optional_metadata_keys(tmp_path):
     assert c.scoring_func == 0 and c.topk_method == 0 and c.use_mla == 0 and c.has_moegate_bias == 0
     assert c.kv_lora_rank == 0 and c.q_lora_rank == 0 and c.first_k_dense_replace == 0
     assert c.norm_eps == pytest.approx(1e-5) and c.act == 0  # gelu
+
+
+def test_header_json_dialect(tmp_path):
+    """The header is whatever a JSON writer emits: whitespace, escapes, unicode escapes, numbers as floats, nested values
+    the loader does not use; a later shard's tensor of the same name replaces an earlier one (the reference assigns into
+    a std::map, src/codec.cpp:318-327)."""
+    import dsk
+    md = synth.preset("tiny_v3", "fp16", False).metadata()
+    md["note"] = "tab\there é \"quoted\" back\\slash"
+    d = str(tmp_path / "d")
+    os.makedirs(d)
+    hdr = {"__metadata__": md, "a/b\"c": {"dtype": "F16", "shape": [2, 3.0], "data_offsets": [0, 12], "extra": {"nested": [1, {"x": None}, True]}},
+           "second": {"dtype": "U8", "shape": [4], "data_offsets": [12, 16]}}
+    hj = json.dumps(hdr, indent=3, ensure_ascii=True).encode()  # \\u00e9 escape, newlines and indentation
+    open(os.path.join(d, "000.dseek"), "wb").write(struct.pack("<Q", len(hj)) + hj + b"\0" * 16)
+    hj2 = json.dumps({"second": {"dtype": "F32", "shape": [2], "data_offsets": [0, 8]}}, separators=(",", ":")).encode()
+    open(os.path.join(d, "001.dseek"), "wb").write(struct.pack("<Q", len(hj2)) + hj2 + b"\0" * 8)
+    c, n_files, n_tensors, n_bytes = dsk.read_dseek_config(d)
+    assert (n_files, n_tensors) == (2, 2) and c.dim == synth.preset("tiny_v3", "fp16", False).dim
+    assert n_bytes == 12 + 4 + 8  # every tensor entry read counts, also the replaced one
+    # a shape entry that is not an integer, a negative offset
+    for bad in ({"dtype": "F32", "shape": [1.5], "data_offsets": [0, 6]}, {"dtype": "U8", "shape": [4], "data_offsets": [-4, 0]}):
+        dd = str(tmp_path / ("bad%d" % id(bad)))
+        _write_raw(dd, {"__metadata__": md, "t": bad}, b"\0" * 16)
+        with pytest.raises(dsk.DskError):
+            dsk.read_dseek_config(dd)
