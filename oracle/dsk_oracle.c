@@ -539,6 +539,16 @@ int orc_sample(const float* logits, int vocab_size, float temperature, float top
   return vocab_size - 1;
 }
 
+/* Sampler::sample_prob (src/sampler.cpp:12-26): softmax probability of logits[index], sums left to right in f32 */
+float orc_sample_prob(const float* logits, int vocab_size, int index) {
+  float max_val = -FLT_MAX;
+  for (int i = 0; i < vocab_size; ++i)
+    if (logits[i] > max_val) max_val = logits[i];
+  float sum = 0.0f;
+  for (int i = 0; i < vocab_size; ++i) sum += expf(logits[i] - max_val);
+  return expf(logits[index] - max_val) / sum;
+}
+
 static inline float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); } /* src/infer.cpp:489-491 */
 static inline float siluf(float x) { return x / (1.0f + expf(-x)); }       /* src/infer.cpp:640-642 */
 static inline float geluf(float x) {                                       /* src/infer.cpp:636-638 */

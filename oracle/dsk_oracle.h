@@ -43,6 +43,7 @@ void orc_rmsnorm(float* o, const float* x, const float* weight, int size, float 
 void orc_softmax(float* o, const float* x, int size);
 /* Sampler::sample / sample_argmax (src/sampler.cpp:28-75); coin = rand() / (float)RAND_MAX */
 int orc_sample(const float* logits, int vocab_size, float temperature, float top_p, float coin);
+float orc_sample_prob(const float* logits, int vocab_size, int index);  /* Sampler::sample_prob, src/sampler.cpp:12-26 */
 void orc_moe_gate(const float* scores_in, const float* bias, int n_routed, int n_active,
                   int norm_topk_prob, float routed_scaling_factor, int scoring_func,
                   int topk_method, int n_group, int topk_group,

@@ -161,6 +161,13 @@ class Oracle(_Lib):
         self.lib.orc_rmsnorm(fp(o), fp(x), fp(w), x.size, eps)
         return o
 
+    def sample_prob(self, logits, index):
+        """Sampler::sample_prob restated (src/sampler.cpp:12-26)."""
+        l = np.ascontiguousarray(logits, np.float32)
+        f = self.lib.orc_sample_prob
+        f.argtypes, f.restype = [c_f, C.c_int, C.c_int], C.c_float
+        return float(f(fp(l), l.size, int(index)))
+
     def sample(self, logits, temperature, top_p, coin):
         """Sampler::sample / sample_argmax restated (src/sampler.cpp:28-75)."""
         l = np.ascontiguousarray(logits, np.float32)
@@ -408,6 +415,14 @@ class RefSession:
 
     def active_bytes(self, pos):
         return self.ref.lib.ref_active_bytes(self.h, pos)
+
+    def sample_prob(self, logits, index):
+        """The reference's own Sampler::sample_prob on `logits`."""
+        l = np.ascontiguousarray(logits, np.float32)
+        assert l.size == self.cfg.vocab_size
+        f = self.ref.lib.ref_sample_prob
+        f.argtypes, f.restype = [C.c_void_p, c_f, C.c_int], C.c_float
+        return float(f(self.h, fp(l), int(index)))
 
     def sample(self, logits, temperature, top_p, seed):
         """The reference's own Sampler::sample on `logits` (vocab_size floats), seeded with `seed`;

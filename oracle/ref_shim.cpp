@@ -245,6 +245,14 @@ int ref_sample(void* h, const float* logits, float temperature, float top_p, uns
   return smp.sample(*s->state, temperature, top_p);
 }
 
+// Sampler::sample_prob as shipped (src/sampler.cpp:12-26)
+float ref_sample_prob(void* h, const float* logits, int index) {
+  auto* s = static_cast<RefSession*>(h);
+  std::memcpy(s->state->logits(), logits, sizeof(float) * s->model->config->vocab_size);
+  Sampler smp(s->model->config, 0);
+  return smp.sample_prob(index, *s->state);
+}
+
 double ref_active_bytes(void* h, int pos) { return static_cast<RefSession*>(h)->model->active_bytes(pos); }
 
 }  // extern "C"

@@ -418,7 +418,7 @@ def test_forward_sample_is_forward_plus_sampler(ctx, oracle):
     B.close()
 
 
-def test_forward_prob_is_the_softmax_probability_of_the_index(ctx):
+def test_forward_prob_is_the_softmax_probability_of_the_index(ctx, oracle):
     """dsk_forward_prob = dsk_forward + Sampler::sample_prob (src/sampler.cpp:12-26), the per-token term of
     run_perplexity; float path: 1e-4 relative to the f64 softmax of the model's own logits (the reference's left-to-right
     f32 sum is itself ~1e-5 away from it); interleaved with sampling steps on the same model (shared parameters)."""
@@ -433,6 +433,8 @@ def test_forward_prob_is_the_softmax_probability_of_the_index(ctx):
         pr /= pr.sum()
         got = B.forward_prob(toks[pos], pos, toks[pos + 1])
         assert abs(got - pr[toks[pos + 1]]) <= 1e-4 * pr[toks[pos + 1]] + 1e-12, pos
+        want = oracle.sample_prob(lg.astype(np.float32), toks[pos + 1])  # the reference's left-to-right f32 sums
+        assert abs(got - want) <= 1e-4 * want + 1e-12, pos
         if pos == 2:  # a sampling step in between must not disturb the probability mode (and vice versa)
             assert B.forward_sample(toks[pos], pos, 1.0, 0.95, 0.5) == ctx.sample(lg.astype(np.float32), 1.0, 0.95, 0.5)
     with pytest.raises(dsk.DskError):
