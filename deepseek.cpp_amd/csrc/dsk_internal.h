@@ -50,6 +50,7 @@ struct DTensor {
   uint8_t* hm = nullptr;
   uint8_t* dm = nullptr;
   float* scale = nullptr;   // F8 block scales
+  bool scale_bound = false; // the ".scale" tensor was actually uploaded / synthesised (alloc_tensor only reserves it)
   size_t e_qs = 0, e_sc = 0, e_hm = 0, e_dm = 0, e_scale = 0;  // per-expert strides in bytes (scale: floats)
   bool bound() const { return base != nullptr; }
 };
@@ -121,6 +122,11 @@ struct GemvLaunch {
   // debug (DSK_TIMELINE=1 with dsk_bench_gemv): 4 wall-clock stamps per workgroup (entry, staged, first
   // row group done, exit), 100 MHz s_memrealtime ticks
   unsigned long long* timeline;
+  // parity taps (dsk_model_run_block): when set, the first workgroup of activation group g copies the Q8_K vector it
+  // staged (int8 codes, block scales) to tap_qs + g * tap_stride / tap_d + g * tap_stride / 256.  Null in production.
+  int8_t* tap_qs;
+  float* tap_d;
+  int tap_stride;
   size_t lds_bytes;
   double algo_bytes;          // host-side bookkeeping for the roofline report
 };
@@ -229,6 +235,11 @@ struct HeadAttnArgs {
   int n_split;
   float* split_part;        // (H, n_split, v_dim + 2)
   unsigned* split_counter;  // (H), zero between launches
+  // parity taps (dsk_model_run_block): workgroup 0 copies the staged Q8_K vectors of norm(q_a) (at 0) and
+  // norm(kv_a[:lora]) (at tap_stride); null in production
+  int8_t* tap_qs;
+  float* tap_d;
+  int tap_stride;
 };
 #define MHA_SPLIT_MIN_KV 1024  // below this one workgroup per head is faster (default; DSK_MHA_SPLIT_MIN overrides)
 #define MHA_SPLIT_MAX 16
@@ -286,6 +297,11 @@ struct MlaHeadArgs {
   int flash_thresh, fl_chunk_len, fl_n_chunks;
   const float* fl_part_o;
   const float* fl_part_ml;
+  // parity taps (dsk_model_run_block): head h copies its latent output (lora floats) to tap_o + h * lora and the
+  // Q8_K vector it staged for wv_b to tap_qs + h * lora / tap_d + h * lora / 256; null in production
+  int8_t* tap_qs;
+  float* tap_d;
+  float* tap_o;
 };
 int mla_head_plan(MlaHeadArgs& A);
 int launch_mla_head(hipStream_t st, const MlaHeadArgs& A, const StepParams* sp, int max_kv);

@@ -51,8 +51,21 @@ extern "C" int dsk_ctx_create(int device_ordinal, dsk_ctx** out) {
   *out = c;
   return DSK_OK;
 }
+// A context outlives its models: destroying it while models are alive only marks it; the last dsk_model_destroy
+// frees it (a host binding may drop its handles in any order, e.g. at interpreter exit).
+static int ctx_free(dsk_ctx* c);
 extern "C" int dsk_ctx_destroy(dsk_ctx* c) {
   if (!c) return DSK_OK;
+  if (c->live_models > 0) {
+    c->closing = true;
+    return DSK_OK;
+  }
+  return ctx_free(c);
+}
+void ctx_model_released(dsk_ctx* c) {
+  if (--c->live_models == 0 && c->closing) ctx_free(c);
+}
+static int ctx_free(dsk_ctx* c) {
   hipSetDevice(c->device);
   for (int i = 0; i < 8; ++i)
     if (c->op_buf[i]) hipFree(c->op_buf[i]);
@@ -189,8 +202,10 @@ extern "C" int dsk_model_create(dsk_ctx* ctx, const dsk_config* cfg, dsk_model**
   if (c.n_routed_experts > 256) DSK_FAIL(DSK_ERR_UNSUPPORTED, "more than 256 routed experts (src/infer.cpp:527)");
   if (c.rs_original_max_position_embeddings <= KV_SINKS_GUARD) DSK_FAIL(DSK_ERR_INVALID, "rs_original_max_position_embeddings too small");
   if (c.qk_rope_head_dim > 128 || (c.qk_rope_head_dim & 1)) DSK_FAIL(DSK_ERR_UNSUPPORTED, "qk_rope_head_dim %d", c.qk_rope_head_dim);
+  if (ctx->closing) DSK_FAIL(DSK_ERR_STATE, "model_create: the context has been destroyed");
   dsk_model* m = new dsk_model();
   m->ctx = ctx;
+  ctx->live_models++;
   m->c = c;
   m->head_dim = c.qk_nope_head_dim + c.qk_rope_head_dim;
   m->L.resize(c.n_layers);
@@ -382,6 +397,7 @@ int bind_src(dsk_model* m, int role, int layer, int quant, const int32_t shape[4
     if (bytes != per * mats * 4) DSK_FAIL(DSK_ERR_INVALID, "bind: scale bytes %zu, expected %zu", bytes, per * mats * 4);
     const size_t lm = rs.e > 0 ? (size_t)local : 1;
     if (lm) DSK_TRY(stage_copy(m->ctx, src, (uint64_t)base * per * 4, t->scale, lm * per * 4));
+    t->scale_bound = true;
     return DSK_OK;
   }
 
@@ -422,6 +438,7 @@ extern "C" int dsk_model_synthesize(dsk_model* m, uint64_t seed) {
     shard_range(m, role, rs.e, &base, &local);
     DSK_TRY(alloc_tensor(c.block_size[0], c.block_size[1], *t, rs.quant, rs.e, rs.rows, rs.n, local, base));
     m->weight_bytes += (double)t->bytes;
+    t->scale_bound = true;  // launch_fill_tensor writes the block scales of an F8 tensor too
     // the seed depends on (role, layer, first local expert) only: every rank generates the same weights
     const uint64_t s = seed * 0x9E3779B97F4A7C15ull + (uint64_t)(layer + 1) * 1000003ull + (uint64_t)role * 7919ull;
     const bool norm = role == DSK_ROLE_FINAL_NORM || role == DSK_ROLE_ATTN_NORM || role == DSK_ROLE_FFN_NORM ||
@@ -496,11 +513,17 @@ extern "C" int dsk_model_finalize(dsk_model* m) {
   const int H = c.n_heads, hd = m->head_dim;
   if (!m->g[DSK_ROLE_EMBED].bound() || !m->g[DSK_ROLE_FINAL_NORM].bound()) DSK_FAIL(DSK_ERR_STATE, "finalize: embed / final norm not bound");
   m->tied = !m->g[DSK_ROLE_OUTPUT].bound();  // src/model.cpp:852-856
+  // F8E5M2 weights need their block scales (the reference asserts on a missing ".scale", src/model.cpp:191,862):
+  // alloc_tensor reserves the scale plane with the weight, so "allocated" says nothing -- it must have been bound
+  if (c.weight_quant == DSK_QUANT_F8E5M2) {
+    if (!m->g[DSK_ROLE_EMBED].scale_bound) DSK_FAIL(DSK_ERR_STATE, "finalize: model.embed has no scale");
+    if (!m->tied && !m->g[DSK_ROLE_OUTPUT].scale_bound) DSK_FAIL(DSK_ERR_STATE, "finalize: model.output has no scale");
+  }
   for (int l = 0; l < c.n_layers; ++l)
     for (int role : ALL_LAYER_ROLES) {
       const RoleShape rs = role_shape(m, role, l);
       if (rs.ok && !m->L[l].t[role].bound()) DSK_FAIL(DSK_ERR_STATE, "finalize: layer %d role %d not bound", l, role);
-      if (rs.ok && rs.quant == DSK_QUANT_F8E5M2 && !m->L[l].t[role].scale) DSK_FAIL(DSK_ERR_STATE, "finalize: layer %d role %d has no scale", l, role);
+      if (rs.ok && rs.quant == DSK_QUANT_F8E5M2 && !m->L[l].t[role].scale_bound) DSK_FAIL(DSK_ERR_STATE, "finalize: layer %d role %d has no scale", l, role);
     }
   if (is_kq(c.weight_quant)) {
     const int lens[] = {c.dim, c.q_lora_rank, c.kv_lora_rank, H * c.v_head_dim, c.hidden_dim,
@@ -635,6 +658,8 @@ extern "C" int dsk_model_destroy(dsk_model* m) {
                   (void*)m->sp_dev})
     if (p) hipFree(p);
   free_plans(m);
+  for (void* p : {(void*)m->tap_qs, (void*)m->tap_d, (void*)m->tap_latent, (void*)m->stage_x_mid})
+    if (p) hipFree(p);
   if (m->router_counter) hipFree(m->router_counter);
   if (m->comb_counter) hipFree(m->comb_counter);
   if (m->att_counter) hipFree(m->att_counter);

@@ -21,6 +21,8 @@ struct dsk_ctx {
   hipStream_t stream = nullptr;
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1;
+  int live_models = 0;   // models created on this context and not yet destroyed
+  bool closing = false;  // dsk_ctx_destroy was called while models were alive: freed by the last dsk_model_destroy
   // scratch for op-level entry points
   void* op_buf[8] = {nullptr};
   size_t op_cap[8] = {0};
@@ -34,6 +36,7 @@ struct dsk_ctx {
   int pin_next = 0;
   double staged_bytes = 0, staged_fill_s = 0;  // bookkeeping for dsk_load_stats
 };
+void ctx_model_released(dsk_ctx* c);
 int stage_copy(dsk_ctx* ctx, const HostSrc& src, uint64_t src_off, void* dev_dst, size_t bytes);
 int upload_tensor(dsk_ctx* ctx, DTensor& t, const HostSrc& src);
 struct dsk_model;
@@ -116,6 +119,16 @@ struct dsk_model {
   unsigned* mha_split_counter = nullptr;
   unsigned* comb_counter = nullptr;  // one arrival counter per row group of the fused MoE combine
   int target_wgs = 1024;
+  // parity harness (dsk_model_run_block): Q8_K staging taps of ONE block, device arenas allocated on first use
+  int stage_layer = -1;          // >= 0 while a tapped block runs
+  int stage_kv_len = 0;          // kv_len of the last tapped block (cache rows the harness may read back)
+  int stage_last_layer = -1;
+  int8_t* tap_qs = nullptr;      // arena of int8 codes; regions below (element offsets, multiples of 256)
+  float* tap_d = nullptr;        // block scales: region offsets / 256
+  float* tap_latent = nullptr;   // MLA: per-head latent outputs (H, lora)
+  float* stage_x_mid = nullptr;  // residual stream after the attention half of the block
+  size_t tap_off_xattn = 0, tap_off_qa = 0, tap_off_kva = 0, tap_off_xffn = 0, tap_off_xffn_sh = 0, tap_off_hb = 0,
+         tap_off_latent = 0, tap_off_final = 0, tap_total = 0;
   // profiling
   bool profiling = false;
   std::vector<KTime> ktimes;

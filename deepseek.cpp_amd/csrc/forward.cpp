@@ -430,8 +430,14 @@ static int attention_mha(dsk_model* m, int l, int max_kv) {
   DSK_TRY(run_plan(m, "gemv_qkv_a", m->lp_qkv_a[l]));
   // second-stage projections (wq_b, wkv_b) + rope + cache write + attention + Q8_K of the head outputs:
   // one launch, one workgroup per head (kernels_gemv.hip head_attn_kernel)
+  HeadAttnArgs HA = m->head_attn[l];
+  if (m->stage_layer == l && m->tap_qs) {  // parity taps of this block (dsk_model_run_block)
+    HA.tap_qs = m->tap_qs + m->tap_off_qa;
+    HA.tap_d = m->tap_d + m->tap_off_qa / 256;
+    HA.tap_stride = (int)(m->tap_off_kva - m->tap_off_qa);
+  }
   PROFILED("attn_mha", m->head_attn_bytes[l] + (double)m->sp_host->kv_len * H * (hd + c.v_head_dim) * 2 + (double)H * (hd * 2 + c.v_head_dim * 11),
-           launch_head_attn(st, m->head_attn[l], m->sp_dev, max_kv,
+           launch_head_attn(st, HA, m->sp_dev, max_kv,
                             m->mha_split > 1 && m->sp_host->kv_len >= m->mha_split_min ? m->mha_split : 1));
   DSK_TRY(run_plan(m, "gemv_wo", m->lp_wo[l]));  // residual: src/infer.cpp:832-834
   return DSK_OK;
@@ -461,8 +467,14 @@ static int attention_mla(dsk_model* m, int l, int max_kv) {
   if (m->mla_flash[l].part_o && m->sp_host->kv_len >= MLA_FLASH_MIN_KV)  // long-context regime (its own graph: dsk_forward)
     PROFILED("attn_mla_flash", (double)m->sp_host->kv_len * (c.kv_lora_rank + c.qk_rope_head_dim) * 2, launch_mla_flash(st, m->mla_flash[l], m->sp_dev, 0));
   // q rope + attention over the shared latent cache + per-head wv_b + Q8_K of the outputs: one launch
+  MlaHeadArgs MA = m->mla_head[l];
+  if (m->stage_layer == l && m->tap_qs) {  // parity taps of this block (dsk_model_run_block)
+    MA.tap_qs = m->tap_qs + m->tap_off_latent;
+    MA.tap_d = m->tap_d + m->tap_off_latent / 256;
+    MA.tap_o = m->tap_latent;
+  }
   PROFILED("attn_mla", m->head_attn_bytes[l] + (double)m->sp_host->kv_len * (c.kv_lora_rank + c.qk_rope_head_dim) * 2 + (double)H * c.v_head_dim * 9,
-           launch_mla_head(st, m->mla_head[l], m->sp_dev, max_kv));
+           launch_mla_head(st, MA, m->sp_dev, max_kv));
   DSK_TRY(run_plan(m, "gemv_wo", m->lp_wo[l]));
   return DSK_OK;
 }
@@ -750,5 +762,174 @@ extern "C" int dsk_time_kernel_class(dsk_model* m, const char* name, int pos, in
   *us_per_launch = (double)ms * 1e3 / ((double)reps * per_token);
   *bytes_per_launch = bytes / per_token;
   *launches_per_token = per_token;
+  return DSK_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// Parity harness: ONE block (or the classifier) on a caller-supplied residual stream, with every Q8_K staging point
+// of the block tapped -- teacher forcing per layer AND per quantisation point (tests/test_teacher_forced_gpu.py).
+// The reference's dead DEBUG_MODEL hooks (src/infer.cpp:10-119) dump the same intermediate state on the CPU side.
+// ---------------------------------------------------------------------------------
+static size_t up256(size_t v) { return (v + 255) / 256 * 256; }
+
+static int ensure_taps(dsk_model* m) {
+  if (m->tap_qs) return DSK_OK;
+  const dsk_config& c = m->c;
+  const int shared_n = c.n_shared_experts * c.moe_intermediate_size;
+  const int hb_stride = std::max(std::max(c.moe_intermediate_size, shared_n), 1);
+  const size_t hb_n = std::max<size_t>((size_t)std::max(1, m->n_slots) * hb_stride, (size_t)c.hidden_dim);
+  size_t o = 0;
+  m->tap_off_xattn = o; o += up256(c.dim);
+  m->tap_off_qa = o; o += up256(std::max(1, c.q_lora_rank));
+  m->tap_off_kva = o; o += up256(c.kv_lora_rank);
+  m->tap_off_xffn = o; o += up256(c.dim);
+  m->tap_off_xffn_sh = o; o += up256(c.dim);
+  m->tap_off_hb = o; o += up256(hb_n);
+  m->tap_off_latent = o; o += up256((size_t)c.n_heads * std::max(1, c.kv_lora_rank));
+  m->tap_off_final = o; o += up256(c.dim);
+  m->tap_total = o;
+  HIP_TRY(hipMalloc((void**)&m->tap_qs, o));
+  HIP_TRY(hipMalloc((void**)&m->tap_d, o / 256 * 4));
+  HIP_TRY(hipMalloc((void**)&m->tap_latent, (size_t)c.n_heads * std::max(1, c.kv_lora_rank) * 4));
+  HIP_TRY(hipMalloc((void**)&m->stage_x_mid, (size_t)c.dim * 4));
+  return DSK_OK;
+}
+
+// point the device copy of launch plan `idx` at a tap region (stride = distance between activation groups), or restore it
+static int patch_plan(dsk_model* m, int idx, size_t off, int stride, bool on) {
+  if (idx < 0) return DSK_OK;
+  GemvLaunch t = m->plans[idx];
+  if (on) {
+    t.tap_qs = m->tap_qs + off;
+    t.tap_d = m->tap_d + off / 256;
+    t.tap_stride = stride;
+  }
+  HIP_TRY(hipMemcpy(m->plans_dev + idx, &t, sizeof t, hipMemcpyHostToDevice));
+  return DSK_OK;
+}
+
+static int patch_layer(dsk_model* m, int l, bool on) {
+  const dsk_config& c = m->c;
+  const int shared_n = c.n_shared_experts * c.moe_intermediate_size;
+  const int hb_stride = std::max(std::max(c.moe_intermediate_size, shared_n), 1);
+  DSK_TRY(patch_plan(m, m->lp_qkv_a[l], m->tap_off_xattn, 0, on));
+  if (c.use_mla) DSK_TRY(patch_plan(m, m->lp_qkv_b[l], m->tap_off_qa, 0, on));  // wq_rope_b || wc on norm(q_a)
+  DSK_TRY(patch_plan(m, m->lp_w13[l], m->tap_off_xffn, 0, on));
+  DSK_TRY(patch_plan(m, m->lp_sh13[l], m->tap_off_xffn_sh, 0, on));
+  DSK_TRY(patch_plan(m, m->lp_w2[l], m->tap_off_hb, m->L[l].is_moe ? hb_stride : 0, on));
+  return DSK_OK;
+}
+
+extern "C" int dsk_model_run_block(dsk_model* m, int layer, const float* x_in, int pos, float* x_out) {
+  if (!m || !m->finalized || !x_in || !x_out) DSK_FAIL(DSK_ERR_INVALID, "run_block: bad argument");
+  if (layer < 0 || layer >= m->c.n_layers || pos < 0) DSK_FAIL(DSK_ERR_INVALID, "run_block: layer %d pos %d", layer, pos);
+  if (m->ctx->world > 1) DSK_FAIL(DSK_ERR_UNSUPPORTED, "run_block: single-GPU models only");
+  HIP_TRY(hipSetDevice(m->ctx->device));
+  hipStream_t st = m->ctx->stream;
+  const dsk_config& c = m->c;
+  DSK_TRY(ensure_taps(m));
+  DSK_TRY(fill_step_params(m, 0, pos));
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipMemset(m->tap_qs, 0x7f, m->tap_total));  // poison: a tap that did not fire is visible
+  HIP_TRY(hipMemset(m->tap_d, 0xff, m->tap_total / 256 * 4));
+  HIP_TRY(hipMemcpy(m->sp_dev, m->sp_host, sizeof(StepParams), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(m->x, x_in, (size_t)c.dim * 4, hipMemcpyHostToDevice));
+  DSK_TRY(patch_layer(m, layer, true));
+  m->stage_layer = layer;
+  const int max_kv = std::min(c.max_seq_len, std::max(1, c.rs_original_max_position_embeddings));
+  int r = c.use_mla ? attention_mla(m, layer, max_kv) : attention_mha(m, layer, max_kv);
+  if (r == DSK_OK && hipMemcpyAsync(m->stage_x_mid, m->x, (size_t)c.dim * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) r = DSK_ERR_HIP;
+  if (r == DSK_OK) r = ffn(m, layer);
+  m->stage_layer = -1;
+  hipError_t e = hipStreamSynchronize(st);
+  int r2 = patch_layer(m, layer, false);
+  if (r != DSK_OK) return r;
+  if (e != hipSuccess) DSK_FAIL(DSK_ERR_HIP, "run_block: %s", hipGetErrorString(e));
+  DSK_TRY(r2);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(x_out, m->x, (size_t)c.dim * 4, hipMemcpyDeviceToHost));
+  m->stage_kv_len = m->sp_host->kv_len;
+  m->stage_last_layer = layer;
+  return DSK_OK;
+}
+
+// final norm + classifier on a caller-supplied residual stream (src/infer.cpp:1292-1316); tap "q8.x_final"
+extern "C" int dsk_model_run_head(dsk_model* m, const float* x_in, float* logits) {
+  if (!m || !m->finalized || !x_in || !logits) DSK_FAIL(DSK_ERR_INVALID, "run_head: bad argument");
+  HIP_TRY(hipSetDevice(m->ctx->device));
+  hipStream_t st = m->ctx->stream;
+  DSK_TRY(ensure_taps(m));
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipMemcpy(m->x, x_in, (size_t)m->c.dim * 4, hipMemcpyHostToDevice));
+  DSK_TRY(patch_plan(m, m->lp_head, m->tap_off_final, 0, true));
+  int r = run_plan(m, "gemv_lm_head", m->lp_head);
+  hipError_t e = hipStreamSynchronize(st);
+  int r2 = patch_plan(m, m->lp_head, 0, 0, false);
+  if (r != DSK_OK) return r;
+  if (e != hipSuccess) DSK_FAIL(DSK_ERR_HIP, "run_head: %s", hipGetErrorString(e));
+  DSK_TRY(r2);
+  HIP_TRY(hipMemcpy(logits, m->logits, (size_t)m->c.vocab_size * 4, hipMemcpyDeviceToHost));
+  return DSK_OK;
+}
+
+extern "C" int dsk_model_get_stage(dsk_model* m, const char* name, void* out, size_t bytes) {
+  if (!m || !m->finalized || !name || !out) DSK_FAIL(DSK_ERR_INVALID, "get_stage: bad argument");
+  if (!m->tap_qs) DSK_FAIL(DSK_ERR_STATE, "get_stage before dsk_model_run_block / dsk_model_run_head");
+  HIP_TRY(hipSetDevice(m->ctx->device));
+  const dsk_config& c = m->c;
+  const int l = std::max(0, m->stage_last_layer);
+  const Layer& L = m->L[l];
+  const int H = c.n_heads, K = std::max(1, c.n_active_routed), E = std::max(1, c.n_routed_experts);
+  const int shared_n = c.n_shared_experts * c.moe_intermediate_size;
+  const int hb_stride = std::max(std::max(c.moe_intermediate_size, shared_n), 1);
+  const size_t hb_n = std::max<size_t>((size_t)std::max(1, m->n_slots) * hb_stride, (size_t)c.hidden_dim);
+  const size_t kv = (size_t)m->stage_kv_len;
+  const void* src = nullptr;
+  size_t avail = 0;
+  const std::string s(name);
+  auto f32 = [&](const float* p, size_t n) { src = p; avail = n * 4; };
+  auto tapq = [&](size_t off, size_t n) { src = m->tap_qs + off; avail = n; };
+  auto tapd = [&](size_t off, size_t n) { src = m->tap_d + off / 256; avail = n / 256 * 4; };
+  if (s == "x_mid") f32(m->stage_x_mid, c.dim);
+  else if (s == "q_a") f32(m->q_a, std::max(1, c.q_lora_rank));
+  else if (s == "kv_a") f32(m->kv_a, c.kv_lora_rank + c.qk_rope_head_dim);
+  else if (s == "att_out") f32(m->att_out, (size_t)H * c.v_head_dim);
+  else if (s == "vb_out") f32(m->vb_out, (size_t)H * c.v_head_dim);
+  else if (s == "latent_out") f32(m->tap_latent, (size_t)H * c.kv_lora_rank);
+  else if (s == "q_c") f32(m->q_c, (size_t)H * c.kv_lora_rank);
+  else if (s == "q_rope") f32(m->q_rope, (size_t)H * c.qk_rope_head_dim);
+  else if (s == "router_logits") f32(m->router_partial, E);
+  else if (s == "gate_scores") f32(m->gate_scores + (size_t)l * E, E);
+  else if (s == "route_w") f32(m->route_w + (size_t)l * K, K);
+  else if (s == "route_e") { src = m->route_e + (size_t)l * K; avail = (size_t)K * 4; }
+  else if (s == "hb") f32(m->hb, hb_n);
+  else if (s == "eout") f32(m->eout, (size_t)std::max(1, m->n_slots) * c.dim);
+  else if (s == "q8.x_attn.qs") tapq(m->tap_off_xattn, c.dim);
+  else if (s == "q8.x_attn.d") tapd(m->tap_off_xattn, c.dim);
+  else if (s == "q8.q_a.qs") tapq(m->tap_off_qa, std::max(1, c.q_lora_rank));
+  else if (s == "q8.q_a.d") tapd(m->tap_off_qa, std::max(1, c.q_lora_rank));
+  else if (s == "q8.kv_a.qs") tapq(m->tap_off_kva, c.kv_lora_rank);
+  else if (s == "q8.kv_a.d") tapd(m->tap_off_kva, c.kv_lora_rank);
+  else if (s == "q8.x_ffn_tap.qs") tapq(m->tap_off_xffn, c.dim);
+  else if (s == "q8.x_ffn_tap.d") tapd(m->tap_off_xffn, c.dim);
+  else if (s == "q8.x_ffn_shared.qs") tapq(m->tap_off_xffn_sh, c.dim);
+  else if (s == "q8.x_ffn_shared.d") tapd(m->tap_off_xffn_sh, c.dim);
+  else if (s == "q8.x_ffn.qs") { src = m->a_xb.qs; avail = m->a_xb.qs ? (size_t)c.dim : 0; }
+  else if (s == "q8.x_ffn.d") { src = m->a_xb.d; avail = m->a_xb.d ? (size_t)c.dim / 256 * 4 : 0; }
+  else if (s == "q8.att.qs") { src = m->a_att.qs; avail = m->a_att.qs ? (size_t)H * c.v_head_dim : 0; }
+  else if (s == "q8.att.d") { src = m->a_att.d; avail = m->a_att.d ? (size_t)H * c.v_head_dim / 256 * 4 : 0; }
+  else if (s == "q8.hb.qs") tapq(m->tap_off_hb, hb_n);
+  else if (s == "q8.hb.d") tapd(m->tap_off_hb, hb_n);
+  else if (s == "q8.latent.qs") tapq(m->tap_off_latent, (size_t)H * c.kv_lora_rank);
+  else if (s == "q8.latent.d") tapd(m->tap_off_latent, (size_t)H * c.kv_lora_rank);
+  else if (s == "q8.x_final.qs") tapq(m->tap_off_final, c.dim);
+  else if (s == "q8.x_final.d") tapd(m->tap_off_final, c.dim);
+  else if (s == "k_cache") { src = L.key_cache; avail = L.key_cache ? kv * H * m->head_dim * 2 : 0; }
+  else if (s == "v_cache") { src = L.value_cache; avail = L.value_cache ? kv * H * c.v_head_dim * 2 : 0; }
+  else if (s == "nope_cache") { src = L.nope_cache; avail = L.nope_cache ? kv * c.kv_lora_rank * 2 : 0; }
+  else if (s == "rope_cache") { src = L.rope_cache; avail = L.rope_cache ? kv * c.qk_rope_head_dim * 2 : 0; }
+  else DSK_FAIL(DSK_ERR_INVALID, "get_stage: unknown stage '%s'", name);
+  if (!src || bytes > avail) DSK_FAIL(DSK_ERR_INVALID, "get_stage: '%s' holds %zu bytes, %zu requested", name, avail, bytes);
+  HIP_TRY(hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
   return DSK_OK;
 }

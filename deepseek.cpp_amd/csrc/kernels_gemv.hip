@@ -420,6 +420,20 @@ DEV void stage_f32(const SRC& T, float* l_x, int tid, float* scratch) {
   }
 }
 
+// parity tap: the staged item records of an n-vector back to the linear Q8_K form (int8 codes, block scales)
+template <bool Q2META>
+DEV void dump_staged_q8(const uint8_t* lds, int n, int8_t* qs, float* d, int tid, int nthreads) {
+  for (int i = tid; i < (n >> 4); i += nthreads) {  // 16-byte runs = sub-blocks
+    const int b = i >> 4, j = i & 15, h = j >> 3, sidx = (j >> 1) & 3, lh = j & 1;
+    const uint8_t* rec = lds + (size_t)(b * 4 + 2 * h + lh) * ITEM_LDS;
+    reinterpret_cast<u32x4*>(qs)[i] = *reinterpret_cast<const u32x4*>(rec + sidx * 16);
+  }
+  for (int b = tid; b < (n >> 8); b += nthreads) {
+    const float* m = reinterpret_cast<const float*>(lds + (size_t)b * 4 * ITEM_LDS + 72);
+    d[b] = Q2META ? m[1] : m[0];
+  }
+}
+
 template <int QT>
 DEV float fitem(u32x4 w, const float* xa, float partial) {
   if (QT == DSK_QUANT_F32) {
@@ -740,7 +754,7 @@ DEV void gemv_body(const GemvLaunch* __restrict__ Lp, const void* h_a0, const vo
   unsigned long long* tl = L.timeline ? L.timeline + (size_t)bid * 8 : nullptr;
   if (tl && tid == 0) tl[0] = t_entry;
 
-  int t0 = 0, t1 = 1, wi, nwg, head = 0;
+  int t0 = 0, t1 = 1, wi, nwg, head = 0, grp_idx = 0;
   const bool bd = L.bd_heads > 0;
   if (bd) {  // block-diagonal stack: workgroup -> head
     head = bid / L.bd_wgs;
@@ -755,6 +769,7 @@ DEV void gemv_body(const GemvLaunch* __restrict__ Lp, const void* h_a0, const vo
     t1 = L.grp_t0[g + 1];
     wi = bid - wg0;
     nwg = L.grp_wg_end[g] - wg0;
+    grp_idx = g;
   }
   auto task_of = [&](int ti) {
     GemvTask T = L.t[ti];
@@ -787,6 +802,11 @@ DEV void gemv_body(const GemvLaunch* __restrict__ Lp, const void* h_a0, const vo
   if (tl && tid == 0) tl[7] = wall_clock64();
   __syncthreads();
   if (tl && tid == 0) tl[1] = wall_clock64();
+  if constexpr (KQ) {
+    if (L.tap_qs && !bd && wi == 0)  // parity tap: what this activation group staged
+      dump_staged_q8<QT == DSK_QUANT_Q2_K>(smem, L.t[t0].n, L.tap_qs + (size_t)grp_idx * L.tap_stride,
+                                          L.tap_d + (size_t)grp_idx * (L.tap_stride >> 8), tid, NW * 64);
+  }
 
   // this workgroup's share of the group's virtual rows, in multiples of part_unit
   const int vtotal = bd ? L.t[0].rows : L.t[t1 - 1].vrow_end;
@@ -983,6 +1003,12 @@ __global__ __launch_bounds__(1024) void head_attn_kernel(const HeadAttnArgs A, c
     else stage_f32<NW>(A.tkv, reinterpret_cast<float*>(act_kv), tid, scratch);
   }
   __syncthreads();
+  if constexpr (KQ) {
+    if (A.tap_qs && blockIdx.x == 0) {  // parity tap
+      if (A.has_q) dump_staged_q8<QT == DSK_QUANT_Q2_K>(act_q, A.tq.n, A.tap_qs, A.tap_d, tid, 1024);
+      dump_staged_q8<QT == DSK_QUANT_Q2_K>(act_kv, A.tkv.n, A.tap_qs + A.tap_stride, A.tap_d + (A.tap_stride >> 8), tid, 1024);
+    }
+  }
 
   // head h's rows of one projection: 64/LPR rows per wave and step.  (Dealing both projections' rows to the
   // waves as one unit list, or 2 row sets per lane, measured slower: this stage is VALU-bound on its one CU.)
@@ -1272,6 +1298,10 @@ __global__ __launch_bounds__(1024) void mla_head_kernel(const MlaHeadArgs A, con
     for (int i = tid; i < lora; i += NT) reinterpret_cast<float*>(act)[i] = o_s[i];
   }
   __syncthreads();
+  if (A.tap_o) {  // parity tap: this head's latent output and the Q8_K vector staged for wv_b
+    for (int i = tid; i < lora; i += NT) A.tap_o[(size_t)h * lora + i] = o_s[i];
+    if constexpr (KQ) dump_staged_q8<QT == DSK_QUANT_Q2_K>(act, lora, A.tap_qs + (size_t)h * lora, A.tap_d + (size_t)h * (lora >> 8), tid, NT);
+  }
   {
     const int lpr_log2 = A.lpr_log2, RPW = 64 >> lpr_log2;
     const int rloc = lane >> lpr_log2, sub = lane & ((1 << lpr_log2) - 1);

@@ -373,8 +373,11 @@ struct Walk {
   }
   int weight(const std::string& base, int role, int layer, bool required) {
     DSK_TRY(bind(base + ".weight", role, layer, required));
+    // need_weight_scales (src/model.cpp:191): an optional weight that IS present needs its scale too (model.output,
+    // src/model.cpp:857-864)
+    const bool have = ck.tensors.find(base + ".weight") != ck.tensors.end();
     if (c.weight_quant == DSK_QUANT_F8E5M2 && role_shape(m, role, layer).quant == DSK_QUANT_F8E5M2)
-      DSK_TRY(bind(base + ".scale", role + DSK_ROLE_SCALE, layer, required));  // need_weight_scales, src/model.cpp:191
+      DSK_TRY(bind(base + ".scale", role + DSK_ROLE_SCALE, layer, required || have));
     return DSK_OK;
   }
   int all() {

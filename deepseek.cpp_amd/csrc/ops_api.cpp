@@ -477,3 +477,35 @@ extern "C" int dsk_bench_router(dsk_ctx* ctx, int n_routed, int dim, int ksplit,
   *us_per_launch = (double)ms * 1e3 / iters;
   return finish(ctx);
 }
+
+// The router GEMV exactly as the model launches it (router_body: 16-wave workgroups, RW rows x 16/RW column slices,
+// slices summed in slice order; rmsnorm recomputed per workgroup): raw logits before scoring (src/infer.cpp:847).
+extern "C" int dsk_router_logits(dsk_ctx* ctx, const float* w, const float* x, const float* norm_w, float eps, int n_routed, int dim,
+                                 float* logits) {
+  DSK_TRY(begin(ctx));
+  if (!w || !x || !logits || n_routed < 1 || n_routed > 256 || dim < 4 || dim % 4) DSK_FAIL(DSK_ERR_INVALID, "router_logits: bad argument");
+  hipStream_t st = ctx_stream(ctx);
+  int ksplit = 8;  // the model's choice (dsk_model_finalize): 8 column slices unless the rows are short
+  while (ksplit > 1 && dim / ksplit < 256) ksplit /= 2;
+  DevBuf dw, dx, dn, partial, cnt, ae, aw;
+  DSK_TRY(dw.alloc((size_t)n_routed * dim * 4));
+  DSK_TRY(dx.alloc((size_t)dim * 4));
+  DSK_TRY(dn.alloc((size_t)dim * 4));
+  DSK_TRY(partial.alloc((size_t)ksplit * n_routed * 4));
+  DSK_TRY(cnt.alloc(64));
+  DSK_TRY(ae.alloc(64));
+  DSK_TRY(aw.alloc(64));
+  HIP_TRY(hipMemcpyAsync(dw.p, w, (size_t)n_routed * dim * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(dx.p, x, (size_t)dim * 4, hipMemcpyHostToDevice, st));
+  if (norm_w) HIP_TRY(hipMemcpyAsync(dn.p, norm_w, (size_t)dim * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(cnt.p, 0, 64, st));
+  RouterArgs r;
+  memset(&r, 0, sizeof r);
+  r.w = dw.as<float>(); r.x = dx.as<float>(); r.norm_w = norm_w ? dn.as<float>() : nullptr; r.eps = eps;
+  r.n_routed = n_routed; r.dim = dim; r.ksplit = ksplit; r.partial = partial.as<float>(); r.counter = cnt.as<unsigned>();
+  r.n_active = 1; r.norm_topk_prob = 0; r.scoring = DSK_SCORE_SIGMOID; r.topk_method = DSK_TOPK_GREEDY; r.n_group = 1; r.topk_group = 1;
+  r.scaling = 1.f; r.active_experts = ae.as<int>(); r.active_weights = aw.as<float>();
+  DSK_TRY(launch_router_gate(st, r));
+  HIP_TRY(hipMemcpyAsync(logits, partial.p, (size_t)n_routed * 4, hipMemcpyDeviceToHost, st));
+  return finish(ctx);
+}

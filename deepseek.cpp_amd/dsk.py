@@ -134,6 +134,10 @@ def lib():
         L.dsk_measure_read_bw.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
         L.dsk_time_kernel_class.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.dsk_expert_shard.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.dsk_model_run_block.argtypes = [C.c_void_p, C.c_int, c_f, C.c_int, c_f]
+        L.dsk_model_run_head.argtypes = [C.c_void_p, c_f, c_f]
+        L.dsk_model_get_stage.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
+        L.dsk_router_logits.argtypes = [C.c_void_p, c_f, c_f, c_f, C.c_float, C.c_int, C.c_int, c_f]
         L.dsk_bench_router.argtypes = [C.c_void_p] + [C.c_int] * 5 + [C.POINTER(C.c_double)]
         L.dsk_bench_gemv.argtypes = [C.c_void_p] + [C.c_int] * 11 + [C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _lib = L
@@ -251,6 +255,15 @@ class Ctx:
                                  lora, rope, kv_len, _f(out)))
         return out
 
+    def router_logits(self, w, x, norm_w=None, eps=1e-6):
+        """raw router logits W(E, dim) . rmsnorm(x, norm_w) in the model's router kernel (src/infer.cpp:839,847)"""
+        w, x = _fa(w), _fa(x)
+        E, dim = w.shape
+        out = np.zeros(E, np.float32)
+        nw = None if norm_w is None else _f(_fa(norm_w))
+        check(lib().dsk_router_logits(self.h, _f(w), _f(x), nw, eps, E, dim, _f(out)))
+        return out
+
     def bench_gemv(self, quant, rows, n, n_tasks=1, kind=0, act_mode=0, lpr=0, R=0, U=0, target_wgs=0, iters=50):
         """-> (us per launch, weight bytes per launch)"""
         us, nb = C.c_double(), C.c_double()
@@ -357,6 +370,29 @@ class Model:
         nxt = C.c_int32()
         check(lib().dsk_forward_argmax(self.h, token, pos, C.byref(nxt)))
         return nxt.value
+
+    def run_block(self, layer: int, x_in, pos: int):
+        """dsk_model_run_block: block `layer` on the residual stream x_in at `pos`, every Q8_K staging point tapped"""
+        x_in = _fa(x_in)
+        out = np.zeros(self.cfg.dim, np.float32)
+        check(lib().dsk_model_run_block(self.h, layer, _f(x_in), pos, _f(out)))
+        return out
+
+    def run_head(self, x_in):
+        x_in = _fa(x_in)
+        out = np.zeros(self.cfg.vocab_size, np.float32)
+        check(lib().dsk_model_run_head(self.h, _f(x_in), _f(out)))
+        return out
+
+    def stage(self, name: str, n: int, dtype=np.float32):
+        """n elements of a named stage buffer of the last run_block / run_head (include/dsk.h dsk_model_get_stage)"""
+        out = np.zeros(n, dtype)
+        check(lib().dsk_model_get_stage(self.h, name.encode(), out.ctypes.data, out.nbytes))
+        return out
+
+    def stage_q8(self, point: str, n: int):
+        """(int8 codes, block scales) the device staged at a Q8_K point"""
+        return self.stage(f"q8.{point}.qs", n, np.int8), self.stage(f"q8.{point}.d", n // 256, np.float32)
 
     def routing(self):
         K = max(1, self.cfg.n_active_routed)

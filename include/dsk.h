@@ -233,6 +233,19 @@ int dsk_model_get_slot_outputs(dsk_model* m, float* out);
 int dsk_model_set_trace(dsk_model* m, int enable);
 int dsk_model_get_trace_x(dsk_model* m, int layer, float* x_out);
 
+/* Teacher-forced execution of ONE block for the parity harness: the residual stream x_in (dim floats) goes in, the
+ * block `layer` runs eagerly at position `pos` (KV caches as the previous calls left them; row kv_pos is written),
+ * x_out receives the block's output.  Every Q8_K staging point of the block (quantize_row_q8_K_ref call sites,
+ * src/infer.cpp:325-336 under :823-931) is tapped: dsk_model_get_stage returns, by name, the int8 codes and block
+ * scales each launch actually staged ("q8.<point>.qs" / ".d": x_attn, q_a, kv_a, att, latent, x_ffn, x_ffn_tap,
+ * x_ffn_shared, hb, x_final) and the float intermediates between the launches (x_mid, q_a, kv_a, att_out, vb_out,
+ * latent_out, q_c, q_rope, router_logits, gate_scores, route_e, route_w, hb, eout) plus the cache rows
+ * [0, kv_len) of the block (k_cache, v_cache, nope_cache, rope_cache).  `bytes` must not exceed the stage's size. */
+int dsk_model_run_block(dsk_model* m, int layer, const float* x_in, int pos, float* x_out);
+/* final norm + classifier on a given residual stream (src/infer.cpp:1292-1316); taps "q8.x_final.*" */
+int dsk_model_run_head(dsk_model* m, const float* x_in, float* logits);
+int dsk_model_get_stage(dsk_model* m, const char* name, void* out, size_t bytes);
+
 /* Per-kernel-class device time of ONE eager forward bracketed by HIP events on the
  * engine stream.  names: up to max_classes pointers to static strings. */
 typedef struct dsk_kernel_time {
@@ -280,6 +293,11 @@ int dsk_attn_mha(dsk_ctx* ctx, const float* q, const uint16_t* kb, const uint16_
 int dsk_attn_mla(dsk_ctx* ctx, const float* q_c, const float* q_rope, const uint16_t* ckv,
                  const uint16_t* krope, int n_heads, int head_dim, int kv_lora_rank, int rope_dim,
                  int kv_len, float* out);
+
+/* The MoE router as the model runs it (F32 GEMV over rmsnorm(x, norm_w) -- src/infer.cpp:839,847 -- in the router
+ * kernel's own summation tree): raw logits (n_routed floats, before scoring).  norm_w may be NULL (x used as is). */
+int dsk_router_logits(dsk_ctx* ctx, const float* w, const float* x, const float* norm_w, float eps, int n_routed, int dim,
+                      float* logits);
 
 /* Measured streaming-read bandwidth of this GPU (GB/s): grid-stride dwordx4 sum over `bytes`
  * (SURVEY 8d "measured roofline" denominator).  Best of `iters`. */

@@ -425,6 +425,28 @@ static int gemv_kquant(int quant, float* out, const float* x, const uint8_t* w, 
   return 0;
 }
 
+/* The same K-quant GEMV with the activation ALREADY quantised (teacher forcing at a Q8_K staging point: the parity
+ * harness feeds the device's own int8 codes and block scales, so the integer dots see identical operands and only the
+ * float association differs).  bsums are recomputed from the codes (exact, src/quant.cpp:643-649). */
+int orc_gemv_q8(int quant, const void* w, int d, int n, const int8_t* qs, const float* yd, float* out) {
+  if (quant != DSK_QUANT_Q2_K && quant != DSK_QUANT_Q3_K) return fail("gemv_q8: k-quants only");
+  if (n % QK_K) return fail("k-quant gemv: n % 256 != 0");
+  int nb = n / QK_K;
+  int16_t* bs = (int16_t*)malloc(sizeof(int16_t) * nb * 16);
+  for (int j = 0; j < nb * 16; ++j) {
+    int sum = 0;
+    for (int ii = 0; ii < 16; ++ii) sum += qs[j * 16 + ii];
+    bs[j] = (int16_t)sum;
+  }
+  size_t row_bytes = (size_t)nb * (quant == DSK_QUANT_Q2_K ? Q2K_BYTES : Q3K_BYTES);
+  for (int i = 0; i < d; i++) {
+    const uint8_t* row = (const uint8_t*)w + (size_t)i * row_bytes;
+    out[i] = quant == DSK_QUANT_Q2_K ? vec_dot_q2k(n, row, qs, yd, bs) : vec_dot_q3k(n, row, qs, yd);
+  }
+  free(bs);
+  return 0;
+}
+
 int orc_gemv(int quant, const void* w, const float* scale, const int32_t* block_size, int d,
              int n, const float* x, float* out) {
   switch (quant) {

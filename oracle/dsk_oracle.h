@@ -35,6 +35,8 @@ void orc_q8k_quantize(const float* x, int n, int8_t* qs, float* d, int16_t* bsum
 void orc_dequant_row(int quant, const void* row, int n, float* y);   /* Q2_K / Q3_K rows */
 int orc_gemv(int quant, const void* w, const float* scale, const int32_t* block_size,
              int d, int n, const float* x, float* out);
+/* K-quant GEMV on a given Q8_K vector (codes + block scales), for teacher-forced parity at a staging point */
+int orc_gemv_q8(int quant, const void* w, int d, int n, const int8_t* qs, const float* yd, float* out);
 int orc_gemv_expert(int quant, const void* w, const float* scale, const int32_t* block_size,
                     int expert, int d, int n, const float* x, float* out);
 int orc_embed_row(int quant, const void* w, const float* scale, const int32_t* block_size,
