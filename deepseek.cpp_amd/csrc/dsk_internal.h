@@ -137,6 +137,40 @@ extern thread_local hipEvent_t g_prof_start, g_prof_stop;
 int gemv_plan(GemvLaunch& h, int target_wgs);
 int gemv_launch(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& host);
 
+// The routed experts of one MoE block in ONE launch (kernels_moe.hip): w1/w3 GLU units, per-slot hand-off, W2 units,
+// k-ordered combine.  Planes of the expert stacks + per-expert strides; the shared expert's W2 as a plain matrix.
+struct MoeFfnArgs {
+  int quant;
+  const uint8_t *w1_qs, *w1_sc, *w1_hm, *w1_dm, *w3_qs, *w3_sc, *w3_hm, *w3_dm;
+  const uint8_t *w2_qs, *w2_sc, *w2_hm, *w2_dm;
+  size_t e13_qs, e13_sc, e13_hm, e13_dm, e2_qs, e2_sc, e2_hm, e2_dm;
+  const uint8_t *sw2_qs, *sw2_sc, *sw2_hm, *sw2_dm;  // shared expert's W2 (dim, shared_n); unused when shared_n == 0
+  int shared_n;
+  const int* route_e;    // this layer's K selected experts / mixing weights (device, written by the router launch)
+  const float* route_w;
+  int K, mi, dim, act;
+  const int8_t* a_qs;    // Q8_K of rmsnorm(x, ffn_norm): left behind by the router launch
+  const float* a_d;
+  const int16_t* a_bsums;
+  float* hb;             // hidden vectors [slot][hb_stride] (slot K = the shared expert's, written by the router launch)
+  int hb_stride;
+  float* eout;           // slot outputs [slot][dim]
+  float* x;              // residual stream
+  unsigned* slot_ctr;    // [K] phase-A arrivals per slot; slot_pass [K]: consumers that have passed (re-arms both)
+  unsigned* slot_pass;
+  unsigned* comb_ctr;    // one arrival counter per 256-row group of the combine
+  int comb_ctr_cap;
+  unsigned* err;         // host-visible: set when a bounded spin gives up
+  int lprA_log2, lprB_log2;  // lanes per row of the two halves (= the two-launch plans': bit-identical results)
+  int UA, UB, lds_a, lds_b, grid;  // filled by moe_ffn_plan
+  int8_t* tap_qs;        // parity taps (dsk_model_run_block): slot s's staged hidden vector at s * tap_stride
+  float* tap_d;
+  int tap_stride;
+  double algo_bytes;
+};
+int moe_ffn_plan(MoeFfnArgs& a, int n_cus);
+int launch_moe_ffn(hipStream_t st, const MoeFfnArgs& a, hipEvent_t ev_start, hipEvent_t ev_stop);
+
 // per-token parameters living in device memory so that a captured graph can be replayed
 struct StepParams {
   int token, pos, kv_sink, kv_pos, kv_len;

@@ -48,6 +48,8 @@ extern "C" int dsk_ctx_create(int device_ordinal, dsk_ctx** out) {
   dsk_ctx* c = new dsk_ctx();
   c->device = device_ordinal;
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_ordinal) == hipSuccess && cus > 0) c->n_cus = cus;
   *out = c;
   return DSK_OK;
 }
@@ -617,6 +619,11 @@ extern "C" int dsk_model_finalize(dsk_model* m) {
   HIP_TRY(hipMemset(m->att_counter, 0, ((size_t)c.n_heads * c.v_head_dim / 256 + 2) * 4));
   HIP_TRY(hipMalloc((void**)&m->comb_counter, (size_t)c.dim * 4));
   HIP_TRY(hipMemset(m->comb_counter, 0, (size_t)c.dim * 4));
+  HIP_TRY(hipMalloc((void**)&m->moe_ctr, 32 * 4));
+  HIP_TRY(hipMemset(m->moe_ctr, 0, 32 * 4));
+  HIP_TRY(hipHostMalloc((void**)&m->err_host, 64, hipHostMallocDefault));
+  memset(m->err_host, 0, 64);
+  m->fuse_moe = getenv("DSK_NO_FUSE_MOE") == nullptr;
   m->ride_shared = getenv("DSK_NO_FUSE_SHARED") == nullptr;    // A/B and test knobs: the ride-along launches can be
   m->ride_kvwrite = getenv("DSK_NO_KVWRITE_RIDE") == nullptr;  // switched back to separate launches per model
   DSK_TRY(build_plans(m));
@@ -660,6 +667,8 @@ extern "C" int dsk_model_destroy(dsk_model* m) {
   free_plans(m);
   for (void* p : {(void*)m->tap_qs, (void*)m->tap_d, (void*)m->tap_latent, (void*)m->stage_x_mid})
     if (p) hipFree(p);
+  if (m->moe_ctr) hipFree(m->moe_ctr);
+  if (m->err_host) hipHostFree(m->err_host);
   if (m->router_counter) hipFree(m->router_counter);
   if (m->comb_counter) hipFree(m->comb_counter);
   if (m->att_counter) hipFree(m->att_counter);

@@ -21,6 +21,7 @@ struct dsk_ctx {
   hipStream_t stream = nullptr;
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1;
+  int n_cus = 256;       // compute units of the device (resident-grid kernels size themselves by it)
   int live_models = 0;   // models created on this context and not yet destroyed
   bool closing = false;  // dsk_ctx_destroy was called while models were alive: freed by the last dsk_model_destroy
   // scratch for op-level entry points
@@ -103,6 +104,11 @@ struct dsk_model {
   std::vector<int> lp_qkv_a, lp_qkv_b, lp_wv_b, lp_wo, lp_w13, lp_w2;  // per-layer indices into plans (-1: none)
   bool ride_shared = true, ride_kvwrite = true;  // DSK_NO_FUSE_SHARED / DSK_NO_KVWRITE_RIDE at model creation switch them off
   std::vector<int> lp_sh13;  // shared expert's w1/w3 GLU riding in the router launch (-1: it is a task of lp_w13)
+  // routed experts in one launch (kernels_moe.hip); grid == 0: the layer keeps the two-launch form (lp_w13, lp_w2)
+  std::vector<MoeFfnArgs> moe_ffn;
+  bool fuse_moe = true;            // DSK_NO_FUSE_MOE at model creation switches it off (A/B, bit-identity tests)
+  unsigned* moe_ctr = nullptr;     // slot_ctr[16] | slot_pass[16]
+  unsigned* err_host = nullptr;    // pinned, device-visible: bounded spins report here
   int lp_head = -1;
   std::vector<MlaHeadArgs> mla_head;   // per layer (MLA path)
   std::vector<double> head_attn_bytes;

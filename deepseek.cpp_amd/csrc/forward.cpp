@@ -143,6 +143,11 @@ int build_plans(dsk_model* m) {
     m->mla_flash.assign(nl, z);
   }
   m->head_attn_bytes.assign(nl, 0.0);
+  {
+    MoeFfnArgs z;
+    memset(&z, 0, sizeof z);
+    m->moe_ffn.assign(nl, z);
+  }
   for (int l = 0; l < nl; ++l) {
     Layer& L = m->L[l];
     {  // 1. wq_a (or wq) || wkv_a on rmsnorm(x, attn_norm)
@@ -354,6 +359,34 @@ int build_plans(dsk_model* m) {
       h.algo_bytes = bytes;
       DSK_TRY(add_plan(m, h, &m->lp_w2[l]));
     }
+    // 8+9 in ONE launch (kernels_moe.hip): K-quants, one GPU, the shared expert's w1/w3 riding in the router launch
+    // (or no shared expert).  Same lanes per row as the two plans above => bit-identical results.
+    if (kq && m->ctx->world == 1 && m->fuse_moe && c.dim % 256 == 0 && (c.n_shared_experts == 0 || m->lp_sh13[l] >= 0) && K <= 16) {
+      MoeFfnArgs a;
+      memset(&a, 0, sizeof a);
+      a.quant = wq;
+      a.w1_qs = w1.qs; a.w1_sc = w1.sc; a.w1_hm = w1.hm; a.w1_dm = w1.dm;
+      a.w3_qs = w3.qs; a.w3_sc = w3.sc; a.w3_hm = w3.hm; a.w3_dm = w3.dm;
+      a.w2_qs = w2.qs; a.w2_sc = w2.sc; a.w2_hm = w2.hm; a.w2_dm = w2.dm;
+      a.e13_qs = w1.e_qs; a.e13_sc = w1.e_sc; a.e13_hm = w1.e_hm; a.e13_dm = w1.e_dm;
+      a.e2_qs = w2.e_qs; a.e2_sc = w2.e_sc; a.e2_hm = w2.e_hm; a.e2_dm = w2.e_dm;
+      if (c.n_shared_experts > 0) {
+        const DTensor& s2 = L.t[DSK_ROLE_SHARED_W2];
+        a.sw2_qs = s2.qs; a.sw2_sc = s2.sc; a.sw2_hm = s2.hm; a.sw2_dm = s2.dm;
+        a.shared_n = shared_n;
+      }
+      a.route_e = ae; a.route_w = aw;
+      a.K = K; a.mi = mi; a.dim = c.dim; a.act = c.act;
+      a.a_qs = m->a_xb.qs; a.a_d = m->a_xb.d; a.a_bsums = m->a_xb.bsums;
+      a.hb = m->hb; a.hb_stride = hb_stride; a.eout = m->eout; a.x = m->x;
+      a.slot_ctr = m->moe_ctr; a.slot_pass = m->moe_ctr + 16;
+      a.comb_ctr = m->comb_counter; a.comb_ctr_cap = c.dim;
+      a.err = m->err_host;
+      a.lprA_log2 = m->plans[m->lp_w13[l]].lpr_log2;
+      a.lprB_log2 = m->plans[m->lp_w2[l]].lpr_log2;
+      a.algo_bytes = m->plans[m->lp_w13[l]].algo_bytes + m->plans[m->lp_w2[l]].algo_bytes;
+      if (moe_ffn_plan(a, m->ctx->n_cus) == DSK_OK) m->moe_ffn[l] = a;  // otherwise: the two-launch form
+    }
   }
   {  // classifier on rmsnorm(x, final_norm) (src/infer.cpp:1292-1316)
     GemvLaunch h;
@@ -512,6 +545,23 @@ static int ffn(dsk_model* m, int l) {
     PROFILED("router_gate", (double)E * c.dim * 4 + c.dim * 8.0, launch_router_gate(st, r));
   }
   const bool exchange = m->ctx->world > 1 && !m->class_filter;  // (class timing enqueues one kernel class only)
+  if (m->moe_ffn[l].grid > 0) {  // routed experts (+ the shared expert's W2) + combine: one launch
+    MoeFfnArgs a = m->moe_ffn[l];
+    if (m->stage_layer == l && m->tap_qs) {
+      a.tap_qs = m->tap_qs + m->tap_off_hb;
+      a.tap_d = m->tap_d + m->tap_off_hb / 256;
+      a.tap_stride = a.hb_stride;
+    }
+    if (m->profiling && !m->class_filter) {  // the kernel's own dispatch timestamps, like run_plan
+      Prof p;
+      DSK_TRY(prof_begin(m, "moe_ffn", a.algo_bytes, &p, false));
+      DSK_TRY(launch_moe_ffn(st, a, p.e0, p.e1));
+      m->ktimes[p.idx].ev.push_back({p.e0, p.e1});
+    } else {
+      PROFILED("moe_ffn", a.algo_bytes, launch_moe_ffn(st, a, nullptr, nullptr));
+    }
+    return DSK_OK;
+  }
   DSK_TRY(run_plan(m, "gemv_experts_w13", m->lp_w13[l]));
   DSK_TRY(run_plan(m, "gemv_experts_w2", m->lp_w2[l]));
   if (exchange || (m->ctx->world > 1 && m->class_filter)) {
@@ -604,6 +654,12 @@ static int run_token(dsk_model* m, int token, int pos, int mode) {
   }
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipGetLastError());
+  if (m->err_host && *m->err_host) {  // a bounded in-kernel spin gave up (kernels_moe.hip): the step's results are invalid
+    *m->err_host = 0;
+    hipMemset(m->moe_ctr, 0, 32 * 4);  // the arrival counters are in an unknown state: re-arm them
+    hipMemset(m->comb_counter, 0, (size_t)m->c.dim * 4);
+    DSK_FAIL(DSK_ERR_HIP, "forward: an in-kernel hand-off timed out");
+  }
   return DSK_OK;
 }
 

@@ -56,6 +56,16 @@ def f16_ulp_diff(a_bits, b_bits):
     return np.abs(ia - ib)
 
 
+def f16_row_diff(row_bits, ref_f32):
+    """last-place distance between a cached f16 row and the f16 rounding (RNE, src/codec.h:26-27) of the expected f32
+    values; an element whose ABSOLUTE difference is below 1e-6 of the row's scale counts as equal (a rotated pair
+    v0*c - v1*s that cancels is tiny and carries the f32 rounding of its terms: any number of f16 places, no information)"""
+    ref_f32 = np.asarray(ref_f32, np.float32)
+    d = f16_ulp_diff(row_bits, ref_f32.astype(np.float16).view(np.uint16))
+    absd = np.abs(np.asarray(row_bits, np.uint16).view(np.float16).astype(np.float64) - ref_f32.astype(np.float16).astype(np.float64))
+    return np.where(absd <= 1e-6 * max(float(np.max(np.abs(ref_f32))), 1e-30), 0, d)
+
+
 class Audit:
     """Collects the evidence of one block."""
 
@@ -94,7 +104,11 @@ def audit_codes(A: Audit, orc, point, y, qh, dh, exact):
         assert np.array_equal(qh, qo), (point, "codes differ on identical inputs", int(np.sum(qh != qo)))
         A.flips[point] = (0, 0.0)
         return
-    assert np.max(ulp_diff_f32(dh, do)) <= 8, (point, "block scales", float(np.max(ulp_diff_f32(dh, do))))
+    # a norm in front: the sum of squares over the vector is associated differently (sequential in the oracle, a fixed
+    # tree on the device; the reference's own is an auto-vectorised 8-lane sum): a common factor of 1 +- O(sqrt(n) eps)
+    # on the whole vector, which moves every block scale alike and no code (codes depend on ratios within the block)
+    rel = np.abs(dh.astype(np.float64) - do) / np.maximum(np.abs(do.astype(np.float64)), 1e-30)
+    assert np.max(rel) <= 1e-5, (point, "block scales", float(np.max(rel)))
     bad = np.nonzero(qh != qo)[0]
     worst = 0.0
     if bad.size:
@@ -163,8 +177,8 @@ class BlockAuditor:
         kc = dev.stage("k_cache", kv_len * H * hd, np.uint16).reshape(kv_len, H * hd)
         vc = dev.stage("v_cache", kv_len * H * vd, np.uint16).reshape(kv_len, H * vd)
         # this position's cache row: f32 -> f16 RNE of values that agree to ~1e-6 may differ in the last f16 place
-        dk = f16_ulp_diff(kc[kv_pos], k.reshape(-1).astype(np.float16).view(np.uint16))
-        dv = f16_ulp_diff(vc[kv_pos], v.reshape(-1).astype(np.float16).view(np.uint16))
+        dk = f16_row_diff(kc[kv_pos], k.reshape(-1))
+        dv = f16_row_diff(vc[kv_pos], v.reshape(-1))
         assert dk.max() <= 1 and dv.max() <= 1, ("cache row", int(dk.max()), int(dv.max()))
         assert (dk > 0).mean() < 0.02 and (dv > 0).mean() < 0.02, ("cache row: too many last-place differences", float((dk > 0).mean()))
         A.notes.append(f"cache row: {float(max((dk > 0).mean(), (dv > 0).mean())):.4f} of the f16 values differ in the last place")
@@ -193,8 +207,8 @@ class BlockAuditor:
         rc = dev.stage("rope_cache", kv_len * rope, np.uint16).reshape(kv_len, rope)
         lat = orc.rmsnorm(kv_a[:lora], self.w(l, "attn.kv_a_norm"), c.norm_eps)
         k_rope = orc.rope(kv_a[lora:], rope, pos, c.rope_theta, v3)
-        dn = f16_ulp_diff(nc[kv_pos], lat.astype(np.float16).view(np.uint16))
-        dr = f16_ulp_diff(rc[kv_pos], k_rope.astype(np.float16).view(np.uint16))
+        dn = f16_row_diff(nc[kv_pos], lat)
+        dr = f16_row_diff(rc[kv_pos], k_rope)
         assert dn.max() <= 1 and dr.max() <= 1, ("latent cache row", int(dn.max()), int(dr.max()))
         assert (dn > 0).mean() < 0.05, float((dn > 0).mean())
         qr = q_rope.reshape(H, rope).copy()

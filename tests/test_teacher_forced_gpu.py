@@ -19,11 +19,14 @@ from tools import synth
 pytestmark = pytest.mark.gpu
 
 
-def _free_running_check(A, x_hip, x_orc, what):
+def _free_running_check(A, x_hip, x_orc, what, pos):
     """x_l of the device against the oracle's own x_l on the same x_{l-1}.  Without a flipped int8 code the two differ
-    by float association only; with flips (each proven a tie by the audit) the int8 noise of W2A8 shows up."""
+    by float association only; with flips (each proven a tie by the audit) the int8 noise of W2A8 shows up.  At
+    pos > 0 the block also reads the cache rows earlier calls wrote (a flip at an earlier position, or an f16 last-place
+    difference, lives on there), so the strict bound applies to pos 0; the audit itself has no such caveat: it
+    recomputes attention from the DEVICE's cache."""
     e = rel_inf(x_hip, x_orc)
-    if A.total_flips() == 0 and "route_tie_gap" not in A.errs:
+    if A.total_flips() == 0 and "route_tie_gap" not in A.errs and pos == 0:
         assert e < 1e-3, (what, e, A.summary())
     else:
         assert e < 5e-2, (what, e, A.summary())
@@ -51,11 +54,11 @@ def test_every_block_teacher_forced_on_the_oracle_stream(ctx, oracle, case):
             flips += A.total_flips()
             worst = max(worst, max(A.errs.values()))
             x_orc = O.trace_x(l)
-            free.append(_free_running_check(A, x_hip, x_orc, (case_id(case), pos, l)))
+            free.append(_free_running_check(A, x_hip, x_orc, (case_id(case), pos, l), pos))
             x = x_orc  # teacher forcing: the next block sees the oracle's stream
         A, logits = teacher.audit_head(oracle, c, T, M, x)
         flips += A.total_flips()
-        if A.total_flips() == 0:
+        if A.total_flips() == 0 and pos == 0:
             assert rel_inf(logits, lo) < 1e-3
     print(f"\n[{case_id(case)}] {5 * c.n_layers} blocks: worst stage error {worst:.2e}, {flips} near-tie flips, "
           f"free-running x_l error median {np.median(free):.2e} max {max(free):.2e}")
@@ -96,7 +99,7 @@ def test_v3_full_width_256_experts_teacher_forced(ctx, oracle, mla):
             flips += A.total_flips()
             worst = max(worst, max(A.errs.values()))
             x_orc = O.trace_x(l)
-            free.append(_free_running_check(A, x_hip, x_orc, ("v3", "mla" if mla else "mha", pos, l)))
+            free.append(_free_running_check(A, x_hip, x_orc, ("v3", "mla" if mla else "mha", pos, l), pos))
             if l >= c.first_k_dense_replace:
                 e_dev = M.stage("route_e", c.n_active_routed, np.int32)
                 routes.append(bool(np.array_equal(e_dev, O.routing()[0][l])))
