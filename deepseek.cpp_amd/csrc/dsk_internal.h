@@ -105,6 +105,7 @@ struct GemvLaunch {
   int NW;                     // waves per workgroup (4 or 16)
   int part_unit;              // rows are dealt to workgroups in multiples of this
   int force_lpr, force_R, force_U, force_NW;  // > 0: override the planner (micro-benchmarks)
+  int fill_div;               // > 0: a group may take up to fill_div x rows / (rows per step) workgroups (default 2: half-filled)
   int b0, b1;                 // F8 block-scale geometry
   // block-diagonal stack (MLA per-head wv_b, src/infer.cpp:1134-1137): t[0] describes head 0 of
   // `bd_heads` equal (rows, n) matrices stacked along rows; head h reads activation a_f32 + h*n and
@@ -156,13 +157,12 @@ struct MoeFfnArgs {
   int hb_stride;
   float* eout;           // slot outputs [slot][dim]
   float* x;              // residual stream
-  unsigned* slot_ctr;    // [K] phase-A arrivals per slot; slot_pass [K]: consumers that have passed (re-arms both)
-  unsigned* slot_pass;
-  unsigned* comb_ctr;    // one arrival counter per 256-row group of the combine
-  int comb_ctr_cap;
+  int n_experts;         // experts in the stacks (offset range check)
+  unsigned* slot_ctr;    // [K] phase-A arrivals per slot; zeroed by the router launch of the same block
   unsigned* err;         // host-visible: set when a bounded spin gives up
   int lprA_log2, lprB_log2;  // lanes per row of the two halves (= the two-launch plans': bit-identical results)
-  int UA, UB, lds_a, lds_b, grid;  // filled by moe_ffn_plan
+  int UA, rows_wg, lds_a, lds_b, lds_o, grid;  // filled by moe_ffn_plan
+  unsigned long long* timeline;  // debug (DSK_MOE_TIMELINE=1): 8 wall-clock stamps per workgroup (100 MHz ticks)
   int8_t* tap_qs;        // parity taps (dsk_model_run_block): slot s's staged hidden vector at s * tap_stride
   float* tap_d;
   int tap_stride;
@@ -230,6 +230,10 @@ struct RouterArgs {       // F32 router GEMV (+ optional rmsnorm prologue) + moe
   float* q_d;
   int16_t* q_bsums;
   int dbg;                // micro-benchmark only: 1 = skip the gate, 2 = skip the weight stream, 4 = skip the norm
+  // arrival counters of a LATER launch of the same block that the gate workgroup zeroes (the fused expert launch's slot
+  // counters, kernels_moe.hip): their previous users finished before this launch started (stream order)
+  unsigned* zero_ctr;
+  int zero_n;
 };
 int launch_router_gate(hipStream_t st, const RouterArgs& a);
 struct GemvLaunch;

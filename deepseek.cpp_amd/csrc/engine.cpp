@@ -624,6 +624,10 @@ extern "C" int dsk_model_finalize(dsk_model* m) {
   HIP_TRY(hipHostMalloc((void**)&m->err_host, 64, hipHostMallocDefault));
   memset(m->err_host, 0, 64);
   m->fuse_moe = getenv("DSK_NO_FUSE_MOE") == nullptr;
+  if (getenv("DSK_MOE_TIMELINE")) {
+    HIP_TRY(hipMalloc((void**)&m->moe_timeline, 1024 * 8 * 8));
+    HIP_TRY(hipMemset(m->moe_timeline, 0, 1024 * 8 * 8));
+  }
   m->ride_shared = getenv("DSK_NO_FUSE_SHARED") == nullptr;    // A/B and test knobs: the ride-along launches can be
   m->ride_kvwrite = getenv("DSK_NO_KVWRITE_RIDE") == nullptr;  // switched back to separate launches per model
   DSK_TRY(build_plans(m));
@@ -668,6 +672,7 @@ extern "C" int dsk_model_destroy(dsk_model* m) {
   for (void* p : {(void*)m->tap_qs, (void*)m->tap_d, (void*)m->tap_latent, (void*)m->stage_x_mid})
     if (p) hipFree(p);
   if (m->moe_ctr) hipFree(m->moe_ctr);
+  if (m->moe_timeline) hipFree(m->moe_timeline);
   if (m->err_host) hipHostFree(m->err_host);
   if (m->router_counter) hipFree(m->router_counter);
   if (m->comb_counter) hipFree(m->comb_counter);

@@ -108,6 +108,7 @@ struct dsk_model {
   std::vector<MoeFfnArgs> moe_ffn;
   bool fuse_moe = true;            // DSK_NO_FUSE_MOE at model creation switches it off (A/B, bit-identity tests)
   unsigned* moe_ctr = nullptr;     // slot_ctr[16] | slot_pass[16]
+  unsigned long long* moe_timeline = nullptr;  // DSK_MOE_TIMELINE=1: stamps of the LAST fused expert launch of a token
   unsigned* err_host = nullptr;    // pinned, device-visible: bounded spins report here
   int lp_head = -1;
   std::vector<MlaHeadArgs> mla_head;   // per layer (MLA path)

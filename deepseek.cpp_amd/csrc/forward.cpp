@@ -307,6 +307,9 @@ int build_plans(dsk_model* m) {
         GemvLaunch hs;
         memset(&hs, 0, sizeof hs);
         hs.quant = wq; hs.glu = 1; hs.force_NW = 16;
+        // 128 quarter-filled workgroups next to the router's 128: at 64 the rider was bound by what ONE CU streams
+        // (~24 GB/s: 14.5 MB / 64 CUs = 9 us) and the launch by the rider (13.7 -> 12.5 us)
+        hs.fill_div = getenv("DSK_RIDER_FILL") ? atoi(getenv("DSK_RIDER_FILL")) : 4;
         GemvTask& T = hs.t[hs.n_tasks++];
         task_weights(T, L.t[DSK_ROLE_SHARED_W1]);
         task_weights2(T, L.t[DSK_ROLE_SHARED_W3]);
@@ -379,9 +382,10 @@ int build_plans(dsk_model* m) {
       a.K = K; a.mi = mi; a.dim = c.dim; a.act = c.act;
       a.a_qs = m->a_xb.qs; a.a_d = m->a_xb.d; a.a_bsums = m->a_xb.bsums;
       a.hb = m->hb; a.hb_stride = hb_stride; a.eout = m->eout; a.x = m->x;
-      a.slot_ctr = m->moe_ctr; a.slot_pass = m->moe_ctr + 16;
-      a.comb_ctr = m->comb_counter; a.comb_ctr_cap = c.dim;
+      a.slot_ctr = m->moe_ctr;
+      a.n_experts = c.n_routed_experts;
       a.err = m->err_host;
+      a.timeline = m->moe_timeline;
       a.lprA_log2 = m->plans[m->lp_w13[l]].lpr_log2;
       a.lprB_log2 = m->plans[m->lp_w2[l]].lpr_log2;
       a.algo_bytes = m->plans[m->lp_w13[l]].algo_bytes + m->plans[m->lp_w2[l]].algo_bytes;
@@ -538,6 +542,7 @@ static int ffn(dsk_model* m, int l) {
   r.active_weights = m->route_w + (size_t)l * K;
   r.scores_out = m->gate_scores + (size_t)l * E;
   if (is_kq(c.weight_quant) && c.dim % 256 == 0) { r.q_qs = m->a_xb.qs; r.q_d = m->a_xb.d; r.q_bsums = m->a_xb.bsums; }
+  if (m->moe_ffn[l].grid > 0) { r.zero_ctr = m->moe_ffn[l].slot_ctr; r.zero_n = K; }  // re-arm the expert launch's slot counters
   if (m->lp_sh13[l] >= 0) {
     const GemvLaunch& hs = m->plans[m->lp_sh13[l]];
     PROFILED("router_gate", (double)E * c.dim * 4 + c.dim * 8.0 + hs.algo_bytes, launch_router_shared(st, r, m->plans_dev + m->lp_sh13[l], hs));
@@ -547,6 +552,8 @@ static int ffn(dsk_model* m, int l) {
   const bool exchange = m->ctx->world > 1 && !m->class_filter;  // (class timing enqueues one kernel class only)
   if (m->moe_ffn[l].grid > 0) {  // routed experts (+ the shared expert's W2) + combine: one launch
     MoeFfnArgs a = m->moe_ffn[l];
+    // (class timing enqueues this class alone: no router launch in front re-arms the slot counters)
+    if (m->class_filter) HIP_TRY(hipMemsetAsync(m->moe_ctr, 0, 32 * 4, st));
     if (m->stage_layer == l && m->tap_qs) {
       a.tap_qs = m->tap_qs + m->tap_off_hb;
       a.tap_d = m->tap_d + m->tap_off_hb / 256;
@@ -987,5 +994,14 @@ extern "C" int dsk_model_get_stage(dsk_model* m, const char* name, void* out, si
   else DSK_FAIL(DSK_ERR_INVALID, "get_stage: unknown stage '%s'", name);
   if (!src || bytes > avail) DSK_FAIL(DSK_ERR_INVALID, "get_stage: '%s' holds %zu bytes, %zu requested", name, avail, bytes);
   HIP_TRY(hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
+  return DSK_OK;
+}
+
+// debug: the 8 wall-clock stamps (100 MHz) per workgroup of the last fused expert launch (DSK_MOE_TIMELINE=1 at model creation)
+extern "C" int dsk_model_get_moe_timeline(dsk_model* m, unsigned long long* out, int n_wgs) {
+  if (!m || !out || n_wgs < 1 || n_wgs > 1024) DSK_FAIL(DSK_ERR_INVALID, "get_moe_timeline: bad argument");
+  if (!m->moe_timeline) DSK_FAIL(DSK_ERR_STATE, "get_moe_timeline: set DSK_MOE_TIMELINE=1 before creating the model");
+  HIP_TRY(hipSetDevice(m->ctx->device));
+  HIP_TRY(hipMemcpy(out, m->moe_timeline, (size_t)n_wgs * 64, hipMemcpyDeviceToHost));
   return DSK_OK;
 }

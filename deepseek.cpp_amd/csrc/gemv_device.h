@@ -402,7 +402,7 @@ DEV void stage_f32(const SRC& T, float* l_x, int tid, float* scratch) {
 
 // parity tap: the staged item records of an n-vector back to the linear Q8_K form (int8 codes, block scales)
 template <bool Q2META>
-DEV void dump_staged_q8(const uint8_t* lds, int n, int8_t* qs, float* d, int tid, int nthreads) {
+__device__ __attribute__((noinline)) void dump_staged_q8(const uint8_t* lds, int n, int8_t* qs, float* d, int tid, int nthreads) {
   for (int i = tid; i < (n >> 4); i += nthreads) {  // 16-byte runs = sub-blocks
     const int b = i >> 4, j = i & 15, h = j >> 3, sidx = (j >> 1) & 3, lh = j & 1;
     const uint8_t* rec = lds + (size_t)(b * 4 + 2 * h + lh) * ITEM_LDS;
@@ -657,6 +657,9 @@ DEV void compute_chunk_f(const ChunkF<QT, R, U, GLU>& c, int n, int lpr_log2, in
   }
 }
 
+#ifndef KQ_PIPELINE
+#define KQ_PIPELINE 1  // -DKQ_PIPELINE=0: the single-buffer loop (A/B builds)
+#endif
 // dot products of R rows (x 64/LPR rows per wave) with a staged activation vector.
 // `pre`: the first chunk was already requested by the caller (prefetch across the prologue).
 template <int QT, int R, int U, bool GLU>
@@ -665,12 +668,31 @@ DEV void rows_dot_kq(const KQRsrc& B, int items, int sub, int lpr_log2, int q, c
   const int its = (items + (1 << lpr_log2) - 1) >> lpr_log2;
   // (requesting the first weight chunk before the staging prologue was measured and is slower: loads
   // return in order, so the prologue's L2 reads queue behind the HBM reads, and the chunk costs registers)
-  ChunkKQ<QT, R, U, GLU> c;
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = acc2[r] = 0.f;
-  for (int it0 = 0; it0 < its; it0 += U) {
-    load_chunk_kq<QT, R, U, GLU>(c, B, its, items, sub, lpr_log2, q, rowblk, it0);
-    compute_chunk_kq<QT, R, U, GLU>(c, its, items, sub, lpr_log2, q, it0, lds_lane, acc, acc2);
+  if constexpr (KQ_PIPELINE && (U >= 4 || (U >= 2 && QT == DSK_QUANT_Q2_K))) {
+    // Two half-chunks in flight alternately: while one is multiplied the other's loads are outstanding, so a wave's
+    // VALU work (~half of the time budget of a streamed item) overlaps its own memory traffic instead of alternating
+    // with it (the waves of a workgroup start in lock step: without this every wave loads, then every wave computes).
+    // Column steps are consumed in order, exactly as below: same sums, same bits.
+    constexpr int H = U / 2;
+    ChunkKQ<QT, R, H, GLU> ca, cb;
+    load_chunk_kq<QT, R, H, GLU>(ca, B, its, items, sub, lpr_log2, q, rowblk, 0);
+    if (H < its) load_chunk_kq<QT, R, H, GLU>(cb, B, its, items, sub, lpr_log2, q, rowblk, H);
+    for (int it0 = 0; it0 < its; it0 += 2 * H) {
+      compute_chunk_kq<QT, R, H, GLU>(ca, its, items, sub, lpr_log2, q, it0, lds_lane, acc, acc2);
+      if (it0 + 2 * H < its) load_chunk_kq<QT, R, H, GLU>(ca, B, its, items, sub, lpr_log2, q, rowblk, it0 + 2 * H);
+      if (it0 + H < its) {
+        compute_chunk_kq<QT, R, H, GLU>(cb, its, items, sub, lpr_log2, q, it0 + H, lds_lane, acc, acc2);
+        if (it0 + 3 * H < its) load_chunk_kq<QT, R, H, GLU>(cb, B, its, items, sub, lpr_log2, q, rowblk, it0 + 3 * H);
+      }
+    }
+  } else {
+    ChunkKQ<QT, R, U, GLU> c;
+    for (int it0 = 0; it0 < its; it0 += U) {
+      load_chunk_kq<QT, R, U, GLU>(c, B, its, items, sub, lpr_log2, q, rowblk, it0);
+      compute_chunk_kq<QT, R, U, GLU>(c, its, items, sub, lpr_log2, q, it0, lds_lane, acc, acc2);
+    }
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {

@@ -883,7 +883,20 @@ int gemv_plan(GemvLaunch& h, int target_wgs) {
   // a quarter of the blocks per wave and a quarter of the redundant prologues.
   h.NW = 4;
   if (!cg && h.bd_heads <= 0 && total_rows >= 192L * 16 * RPW * h.R) h.NW = 16;
+  // small launches (the first-stage projections: 2112 rows of 7168): 16-wave workgroups quarter-filled with rows still
+  // quantise the activation vector four times faster than 4-wave ones (2 instead of 7 blocks per wave)
+  static const int small_nw16 = getenv("DSK_SMALL_NW16") ? atoi(getenv("DSK_SMALL_NW16")) : 1;  // measured: qkv_a 9.7 -> 7.9 us
+  int fill_div = 2;
+  if (small_nw16 && h.NW == 4 && !cg && h.bd_heads <= 0 && kq && h.force_NW <= 0 && total_rows >= 32L * 16 * RPW) { h.NW = 16; fill_div = 4; }
   if (h.force_NW == 4 || h.force_NW == 16) h.NW = h.force_NW;
+  if (h.fill_div > 0) fill_div = h.fill_div;
+  // (two rows per lane so that a workgroup's share fits ONE step -- wo: 28 rows at 16 per step -- measured slower:
+  // 12.0 -> 13.1 us; kept behind DSK_R2 for A/B runs)
+  static const int r2 = getenv("DSK_R2") ? atoi(getenv("DSK_R2")) : 0;
+  if (r2 && !cg && !h.glu && h.bd_heads <= 0 && h.NW == 16 && h.force_R <= 0 && h.R == 1 && h.quant != DSK_QUANT_Q3_K) {
+    const long per_wg = (total_rows + 255) / 256;
+    if (per_wg > 16L * RPW && per_wg <= 32L * RPW) { h.R = 2; if (h.U > 4) h.U = 4; }
+  }
   // Q3_K items hold three planes per step: under the 128-VGPR budget of a 16-wave workgroup the wide
   // variants spill inside the column loop (hipcc: 172..664 B of scratch), so they take fewer steps in flight
   if (h.quant == DSK_QUANT_Q3_K && h.NW == 16 && h.force_U <= 0) {
@@ -927,7 +940,7 @@ int gemv_plan(GemvLaunch& h, int target_wgs) {
     int share = (int)(W * (work_g / total_work) + 0.5);
     const long units = (rows_g + h.part_unit - 1) / h.part_unit;
     // no more workgroups than half-filled row groups (combine: than whole groups, evenly dealt)
-    long cap = cg ? units : (2 * rows_g + RG - 1) / RG;
+    long cap = cg ? units : (fill_div * rows_g + RG - 1) / RG;
     if (share > cap) share = (int)cap;
     if (share < 1) share = 1;
     if (cg) share = (int)((units + (units + share - 1) / share - 1) / ((units + share - 1) / share));

@@ -4,19 +4,20 @@
 //     h_k  = act(W1[e_k] xb) * (W3[e_k] xb)          matmul_expert x2 + GLU
 //     o_k  = W2[e_k] h_k                              matmul_expert (h_k re-quantised to Q8_K, src/infer.cpp:325-336)
 //     x   += w_k * o_k  (k order),  x += shared_out   (the shared expert's W2 runs here too)
-// The two-launch form (gemv w1/w3 -> gemv w2 + combine) pays a kernel boundary and a full prologue between the halves
-// although slot k's second half only needs slot k's hidden vector.  Here one resident grid of 16-wave workgroups (one
-// per CU) runs both halves:
+// The two-launch form (gemv w1/w3 -> gemv w2 + combine) pays a kernel boundary and a full prologue between the halves,
+// and its second half is a chain of dependent memory round trips (stage, stream, publish, arrive, combine) on small
+// workgroups.  Here one resident grid of 16-wave workgroups (one per CU) runs both halves:
 //   phase A  flat list of (slot, 64-row unit) pairs of the w1/w3 GLU; a finished unit publishes its rows of h_k
-//            (write-through stores) and arrives on the slot's counter;
-//   phase B  flat list of (slot, 256-row unit) pairs of W2 (shared expert = one more slot).  The unit's weight chunk is
-//            REQUESTED FIRST, then the workgroup waits for its slot's counter (a local hand-off among the ~32
-//            workgroups of the slot, not a grid barrier), stages h_k (sc1 loads -> Q8_K in LDS) and multiplies;
-//   combine  as in the two-launch form: slot outputs go out write-through, one arrival per 256-row group, the last
-//            arriver adds x += w_k o_k in k order, then the shared expert.
+//            (write-through stores) and arrives on the slot's counter (no-return atomics);
+//   phase B  every workgroup owns a slice of the ROWS of x for ALL slots: its W2 rows of the K experts and of the
+//            shared expert are REQUESTED FIRST (they depend on the routing only), then it waits until all slots have
+//            arrived, stages the K+1 hidden vectors (sc1 loads -> Q8_K in LDS), multiplies, and adds
+//            x += w_k o_k in k order, then the shared expert, for its own rows: no cross-workgroup combine at all.
+// The slot counters are re-armed by the router launch of the same block (its gate workgroup; stream order makes that
+// safe), so the hot path has no atomic with a return value.
 // Per-row arithmetic (lanes per row, column-step order, reduction trees, Q8_K staging, combine order) is the same code
 // with the same parameters as the two-launch form: results are BIT-identical to it (tests/test_fused_moe_gpu.py).
-// Every workgroup of the grid is resident (grid <= CUs), producers never wait, spins are bounded (err flag).
+// Every workgroup of the grid is resident (grid <= CUs), producers never wait, the one spin is bounded (err flag).
 #include "dsk_internal.h"
 #include "gemv_device.h"
 
@@ -37,18 +38,14 @@ DEV KQRsrc expert_rsrc13(const MoeFfnArgs& a, int e) {
   return p.hm ? kq_rsrc<DSK_QUANT_Q3_K, true>(p) : kq_rsrc<DSK_QUANT_Q2_K, true>(p);
 }
 
+// W2: ONE descriptor over the whole expert stack (a lane adds its expert's block offset to its row offset, so the rows
+// of one wave may belong to different experts), or over the shared expert's plain matrix
 template <int QT>
-DEV KQRsrc w2_rsrc(const MoeFfnArgs& a, int slot, int e) {
+DEV KQRsrc w2_rsrc(const MoeFfnArgs& a, bool shared) {
   WPtr p;
   p.present = true;
-  if (slot < a.K) {
-    p.qs = a.w2_qs + (size_t)e * a.e2_qs;
-    p.sc = a.w2_sc + (size_t)e * a.e2_sc;
-    p.hm = a.w2_hm ? a.w2_hm + (size_t)e * a.e2_hm : nullptr;
-    p.dm = a.w2_dm + (size_t)e * a.e2_dm;
-  } else {  // the shared expert: a plain matrix
-    p.qs = a.sw2_qs; p.sc = a.sw2_sc; p.hm = a.sw2_hm; p.dm = a.sw2_dm;
-  }
+  if (!shared) { p.qs = a.w2_qs; p.sc = a.w2_sc; p.hm = a.w2_hm; p.dm = a.w2_dm; }
+  else { p.qs = a.sw2_qs; p.sc = a.sw2_sc; p.hm = a.sw2_hm; p.dm = a.sw2_dm; }
   p.qs2 = p.sc2 = p.hm2 = p.dm2 = nullptr;
   p.scale = p.scale2 = nullptr;
   return kq_rsrc<QT, false>(p);
@@ -60,14 +57,16 @@ template <int QT, int UA, int UB>
 __global__ __launch_bounds__(1024) void moe_ffn_kernel(const MoeFfnArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ float scratch[16];
-  __shared__ int flag_s;
   constexpr int NW = 16;
   constexpr bool Q2 = QT == DSK_QUANT_Q2_K;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int bid = blockIdx.x, G = gridDim.x;
   uint8_t* actA = smem;
-  uint8_t* actB = smem + a.lds_a;
+  uint8_t* actB = smem + a.lds_a;                                            // slots x lds_b item records
+  float* o_s = reinterpret_cast<float*>(smem + a.lds_a + (size_t)a.lds_b * (a.K + 1));  // [slot][rows_wg] slot outputs
   const int K = a.K, slots = K + (a.shared_n > 0 ? 1 : 0);
+  unsigned long long* tl = a.timeline ? a.timeline + (size_t)bid * 8 : nullptr;
+  if (tl && tid == 0) tl[0] = wall_clock64();
 
   // ---- prologue: the router left Q8_K(rmsnorm(x)) behind (previous launch): copy it into item records ----
   {
@@ -77,6 +76,7 @@ __global__ __launch_bounds__(1024) void moe_ffn_kernel(const MoeFfnArgs a) {
     stage_q8<Q2, NW>(S, actA, tid, scratch);
   }
   __syncthreads();
+  if (tl && tid == 0) tl[1] = wall_clock64();
 
   // ---- phase A: w1/w3 GLU units ----
   {
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(1024) void moe_ffn_kernel(const MoeFfnArgs a) {
         int rowblk[1] = {(valid ? rr : a.mi - 1) * nb + (sub >> 2)};
         float acc[1], acc2[1];
         rows_dot_kq<QT, 1, UA, true>(B, nb * 4, sub, lpr_log2, sub & 3, rowblk, actA + sub * ITEM_LDS, acc, acc2);
-        if (sub == 0 && valid)  // src/infer.cpp:859-872; write-through: the slot's consumers sit on other CUs
+        if (sub == 0 && valid)  // src/infer.cpp:859-872; write-through: the consumers sit on other CUs
           __hip_atomic_store(a.hb + (size_t)s * a.hb_stride + rr, act_fn(acc[0], a.act) * acc2[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the arrival
@@ -104,104 +104,137 @@ __global__ __launch_bounds__(1024) void moe_ffn_kernel(const MoeFfnArgs a) {
     }
   }
 
-  // ---- phase B: W2 units (routed slots in k order, then the shared expert) + k-ordered combine ----
+  if (tl && tid == 0) tl[2] = wall_clock64();
+  // ---- phase B: this workgroup's rows [r_lo, r_hi) of x, for all slots ----
   {
     const int lpr_log2 = a.lprB_log2, RPW = 64 >> lpr_log2;
     const int rloc = lane >> lpr_log2, sub = lane & ((1 << lpr_log2) - 1);
-    constexpr int R = 2;
-    const int RG = NW * RPW * R;  // rows per unit
-    for (int t = bid; t < slots * a.UB; t += G) {
-      const int s = t / a.UB, g = t - s * a.UB;
-      const bool routed = s < K;
-      const int n = routed ? a.mi : a.shared_n;
-      const int e = routed ? a.route_e[s] : 0;
-      const KQRsrc B = w2_rsrc<QT>(a, s, e);
-      const int nb = n >> 8, items = nb * 4;
-      const int its = (items + (1 << lpr_log2) - 1) >> lpr_log2;
-      const int base = g * RG;
-      const int row0 = base + wave * (RPW * R);
-      int row[R], rowblk[R];
-      bool valid[R];
+    const int nrows_max = a.rows_wg;
+    const int r_lo = bid * nrows_max;
+    const int nrows = max(0, min(a.dim, r_lo + nrows_max) - r_lo);
+    // jobs: a wave handles two RPW-row steps per job (two independent rows per lane).  Routed steps walk the virtual rows
+    // (slot, row) slot-major; the shared expert's steps follow (their own descriptor: a job never mixes the two kinds).
+    const int WR = (nrows * K + RPW - 1) / RPW, JR = (WR + 1) >> 1;
+    const int WS = slots > K ? (nrows + RPW - 1) / RPW : 0, JS = (WS + 1) >> 1;
+    const int nbR = a.mi >> 8, nbS = a.shared_n >> 8;
+    const KQRsrc BR = w2_rsrc<QT>(a, false);
+    const KQRsrc BS = w2_rsrc<QT>(a, slots > K);
+    struct Job { bool shared; int n_items, its; bool valid[2]; int slot[2], rr[2]; int rowblk[2][1]; };
+    auto make_job = [&](int j) {
+      Job J;
+      J.shared = j >= JR;
+      const int nb = J.shared ? nbS : nbR;
+      J.n_items = nb * 4;
+      J.its = (J.n_items + (1 << lpr_log2) - 1) >> lpr_log2;
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int rr = row0 + r * RPW + rloc;
-        valid[r] = rr < a.dim;
-        row[r] = valid[r] ? rr : a.dim - 1;
-        rowblk[r] = row[r] * nb + (sub >> 2);
+      for (int r = 0; r < 2; ++r) {
+        const int step = (J.shared ? j - JR : j) * 2 + r;
+        const int v = step * RPW + rloc;
+        if (J.shared) {
+          J.valid[r] = v < nrows;
+          J.slot[r] = K;
+          J.rr[r] = J.valid[r] ? v : 0;
+          J.rowblk[r][0] = (r_lo + J.rr[r]) * nb + (sub >> 2);
+        } else {
+          J.valid[r] = v < nrows * K;
+          const int vv = J.valid[r] ? v : 0;
+          J.slot[r] = vv / (nrows > 0 ? nrows : 1);
+          J.rr[r] = vv - J.slot[r] * nrows;
+          const int e = a.route_e[J.slot[r]];
+          J.rowblk[r][0] = (e * a.dim + r_lo + J.rr[r]) * nb + (sub >> 2);  // expert e's rows inside the stack
+        }
       }
-      const bool has_rows = row0 < a.dim;
-      // the unit's first weight chunk is requested BEFORE the hand-off: it streams while the slot's producers finish
-      ChunkKQ<QT, R, UB, false> c;
-      if (has_rows) load_chunk_kq<QT, R, UB, false>(c, B, its, items, sub, lpr_log2, sub & 3, rowblk, 0);
-      if (routed) {  // wait until every phase-A unit of slot s has published its rows of h_s
-        if (tid == 0) {
-          unsigned spins = 0;
-          while (__hip_atomic_load(a.slot_ctr + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)a.UA) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 20)) { *a.err = 1u; break; }
+      return J;
+    };
+    const int n_jobs = nrows > 0 ? JR + JS : 0;
+    // the first job's weights are requested BEFORE the hand-off: they stream while the slots' producers finish
+    ChunkKQ<QT, 1, UB, false> c0, c1;
+    Job J = make_job(wave < n_jobs ? wave : 0);
+    if (wave < n_jobs) {
+      load_chunk_kq<QT, 1, UB, false>(c0, J.shared ? BS : BR, J.its, J.n_items, sub, lpr_log2, sub & 3, J.rowblk[0], 0);
+      load_chunk_kq<QT, 1, UB, false>(c1, J.shared ? BS : BR, J.its, J.n_items, sub, lpr_log2, sub & 3, J.rowblk[1], 0);
+    }
+    float xv = 0.f;
+    if (tid < nrows) xv = a.x[r_lo + tid];
+    // wait until every phase-A unit of every slot has published its rows (lane k of wave 0 watches slot k)
+    if (wave == 0) {
+      unsigned spins = 0;
+      for (;;) {
+        const bool ok = lane >= K || __hip_atomic_load(a.slot_ctr + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)a.UA;
+        if (__all(ok)) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 20)) { if (lane == 0) *a.err = 1u; break; }
+      }
+    }
+    __syncthreads();
+    if (tl && tid == 0) tl[3] = wall_clock64();
+    // stage the hidden vectors: 16-byte sc1 loads (written by other CUs during THIS launch: served by L2 / memory, never
+    // by this CU's L1), all of a wave's blocks requested before the first is quantised (one memory round trip, not one
+    // per block); Q8_K per 256-block (quantize_row_q8_K_ref)
+    {
+      const int nblk = K * nbR + nbS;
+      const rsrc_t hr = make_rsrc(a.hb);
+      constexpr int SB = 5;
+      for (int b0 = wave; b0 < nblk; b0 += NW * SB) {
+        u32x4 hv[SB];
+#pragma unroll
+        for (int k = 0; k < SB; ++k) {
+          const int b = b0 + k * NW;
+          if (b < nblk) {
+            const int s = b < K * nbR ? b / nbR : K, bb = b < K * nbR ? b - s * nbR : b - K * nbR;
+            hv[k] = __builtin_amdgcn_raw_buffer_load_b128(hr, (s * a.hb_stride + bb * 256 + lane * 4) * 4, 0, 16 /* sc1 */);
           }
-          // the slot's last consumer to pass re-arms both counters (every consumer has seen the full count by then)
-          const unsigned old = __hip_atomic_fetch_add(a.slot_pass + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (old == (unsigned)a.UB - 1) {
-            __hip_atomic_store(a.slot_ctr + s, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(a.slot_pass + s, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int k = 0; k < SB; ++k) {
+          const int b = b0 + k * NW;
+          if (b < nblk) {
+            const int s = b < K * nbR ? b / nbR : K, bb = b < K * nbR ? b - s * nbR : b - K * nbR;
+            const u32 w0 = hv[k].x, w1 = hv[k].y, w2 = hv[k].z, w3 = hv[k].w;
+            const float v[4] = {u2f(w0), u2f(w1), u2f(w2), u2f(w3)};
+            q8k_block_lds<Q2>(v, lane, actB + (size_t)s * a.lds_b + (size_t)bb * 4 * ITEM_LDS);
           }
-        }
-      }
-      __syncthreads();  // (also: every wave is done with actB of the previous unit)
-      // stage h_s: sc1 loads (written by other CUs during THIS launch), Q8_K per 256-block (quantize_row_q8_K_ref)
-      const float* hsrc = a.hb + (size_t)s * a.hb_stride;
-      for (int b = wave; b < nb; b += NW) {
-        float v[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = __hip_atomic_load(hsrc + b * 256 + lane * 4 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        q8k_block_lds<Q2>(v, lane, actB + (size_t)b * 4 * ITEM_LDS);
-      }
-      __syncthreads();
-      if (a.tap_qs && g == 0)  // parity tap: what this slot staged
-        dump_staged_q8<Q2>(actB, n, a.tap_qs + (size_t)s * a.tap_stride, a.tap_d + (size_t)s * (a.tap_stride >> 8), tid, 1024);
-      float acc[R], acc2[R];
-      if (has_rows) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = acc2[r] = 0.f;
-        const uint8_t* lds_lane = actB + sub * ITEM_LDS;
-        for (int it0 = 0; it0 < its; it0 += UB) {
-          if (it0 > 0) load_chunk_kq<QT, R, UB, false>(c, B, its, items, sub, lpr_log2, sub & 3, rowblk, it0);
-          compute_chunk_kq<QT, R, UB, false>(c, its, items, sub, lpr_log2, sub & 3, it0, lds_lane, acc, acc2);
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = lanes_sum(acc[r], lpr_log2);
-        if (sub == 0) {
-#pragma unroll
-          for (int r = 0; r < R; ++r)
-            if (valid[r]) __hip_atomic_store(a.eout + (size_t)s * a.dim + row[r], acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-      // ---- combine: the last slot to finish this row group adds x += w_k * o_k (k order), then the shared expert ----
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) {
-        const unsigned old = __hip_atomic_fetch_add(a.comb_ctr + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        flag_s = old == (unsigned)slots - 1;
-        if (flag_s) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          __hip_atomic_store(a.comb_ctr + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
-        }
-      }
-      __syncthreads();
-      if (flag_s) {
-        const int hi = min(a.dim, base + RG);
-        for (int rr = base + tid; rr < hi; rr += 1024) {
-          float xv = a.x[rr];
-          for (int k = 0; k < K; ++k) {  // src/infer.cpp:874-877
-            const float v = __hip_atomic_load(a.eout + (size_t)k * a.dim + rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            xv = fmaf(v, a.route_w[k], xv);
-          }
-          if (slots > K) xv += __hip_atomic_load(a.eout + (size_t)K * a.dim + rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // :900-903
-          a.x[rr] = xv;
         }
       }
     }
+    __syncthreads();
+    if (tl && tid == 0) tl[4] = wall_clock64();
+    if (a.tap_qs && bid == 0)  // parity tap: what the slots staged
+      for (int s = 0; s < slots; ++s)
+        dump_staged_q8<Q2>(actB + (size_t)s * a.lds_b, s < K ? a.mi : a.shared_n, a.tap_qs + (size_t)s * a.tap_stride,
+                           a.tap_d + (size_t)s * (a.tap_stride >> 8), tid, 1024);
+    for (int j = wave; j < n_jobs; j += NW) {
+      if (j != wave) {
+        J = make_job(j);
+        load_chunk_kq<QT, 1, UB, false>(c0, J.shared ? BS : BR, J.its, J.n_items, sub, lpr_log2, sub & 3, J.rowblk[0], 0);
+        load_chunk_kq<QT, 1, UB, false>(c1, J.shared ? BS : BR, J.its, J.n_items, sub, lpr_log2, sub & 3, J.rowblk[1], 0);
+      }
+      const KQRsrc& B = J.shared ? BS : BR;
+      float acc0[1] = {0.f}, acc1[1] = {0.f}, dummy[1] = {0.f};
+      const uint8_t* l0 = actB + (size_t)J.slot[0] * a.lds_b + sub * ITEM_LDS;
+      const uint8_t* l1 = actB + (size_t)J.slot[1] * a.lds_b + sub * ITEM_LDS;
+      for (int it0 = 0; it0 < J.its; it0 += UB) {
+        if (it0 > 0) {
+          load_chunk_kq<QT, 1, UB, false>(c0, B, J.its, J.n_items, sub, lpr_log2, sub & 3, J.rowblk[0], it0);
+          load_chunk_kq<QT, 1, UB, false>(c1, B, J.its, J.n_items, sub, lpr_log2, sub & 3, J.rowblk[1], it0);
+        }
+        compute_chunk_kq<QT, 1, UB, false>(c0, J.its, J.n_items, sub, lpr_log2, sub & 3, it0, l0, acc0, dummy);
+        compute_chunk_kq<QT, 1, UB, false>(c1, J.its, J.n_items, sub, lpr_log2, sub & 3, it0, l1, acc1, dummy);
+      }
+      const float o0 = lanes_sum(acc0[0], lpr_log2), o1 = lanes_sum(acc1[0], lpr_log2);
+      if (sub == 0) {
+        if (J.valid[0]) { o_s[J.slot[0] * nrows_max + J.rr[0]] = o0; a.eout[(size_t)J.slot[0] * a.dim + r_lo + J.rr[0]] = o0; }
+        if (J.valid[1]) { o_s[J.slot[1] * nrows_max + J.rr[1]] = o1; a.eout[(size_t)J.slot[1] * a.dim + r_lo + J.rr[1]] = o1; }
+      }
+    }
+    __syncthreads();
+    if (tl && tid == 0) tl[5] = wall_clock64();
+    if (tid < nrows) {  // x += w_k * o_k in k order (src/infer.cpp:874-877), then the shared expert (:900-903)
+      for (int k = 0; k < K; ++k) xv = fmaf(o_s[k * nrows_max + tid], a.route_w[k], xv);
+      if (slots > K) xv += o_s[K * nrows_max + tid];
+      a.x[r_lo + tid] = xv;
+    }
+    if (tl && tid == 0) tl[6] = wall_clock64();
   }
 }
 
@@ -215,24 +248,27 @@ int moe_ffn_plan(MoeFfnArgs& a, int n_cus) {
   if (lprA < 4 || lprB < 4 || itemsA % lprA || itemsB % lprB || (a.shared_n > 0 && itemsS % lprB))
     DSK_FAIL(DSK_ERR_UNSUPPORTED, "moe_ffn: lanes per row %d / %d do not divide the rows", lprA, lprB);
   const int RGA = 16 * (64 / lprA), RGB = 16 * (64 / lprB) * 2;
+  (void)RGB;
   a.UA = (a.mi + RGA - 1) / RGA;
-  a.UB = (a.dim + RGB - 1) / RGB;
-  if (a.UB > a.comb_ctr_cap) DSK_FAIL(DSK_ERR_UNSUPPORTED, "moe_ffn: %d row groups", a.UB);
+  // one descriptor spans the W2 stack: a lane's byte offset (expert, row, block) must fit its 32-bit offset field
+  if ((double)a.n_experts * a.dim * (a.mi / 256) * 64.0 >= 2147483648.0) DSK_FAIL(DSK_ERR_UNSUPPORTED, "moe_ffn: the W2 stack exceeds the 31-bit offset of a buffer load");
+  // every workgroup must be resident at once (phase B spins on the slot counters): one 16-wave workgroup per CU
+  int grid = a.K * a.UA;
+  if (grid > n_cus) grid = n_cus;
+  if (grid > a.dim) grid = a.dim;
+  a.grid = grid;
+  a.rows_wg = (a.dim + grid - 1) / grid;  // rows of x a workgroup owns in phase B
+  if (a.rows_wg > 1024) DSK_FAIL(DSK_ERR_UNSUPPORTED, "moe_ffn: %d rows per workgroup", a.rows_wg);
   a.lds_a = (int)(((size_t)(a.dim / 64) * ITEM_LDS + 15) & ~(size_t)15);
   const int nB = a.mi > a.shared_n ? a.mi : a.shared_n;
   a.lds_b = (int)(((size_t)(nB / 64) * ITEM_LDS + 15) & ~(size_t)15);
-  if (a.lds_a + a.lds_b > 150 * 1024) DSK_FAIL(DSK_ERR_UNSUPPORTED, "moe_ffn: activations do not fit LDS");
-  // every workgroup must be resident at once (the slot hand-off spins): one 16-wave workgroup per CU
-  int grid = a.K * a.UA;
-  const int unitsB = (a.K + (a.shared_n > 0 ? 1 : 0)) * a.UB;
-  if (unitsB > grid) grid = unitsB;
-  if (grid > n_cus) grid = n_cus;
-  a.grid = grid;
+  a.lds_o = (a.K + 1) * a.rows_wg * 4;
+  if ((size_t)a.lds_a + (size_t)a.lds_b * (a.K + 1) + a.lds_o > 150 * 1024) DSK_FAIL(DSK_ERR_UNSUPPORTED, "moe_ffn: activations do not fit LDS");
   return DSK_OK;
 }
 
 int launch_moe_ffn(hipStream_t st, const MoeFfnArgs& a, hipEvent_t ev_start, hipEvent_t ev_stop) {
-  const size_t lds = (size_t)a.lds_a + a.lds_b;
+  const size_t lds = (size_t)a.lds_a + (size_t)a.lds_b * (a.K + 1) + a.lds_o;
   auto go = [&](auto k) {
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (ev_start && ev_stop) hipExtLaunchKernelGGL(k, dim3(a.grid), dim3(1024), (uint32_t)lds, st, ev_start, ev_stop, 0u, a);

@@ -255,6 +255,7 @@ RDEV void router_body(const RouterArgs& a, int bid, int nblocks) {
   if (!is_last) return;
   if (a.dbg & 1) { if (tid == 0) *a.counter = 0; return; }
   if (tid == 0) __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
+  if (a.zero_ctr && tid < a.zero_n) __hip_atomic_store(a.zero_ctr + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   float v = 0.f;
   if (tid < E) v = __hip_atomic_load(a.partial + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   gate_body(tid, v, a.bias, E, a.n_active, a.norm_topk_prob, a.scaling, a.scoring, a.topk_method, a.n_group, a.topk_group,

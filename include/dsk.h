@@ -318,6 +318,11 @@ int dsk_bench_gemv(dsk_ctx* ctx, int quant, int rows, int n, int n_tasks, int ki
                    int force_lpr, int force_R, int force_U, int target_wgs, int iters,
                    double* us_per_launch, double* bytes_per_launch);
 
+/* Diagnostics: 8 wall-clock stamps (100 MHz ticks: entry, staged, phase A done, hand-off passed, hidden vectors staged,
+   rows done, exit, unused) per workgroup of the LAST fused routed-expert launch; needs DSK_MOE_TIMELINE=1 in the
+   environment when the model is created. */
+int dsk_model_get_moe_timeline(dsk_model* m, unsigned long long* out, int n_wgs);
+
 /* Router (F32 GEMV + rmsnorm prologue) + moe_gate micro-benchmark on synthetic weights; flags: 0 = the
    production kernel, 1 = skip the gate, 2 = skip the weight stream, 4 = skip the norm (bitwise or). */
 int dsk_bench_router(dsk_ctx* ctx, int n_routed, int dim, int ksplit, int flags, int iters, double* us_per_launch);

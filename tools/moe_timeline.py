@@ -1,0 +1,28 @@
+"""Where the fused routed-expert launch (kernels_moe.hip) spends its time: per-workgroup wall-clock stamps of the last
+MoE block of a token.   DSK_MOE_TIMELINE=1 python tools/moe_timeline.py [--layers 8]"""
+import argparse, ctypes as C, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "deepseek.cpp_amd"))
+os.environ.setdefault("DSK_MOE_TIMELINE", "1")
+import dsk
+from tools import synth
+
+ap = argparse.ArgumentParser(); ap.add_argument("--layers", type=int, default=8); a = ap.parse_args()
+c = synth.preset("v3", "q2_k", False, n_layers=a.layers, max_seq_len=64)
+ctx = dsk.Ctx(0); M = dsk.Model(ctx, c, None, synth_seed=0)
+for pos in range(6):
+    M.forward(17 + pos, pos)
+n = 256
+buf = np.zeros((n, 8), np.uint64)
+f = dsk.lib().dsk_model_get_moe_timeline; f.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+dsk.check(f(M.h, buf.ctypes.data, n))
+t = buf.astype(np.float64) / 100.0  # us
+t0 = t[:, 0].min()
+names = ["entry", "staged x", "phase A done", "hand-off passed", "hidden staged", "rows done", "exit"]
+print("stamp                 min      median   max   (us after the first workgroup's entry)")
+for i, nm in enumerate(names):
+    v = t[:, i] - t0
+    print(f"{nm:18s} {v.min():8.2f} {np.median(v):8.2f} {v.max():8.2f}")
+d = np.diff(t[:, :7], axis=1)
+print("segment medians (us):", {names[i + 1]: round(float(np.median(d[:, i])), 2) for i in range(6)})
