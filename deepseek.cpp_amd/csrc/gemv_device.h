@@ -658,7 +658,11 @@ DEV void compute_chunk_f(const ChunkF<QT, R, U, GLU>& c, int n, int lpr_log2, in
 }
 
 #ifndef KQ_PIPELINE
-#define KQ_PIPELINE 1  // -DKQ_PIPELINE=0: the single-buffer loop (A/B builds)
+// 0: one chunk: load U steps, multiply them, repeat (the default).  1: two half-chunks alternate -- same registers, half
+// the loads in flight per burst: measured SLOWER everywhere (experts phase 17.0 -> 20.0 us, wo 12.0 -> 13.9): at 16
+// waves x 128 VGPRs a lane cannot hold two full chunks, and 64 B per lane in flight is below what one CU needs to keep
+// its ~24 GB/s share of HBM busy.  2: two full chunks (spills at 16 waves; for 8-wave / 256-VGPR experiments).
+#define KQ_PIPELINE 0
 #endif
 // dot products of R rows (x 64/LPR rows per wave) with a staged activation vector.
 // `pre`: the first chunk was already requested by the caller (prefetch across the prologue).
@@ -675,7 +679,7 @@ DEV void rows_dot_kq(const KQRsrc& B, int items, int sub, int lpr_log2, int q, c
     // VALU work (~half of the time budget of a streamed item) overlaps its own memory traffic instead of alternating
     // with it (the waves of a workgroup start in lock step: without this every wave loads, then every wave computes).
     // Column steps are consumed in order, exactly as below: same sums, same bits.
-    constexpr int H = U / 2;
+    constexpr int H = KQ_PIPELINE == 2 ? U : U / 2;  // 2: two FULL chunks alternate (twice the loads in flight)
     ChunkKQ<QT, R, H, GLU> ca, cb;
     load_chunk_kq<QT, R, H, GLU>(ca, B, its, items, sub, lpr_log2, q, rowblk, 0);
     if (H < its) load_chunk_kq<QT, R, H, GLU>(cb, B, its, items, sub, lpr_log2, q, rowblk, H);
