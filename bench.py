@@ -35,6 +35,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "deepseek.cpp_amd"))
 
+PMC_FILE = "r02_pmc.json"
+
+
+def csrc_sha() -> str:
+    """sha256 (16 hex) over the kernel / engine sources: ties a committed profile to the code it was taken on"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "deepseek.cpp_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 achievable
 README_TOK_S = 4.02     # reference README.md:26 (V3 Q2_K, MHA path, EPYC 7R13 16 threads) -- BASELINE.md section 1
 
@@ -48,7 +63,9 @@ def parse():
     ap.add_argument("--quant", default="q2_k")
     ap.add_argument("--attn", default="mha", choices=["mha", "mla"], help="reference attention path (BlockMHA is the README's)")
     ap.add_argument("--layers", type=int, default=0, help="override n_layers (0 = the model's own depth)")
-    ap.add_argument("--ctx", type=int, default=1024, help="KV-cache allocation (max_seq_len)")
+    ap.add_argument("--ctx", type=int, default=4200, help="KV-cache allocation (max_seq_len); the kv_len sweep needs > 4096")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (MLA path, kv_len sweep)")
+    ap.add_argument("--dry-shard", default="", help="R/W: single-process dry run of expert shard R of W (no communicator)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -166,6 +183,9 @@ def main():
         uid = [ctx.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(uid[0], rank, world)
+    elif a.dry_shard:  # the sharded code path of rank R of W on one GPU (the exchange is skipped: timing only)
+        r_, w_ = (int(v) for v in a.dry_shard.split("/"))
+        ctx.comm_init_dry(r_, w_)
 
     c = synth.preset(a.model, a.quant, a.attn == "mla")
     c.model_name = a.model
@@ -232,18 +252,47 @@ def main():
                                  bytes_per_launch=round(nb), gbps=round(nb / max(us, 1e-9) / 1e3, 1))
         dom = max(kernels, key=lambda n: kernels[n]["ms_per_step"])
         k = kernels[dom]
-        traffic = None
-        try:  # HBM bytes per launch from the committed PMC pass (tools/prof_summary.py, profiles/)
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
-            traffic = pm.get("traffic_bytes_per_launch", {}).get(dom)
+        # HBM traffic is NOT measured in this run: PMC counters need their own rocprofv3 passes.  The figure of the committed
+        # pass is reported only if it was taken on these very kernel sources (sha of deepseek.cpp_amd/csrc), and labelled.
+        traffic, traffic_source = None, "not measured in this run (no committed PMC pass for these kernel sources)"
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
+            if pm.get("csrc_sha") == csrc_sha():
+                traffic = pm.get("traffic_bytes_per_launch", {}).get(dom)
+                traffic_source = f"profiles/{PMC_FILE} (separate rocprofv3 --pmc passes on the same kernel sources, csrc sha {pm.get('csrc_sha')})"
         except Exception:
-            traffic = None
+            pass
         roof = dict(bound="hbm", kernel=dom, achieved=k["gbps"], peak=HBM_PEAK_GBPS, unit="GB/s",
-                    frac=round(k["gbps"] / HBM_PEAK_GBPS, 4), traffic=traffic,
+                    frac=round(k["gbps"] / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_source=traffic_source,
                     bytes_per_launch=k["bytes_per_launch"], avg_launch_us=k["us_per_launch"],
                     launches_per_token=k["launches_per_step"],
                     token_gbps=round(algo_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                     token_frac=round(algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4))
+    def sweep(model, tag):
+        """ms per decode step at kv_len 128 / 1024 / 4096: 6 steps each after 2 of warm-up; the cache rows
+        below the position hold whatever earlier steps left (zeros mostly): attention streams them all the same"""
+        out = {}
+        for kv in (128, 1024, 4096):
+            if kv + 10 > c.max_seq_len:
+                continue
+            p0 = kv - 1
+            for i in range(2):
+                model.forward_nocopy(int(tokens[i]), p0 + i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(6):
+                model.forward_nocopy(int(tokens[2 + i]), p0 + 2 + i)
+            torch.cuda.synchronize()
+            out[str(kv)] = round((time.perf_counter() - t0) / 6 * 1e3, 4)
+        return out
+
+    extras = {}
+    full_v3 = a.model == "v3" and a.quant == "q2_k"
+    if rank == 0 and world == 1 and not a.no_extras and not a.dry_shard:
+        try:
+            extras["kv_sweep"] = {a.attn: sweep(M, a.attn)}
+        except Exception as e:
+            extras["kv_sweep"] = {"error": repr(e)[:160]}
     measured_bw = None
     if rank == 0:
         try:
@@ -251,6 +300,34 @@ def main():
             measured_bw = round(ctx.measure_read_bw(4 << 30, 5), 1)
         except Exception:
             measured_bw = None
+    if rank == 0 and world == 1 and not a.no_extras and not a.dry_shard and a.attn == "mha" and full_v3:
+        # the north star's MLA path on the same shapes (BlockMLA, absorbed weights): its own model (226 GB: after the MHA one is freed)
+        try:
+            c2 = synth.preset(a.model, a.quant, True)
+            if a.layers > 0:
+                c2.n_layers = a.layers
+                c2.first_k_dense_replace = min(c2.first_k_dense_replace, a.layers)
+            c2.max_seq_len = c.max_seq_len
+            M2 = dsk.Model(ctx, c2, None, synth_seed=0)
+            p2 = 0
+            for _ in range(a.warmup):
+                M2.forward_nocopy(int(tokens[p2]), p2)
+                p2 += 1
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                M2.forward_nocopy(int(tokens[p2]), p2)
+                p2 += 1
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t0
+            ab2 = M2.active_bytes(a.warmup + a.steps // 2)
+            extras["mla"] = {"tok_s": round(a.steps / dt2, 3), "ms_per_step": round(dt2 / a.steps * 1e3, 4),
+                             "algo_bytes_per_token": round(ab2),
+                             "token_frac": round(ab2 / (dt2 / a.steps) / 1e9 / HBM_PEAK_GBPS, 4)}
+            extras["kv_sweep"]["mla"] = sweep(M2, "mla")
+            M2.close()
+        except Exception as e:
+            extras["mla"] = {"error": repr(e)[:160]}
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
@@ -260,7 +337,8 @@ def main():
     if rank == 0:
         full = a.model == "v3" and a.layers in (0, 61) and a.quant == "q2_k"
         out = {
-            "metric": "decode tok/s (batch=1) + achieved HBM GB/s vs roofline, DeepSeek-V3 Q2_K",
+            "metric": ("decode tok/s (batch=1) + achieved HBM GB/s vs roofline, DeepSeek-V3 Q2_K" if full else
+                       f"decode tok/s (batch=1) + achieved HBM GB/s vs roofline, {a.model} {a.quant} ({c.n_layers} blocks)"),
             "value": round(tok_s, 3), "unit": "tok/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": round(tok_s / README_TOK_S, 2) if (full and a.attn == "mha") else None,
@@ -269,11 +347,14 @@ def main():
             "config": {"workload": f"DeepSeek-{a.model} {a.quant} batch=1 decode, {c.n_layers} blocks, "
                                    f"{c.n_routed_experts} routed experts top-{c.n_active_routed}, {a.attn.upper()} path, "
                                    f"pos {a.warmup}..{a.warmup + a.steps - 1}, logits D2H included",
-                       "parallelism": "1 GPU" if world == 1 else f"experts sharded over {world} GPUs (RCCL all-reduce per MoE layer)",
+                       "parallelism": (f"dry run of expert shard {a.dry_shard} on one GPU (no exchange)" if a.dry_shard else
+                                       "1 GPU" if world == 1 else f"experts sharded over {world} GPUs (RCCL all-reduce per MoE layer; EXPERIMENTAL: never run on > 1 GPU)"),
                        "hip_graph": not a.no_graph, "model_build_s": round(t_build, 1),
                        "device_gb": round(M_device_gb, 1), "algo_bytes_per_token": round(algo_bytes)},
             "roofline": roof, "kernels": kernels, "measured_read_gbps": measured_bw, "cpu_baseline": cpu,
+            "csrc_sha": csrc_sha(),
         }
+        out.update(extras)
         print(json.dumps(out), flush=True)
     barrier()
     if world > 1:

@@ -365,9 +365,27 @@ def bind_all(T: Dict[str, Tens], bind):
 _DT = {np.dtype(np.float32): "F32", np.dtype(np.float16): "F16", np.dtype(np.uint8): "U8"}
 
 
-def write_dseek(dirname: str, c: Cfg, T: Dict[str, Tens], shards: int = 1):
+def synthetic_vocab(n: int):
+    """A vocabulary the reference's Tokenizer (src/tokenizer.cpp) accepts: <s>, </s>, the 256 byte-fallback tokens,
+    printable single characters, then two-letter pieces; `n` entries, NUL-separated like convert.py:584 writes them."""
+    v = ["<s>", "</s>"] + ["<0x%02X>" % i for i in range(256)]
+    v += [chr(i) for i in range(32, 127)]
+    letters = "etaoinshrdlucmfwypvbgkqjxz "
+    for a in letters:
+        for b in letters:
+            if len(v) < n:
+                v.append(a + b)
+    i = 0
+    while len(v) < n:
+        v.append("tok%d" % i)
+        i += 1
+    return v[:n]
+
+
+def write_dseek(dirname: str, c: Cfg, T: Dict[str, Tens], shards: int = 1, tokenizer: bool = False):
     """`shards` files `shard_00k.dseek`: u64 header len | JSON | data (src/codec.cpp:304-331); the metadata goes
-    into the first one, tensors are dealt to the files in order (convert.py writes 8 layers per shard)."""
+    into the first one, tensors are dealt to the files in order (convert.py writes 8 layers per shard).
+    tokenizer=True adds `tokenizer.tokens` (U8, NUL-separated: convert.py:584), which the reference's `main` needs."""
     os.makedirs(dirname, exist_ok=True)
     names = list(T.keys())
     per = -(-len(names) // max(1, shards))
@@ -382,6 +400,9 @@ def write_dseek(dirname: str, c: Cfg, T: Dict[str, Tens], shards: int = 1):
             blobs.append(b)
             off += len(b)
 
+        if k == 0 and tokenizer:
+            tok = "\0".join(synthetic_vocab(c.vocab_size)).encode("latin-1") + b"\0"
+            add("tokenizer.tokens", np.frombuffer(tok, np.uint8), "U8", (len(tok),))
         for name in names[k * per:(k + 1) * per]:
             t = T[name]
             if t.quant == QUANT_IDS["f8e5m2"]:
