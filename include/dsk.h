@@ -141,8 +141,12 @@ int dsk_abi_version(void);
 /* ---- expert-sharded multi-GPU (one process per GPU, RCCL over xGMI) --------
  * No reference counterpart: routed experts e with
  * e / ceil(E/world) == rank live on this rank; everything else is replicated.
- * Per MoE layer the per-slot expert outputs are all-gathered and summed in k order,
- * so results are bit-identical to the 1-GPU run.  uid = 128-byte ncclUniqueId made
+ * Per MoE layer every rank computes the slots whose expert it owns and writes ZEROS for the others; one sum
+ * all-reduce over the K x dim slot buffer (each slot is non-zero on exactly one rank, so the sum is exact and
+ * order-independent) hands every rank all slot outputs, which are then added in k order: bit-identical to the
+ * 1-GPU run (an all-gather of per-rank partial sums would move the same K x dim bytes at world = K and give up
+ * the bit identity).  EXPERIMENTAL: the exchange has never run on more than one GPU (the
+ * single-GPU dry run below validates everything except the RCCL call).  uid = 128-byte ncclUniqueId made
  * by rank 0 with dsk_comm_unique_id() and broadcast by the launcher. */
 int dsk_comm_unique_id(void* uid128);
 int dsk_comm_init(dsk_ctx* ctx, const void* uid128, int rank, int world);

@@ -90,22 +90,19 @@ def assert_model_parity(st, kquant, what=""):
     Float-weight models (fp32 / fp16 / f8e5m2): every token of the free-running sequence and every
     independent trial within 1e-3 of the logit scale, routing identical everywhere.
 
-    W2A8 / W3A8 models are discontinuous in their activations: a 1e-7 difference in an RMSNorm
-    output flips an int8 rounding in Q8_K, which on these dim-512 test models moves a GEMV output
-    by ~1e-3 and can flip a near-tied top-k (SURVEY 7 "hard parts", Appendix C) -- and the KV cache
-    then carries the difference to all later positions.  The reference disagrees with *itself*
-    at that level under any re-association, so the criterion is statistical: at least half of the
-    independent pos-0 trials agree to 1e-4 (i.e. no flip happened: the arithmetic is the same),
-    nothing is grossly wrong anywhere (< 0.3 of the logit scale; a layout or indexing bug gives
-    O(1)), and routing is identical in >= 85 % of the (token, layer) decisions.
+    W2A8 / W3A8 models are discontinuous in their activations: a last-bit difference in an RMSNorm output can flip an
+    int8 rounding that sits on a tie (quantize_row_q8_K_ref, src/quant.cpp:616-653), and a free-running model carries
+    the flip forward (KV cache included).  The EXACT statement for these models is the teacher-forced, flip-audited
+    test (tests/teacher.py, tests/test_teacher_forced_gpu.py): every staging point's codes equal the reference's except
+    proven ties, every stage within 2e-5 on identical codes, expert indices identical.  Here only a smoke remains:
+    at least half of the independent pos-0 trials see no tie at all and then agree to float precision (2e-5), and
+    nothing is grossly wrong anywhere (< 0.3 of the logit scale: a layout or indexing bug gives O(1)).
     """
     seq, e0 = st["seq_errs"], st["errs0"]
     if kquant:
-        frac = float(np.mean(np.array(e0) < 1e-4))
-        assert frac >= 0.5, (what, "independent trials within 1e-4", frac, e0)
+        frac = float(np.mean(np.array(e0) < 2e-5))
+        assert frac >= 0.5, (what, "independent trials without a rounding tie, within 2e-5", frac, e0)
         assert max(seq + e0) < 0.3, (what, seq, e0)
-        assert st["routes0"][0] >= 0.85 * st["routes0"][1], (what, st["routes0"])
-        assert st["routes"][0] >= 0.75 * st["routes"][1], (what, st["routes"])
     else:
         assert max(seq + e0) < 1e-3, (what, seq, e0)
         assert st["routes"][0] == st["routes"][1] and st["routes0"][0] == st["routes0"][1], (what, st["routes"], st["routes0"])
