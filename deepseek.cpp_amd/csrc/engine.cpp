@@ -423,6 +423,37 @@ int bind_src(dsk_model* m, int role, int layer, int quant, const int32_t shape[4
   return upload_tensor(m->ctx, *t, src);
 }
 
+// the plane layout persisted offline (tools/repack.py).  No staging buffer, no repack kernel: every plane
+// of the rank's experts is one contiguous byte range of the file going straight into its device plane.
+int bind_planes(dsk_model* m, int role, int layer, int quant, const HostSrc planes[4], const size_t bytes[4]) {
+  if (!m) DSK_FAIL(DSK_ERR_INVALID, "bind: null argument");
+  if (m->finalized) DSK_FAIL(DSK_ERR_STATE, "bind after finalize");
+  if (!is_kq(quant)) DSK_FAIL(DSK_ERR_INVALID, "bind_planes: k-quants only");
+  HIP_TRY(hipSetDevice(m->ctx->device));
+  DTensor* t;
+  DSK_TRY(tensor_slot(m, role, layer, &t));
+  const RoleShape rs = role_shape(m, role, layer);
+  if (!rs.ok) DSK_FAIL(DSK_ERR_INVALID, "bind: role %d is not part of this configuration (layer %d)", role, layer);
+  if (quant != rs.quant) DSK_FAIL(DSK_ERR_INVALID, "bind: role %d layer %d has quant %d, expected %d", role, layer, quant, rs.quant);
+  if (rs.n % 256) DSK_FAIL(DSK_ERR_INVALID, "bind: k-quant row length %d is not a multiple of 256", rs.n);
+  if (t->bound()) DSK_FAIL(DSK_ERR_STATE, "bind: role %d layer %d bound twice", role, layer);
+  const dsk_config& c = m->c;
+  int base, local;
+  shard_range(m, role, rs.e, &base, &local);
+  const size_t mats = rs.e > 0 ? rs.e : 1, lm = rs.e > 0 ? (size_t)local : 1;
+  const size_t nblk = (size_t)rs.rows * rs.n / 256;
+  const size_t per[4] = {nblk * 64, nblk * (quant == DSK_QUANT_Q2_K ? 16 : 12), quant == DSK_QUANT_Q3_K ? nblk * 32 : 0,
+                         nblk * (quant == DSK_QUANT_Q2_K ? 4 : 2)};
+  for (int i = 0; i < 4; ++i)
+    if (bytes[i] != per[i] * mats) DSK_FAIL(DSK_ERR_INVALID, "bind: plane %d of role %d layer %d has %zu bytes, expected %zu", i, role, layer, bytes[i], per[i] * mats);
+  DSK_TRY(alloc_tensor(c.block_size[0], c.block_size[1], *t, quant, rs.e, rs.rows, rs.n, local, base));
+  m->weight_bytes += (double)t->bytes;
+  uint8_t* dst[4] = {t->qs, t->sc, t->hm, t->dm};
+  for (int i = 0; i < 4 && lm; ++i)
+    if (per[i]) DSK_TRY(stage_copy(m->ctx, planes[i], (uint64_t)base * per[i], dst[i], lm * per[i]));
+  return DSK_OK;
+}
+
 extern "C" int dsk_model_synthesize(dsk_model* m, uint64_t seed) {
   if (!m) DSK_FAIL(DSK_ERR_INVALID, "synthesize: null model");
   if (m->finalized) DSK_FAIL(DSK_ERR_STATE, "synthesize after finalize");

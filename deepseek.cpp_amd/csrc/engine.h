@@ -42,6 +42,9 @@ int stage_copy(dsk_ctx* ctx, const HostSrc& src, uint64_t src_off, void* dev_dst
 int upload_tensor(dsk_ctx* ctx, DTensor& t, const HostSrc& src);
 struct dsk_model;
 int bind_src(dsk_model* m, int role, int layer, int quant, const int32_t shape[4], const HostSrc& src, size_t bytes);
+// a K-quant tensor stored in the engine's own plane layout (tools/repack.py): planes[0..3] = qs, sc, hm
+// (Q3_K only), dm, each (experts x per-expert plane bytes) contiguous; copied into the device planes as they are
+int bind_planes(dsk_model* m, int role, int layer, int quant, const HostSrc planes[4], const size_t bytes[4]);
 
 static const int NROLES = 32;
 int cdiv_i(int a, int b);

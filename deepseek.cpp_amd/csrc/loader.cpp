@@ -334,6 +334,7 @@ struct Walk {
   dsk_model* m;
   Checkpoint& ck;
   const dsk_config& c;
+  bool planes = false;  // the checkpoint stores K-quant tensors in the engine's plane layout
   int n_bound = 0;
   uint64_t file_bytes = 0;
 
@@ -346,6 +347,8 @@ struct Walk {
     }
     const FileTensor& ft = it->second;
     const bool is_scale = role >= DSK_ROLE_SCALE;
+    if (planes && !is_scale && is_kq(role_shape(m, role, layer).quant) && role_shape(m, role, layer).ok)
+      return bind_plane_set(name, role, layer);
     const RoleShape rs = role_shape(m, is_scale ? role - DSK_ROLE_SCALE : role, layer);
     if (!rs.ok) return DSK_OK;  // present in the file, not part of this configuration: the reference never asks for it
     const int quant = is_scale ? DSK_QUANT_F32 : rs.quant;
@@ -369,6 +372,27 @@ struct Walk {
     DSK_TRY(bind_src(m, role, layer, quant, shape, src, ft.size));
     ++n_bound;
     file_bytes += ft.size;
+    return DSK_OK;
+  }
+  // plane layout (metadata gpu_layout = planes-v1, tools/repack.py): "<name>" is a 1-byte marker, the data sit in
+  // "<name>.qs" / ".sc" / ".hm" (Q3_K) / ".dm"
+  int bind_plane_set(const std::string& name, int role, int layer) {
+    const RoleShape rs = role_shape(m, role, layer);
+    static const char* SUF[4] = {".qs", ".sc", ".hm", ".dm"};
+    HostSrc src[4];
+    size_t bytes[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i) {
+      if (i == 2 && rs.quant != DSK_QUANT_Q3_K) continue;
+      auto it = ck.tensors.find(name + SUF[i]);
+      if (it == ck.tensors.end()) DSK_FAIL(DSK_ERR_INVALID, "loader: plane %s%s is missing", name.c_str(), SUF[i]);
+      if (it->second.dtype != "U8") DSK_FAIL(DSK_ERR_INVALID, "loader: plane %s%s is not U8", name.c_str(), SUF[i]);
+      src[i].fd = ck.fds[it->second.file];
+      src[i].off = it->second.off;
+      bytes[i] = it->second.size;
+      file_bytes += it->second.size;
+    }
+    DSK_TRY(bind_planes(m, role, layer, rs.quant, src, bytes));
+    ++n_bound;
     return DSK_OK;
   }
   int weight(const std::string& base, int role, int layer, bool required) {
@@ -421,6 +445,16 @@ extern "C" int dsk_model_load_dseek(dsk_ctx* ctx, const char* dir, int context, 
   DSK_TRY(dsk_model_create(ctx, &c, &m));
   const double staged0 = ctx->staged_bytes, fill0 = ctx->staged_fill_s;
   Walk W{m, ck, m->c};
+  {
+    auto it = ck.meta.find("gpu_layout");
+    if (it != ck.meta.end()) {
+      if (it->second != "planes-v1") {
+        dsk_model_destroy(m);
+        DSK_FAIL(DSK_ERR_UNSUPPORTED, "loader: unknown gpu_layout '%s'", it->second.c_str());
+      }
+      W.planes = true;
+    }
+  }
   int r = W.all();
   if (r == DSK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) r = DSK_ERR_HIP;
   if (r == DSK_OK) r = dsk_model_finalize(m);

@@ -524,3 +524,41 @@ def test_dseek_loader_vs_the_reference_reading_the_same_files(ctx, ref, tmp_path
         assert np.array_equal(M.routing()[0], S.routing()[0]), pos
     M.close()
     S.close()
+
+
+@pytest.mark.parametrize("quant,mla", [("q2_k", True), ("q3_k", False)])
+def test_repacked_plane_layout_checkpoint_loads_bit_identically(ctx, quant, mla):
+    """tools/repack.py persists the engine's plane layout; dsk_model_load_dseek copies the planes straight
+    into HBM (no repack kernels).  Same device bytes => bit-identical logits, routing and slot outputs; an expert-sharded
+    dry run reads only its own experts' ranges of every plane."""
+    import dsk
+    from tools import repack
+    c = synth.preset("tiny_v3", quant, mla)
+    T = synth.synth_model(c, seed=29)
+    d, d2 = tempfile.mkdtemp(prefix="dsk_ref_"), tempfile.mkdtemp(prefix="dsk_planes_")
+    try:
+        synth.write_dseek(d, c, T, shards=2, tokenizer=True)
+        repack.repack(d, d2)
+        A, B = dsk.Model.from_dseek(ctx, d), dsk.Model.from_dseek(ctx, d2)
+        assert B.load_stats.n_tensors == A.load_stats.n_tensors
+        for pos, tok in enumerate([4, 90, 1000, 17]):
+            assert np.array_equal(A.forward(tok, pos), B.forward(tok, pos)), pos
+            assert np.array_equal(A.routing()[0], B.routing()[0])
+            assert np.array_equal(A.slot_outputs(), B.slot_outputs())
+        A.close()
+        B.close()
+        x = dsk.Ctx(0)
+        x.comm_init_dry(1, 2)
+        S1, S2 = dsk.Model.from_dseek(x, d), dsk.Model.from_dseek(x, d2)
+        assert S2.load_stats.staged_bytes == S1.load_stats.staged_bytes < B.load_stats.staged_bytes
+        S1.forward(5, 0)
+        S2.forward(5, 0)
+        assert np.array_equal(S1.slot_outputs(), S2.slot_outputs())
+        S1.close()
+        S2.close()
+        x.close()
+    finally:
+        for dd in (d, d2):
+            for f in os.listdir(dd):
+                os.unlink(os.path.join(dd, f))
+            os.rmdir(dd)

@@ -47,3 +47,48 @@ def test_prof_summary_on_a_synthetic_database(tmp_path):
     assert abs(p["calibration"]["bytes_per_fetch_size_unit"] - 2048) < 1e-6
     assert abs(p["traffic_bytes_per_launch"]["gemv_experts_w13"] - 90e6) < 2
     assert "kernel" in open(out + "_kernel_trace.txt").read()
+
+
+def test_repack_gpu_layout_planes_roundtrip(tmp_path):
+    """tools/repack.py: every K-quant tensor of a checkpoint becomes byte planes that hold exactly the
+    bytes of the reference blocks (a permutation), the header still parses (dsk_dseek_read_config), everything else
+    is copied verbatim."""
+    import json
+    import struct
+    import numpy as np
+    import dsk
+    from tools import repack, synth
+    for quant, bsz in (("q2_k", 84), ("q3_k", 110)):
+        c = synth.preset("tiny_v3", quant, True)
+        T = synth.synth_model(c, seed=3)
+        src, dst = str(tmp_path / f"src_{quant}"), str(tmp_path / f"dst_{quant}")
+        synth.write_dseek(src, c, T, shards=2, tokenizer=True)
+        repack.repack(src, dst)
+        cfg_a, cfg_b = dsk.read_dseek_config(src)[0], dsk.read_dseek_config(dst)[0]
+        assert bytes(cfg_a) == bytes(cfg_b)
+        assert repack.read_shard(f"{dst}/shard_000.dseek")[0]["__metadata__"]["gpu_layout"] == "planes-v1"
+        shards = []
+        for fn in ("shard_000.dseek", "shard_001.dseek"):
+            hdr, data0 = repack.read_shard(f"{dst}/{fn}")
+            shards.append((hdr, data0, np.fromfile(f"{dst}/{fn}", np.uint8)))
+        name = "model.layers.1.mlp.w1.weight"  # an expert stack
+
+        def get(n):
+            for hdr, data0, raw in shards:
+                if n in hdr:
+                    return raw[data0 + hdr[n]["data_offsets"][0]:data0 + hdr[n]["data_offsets"][1]]
+            raise KeyError(n)
+        blocks = T[name].data.reshape(-1, bsz)
+        if quant == "q2_k":
+            assert np.array_equal(get(name + ".qs").reshape(-1, 64), blocks[:, 16:80])
+            assert np.array_equal(get(name + ".dm").reshape(-1, 4), blocks[:, 80:84])
+            sc = get(name + ".sc").reshape(-1, 16)
+            for jj in range(16):  # sub-block 8h + 2s + lh sits at quarter 2h + lh, slot s
+                h, s, lh = jj >> 3, (jj >> 1) & 3, jj & 1
+                assert np.array_equal(sc[:, (2 * h + lh) * 4 + s], blocks[:, jj])
+        else:
+            assert np.array_equal(get(name + ".hm").reshape(-1, 32), blocks[:, :32])
+            assert np.array_equal(get(name + ".qs").reshape(-1, 64), blocks[:, 32:96])
+            assert np.array_equal(get(name + ".sc").reshape(-1, 12), blocks[:, 96:108])
+            assert np.array_equal(get(name + ".dm").reshape(-1, 2), blocks[:, 108:110])
+        assert np.array_equal(get("model.layers.1.moegate.weight").view(np.float32), T["model.layers.1.moegate.weight"].data.reshape(-1))

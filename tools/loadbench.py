@@ -39,6 +39,21 @@ def main():
                   f"(pread into pinned buffers {s.read_seconds:.2f} s = {s.file_bytes / max(s.read_seconds, 1e-9) / 1e9:.2f} GB/s)")
             lg = M.forward(5, 0)
             M.close()
+        # the same checkpoint in the engine's plane layout (tools/repack.py): no staging copy, no repack kernels
+        from tools import repack
+        d2 = tempfile.mkdtemp(prefix="dsk_loadbench_planes_", dir=base)
+        try:
+            repack.repack(d, d2)
+            for label in ("planes: first load", "planes: second load"):
+                M = dsk.Model.from_dseek(ctx, d2)
+                s = M.load_stats
+                print(f"{label:26s}: {s.file_bytes / 1e9:.2f} GB, {s.n_tensors} tensors in {s.seconds:.2f} s = {s.file_bytes / s.seconds / 1e9:.2f} GB/s "
+                      f"(pread into pinned buffers {s.read_seconds:.2f} s)")
+                import numpy as np
+                assert np.array_equal(lg, M.forward(5, 0))
+                M.close()
+        finally:
+            shutil.rmtree(d2, ignore_errors=True)
         t1 = time.time()
         M = dsk.Model(ctx, c, T)
         dt = time.time() - t1
