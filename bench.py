@@ -243,7 +243,7 @@ def main():
             # own dispatch timestamps inside the real token sequence (what rocprofv3 --kernel-trace reports);
             # other classes: their launches of a token, back to back between two events (dsk_time_kernel_class)
             us, nb, n_l = g["total_ms"] / g["launches"] * 1e3, g["algo_bytes"] / g["launches"], per_tok
-            if not name.startswith("gemv_"):
+            if not (name.startswith("gemv_") or name == "moe_ffn"):  # moe_ffn: its own dispatch timestamps too
                 try:
                     us, nb, n_l = M.time_kernel_class(name, pos, reps=6)
                 except dsk.DskError:

@@ -305,7 +305,7 @@ ADEV void attn_out_q8(const AttnMhaArgs& a, int h, int tid, float o, int* last_f
       const unsigned old = __hip_atomic_fetch_add(a.q_counter + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       *last_flag = old == (unsigned)(h1 - h0);
       if (*last_flag) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        FINISHER_ACQUIRE();
         __hip_atomic_store(a.q_counter + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }

@@ -26,6 +26,26 @@ void dsk_set_error(int code, const char* fmt, ...);
     if (_r != DSK_OK) return _r; \
   } while (0)
 
+// ---- last-arriver hand-offs inside a launch (MoE combine, router gate, attention Q8_K finisher, split-context merge) ----
+// Protocol: the payload goes out with write-through stores (__hip_atomic_store relaxed/agent = global_store sc1), EVERY
+// storing wave drains its stores (asm s_waitcnt vmcnt(0)), __syncthreads, ONE lane arrives on a counter (relaxed agent
+// fetch_add); the workgroup that sees the last count reads the payload with sc1 LOADS (__hip_atomic_load relaxed/agent),
+// which are served by L2 / memory and never by the reading CU's L1.  That is the "{sc1 stores and sc1 loads on both
+// sides}" form MI355X_MICROARCH.md lists as valid on gfx950 without any agent-scope fence: the drained write-through
+// store is in memory before the arrival is issued, and the finisher's loads cannot hit a stale L1 line.  The agent
+// acquire the finisher ALSO issues (buffer_inv sc1) is therefore belt and braces; it stays on because it is cheap where
+// it sits (measured: the whole token 5.350 ms with it, 5.327 ms without, -DDSK_FINISHER_ACQUIRE=0) and makes the
+// protocol a textbook release-by-drain / acquire pair.  tests/test_fused_moe_gpu.py replays every hand-off thousands
+// of times from a captured graph and checks the bits.
+#ifndef DSK_FINISHER_ACQUIRE
+#define DSK_FINISHER_ACQUIRE 1
+#endif
+#if DSK_FINISHER_ACQUIRE
+#define FINISHER_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#else
+#define FINISHER_ACQUIRE() ((void)0)
+#endif
+
 // ---- device-side tensor views -------------------------------------------------
 // K-quant matrices are re-laid-out at upload into byte planes (same total bytes as the
 // reference's AoS blocks, src/quant.h:41-52,70-76), so that a wave reads each plane with

@@ -552,8 +552,6 @@ static int ffn(dsk_model* m, int l) {
   const bool exchange = m->ctx->world > 1 && !m->class_filter;  // (class timing enqueues one kernel class only)
   if (m->moe_ffn[l].grid > 0) {  // routed experts (+ the shared expert's W2) + combine: one launch
     MoeFfnArgs a = m->moe_ffn[l];
-    // (class timing enqueues this class alone: no router launch in front re-arms the slot counters)
-    if (m->class_filter) HIP_TRY(hipMemsetAsync(m->moe_ctr, 0, 32 * 4, st));
     if (m->stage_layer == l && m->tap_qs) {
       a.tap_qs = m->tap_qs + m->tap_off_hb;
       a.tap_d = m->tap_d + m->tap_off_hb / 256;
@@ -565,7 +563,14 @@ static int ffn(dsk_model* m, int l) {
       DSK_TRY(launch_moe_ffn(st, a, p.e0, p.e1));
       m->ktimes[p.idx].ev.push_back({p.e0, p.e1});
     } else {
-      PROFILED("moe_ffn", a.algo_bytes, launch_moe_ffn(st, a, nullptr, nullptr));
+      Prof p;
+      DSK_TRY(prof_begin(m, "moe_ffn", a.algo_bytes, &p));
+      if (!p.skip) {
+        // class timing enqueues this class alone: no router launch in front re-arms the slot counters
+        if (m->class_filter) HIP_TRY(hipMemsetAsync(m->moe_ctr, 0, 32 * 4, st));
+        DSK_TRY(launch_moe_ffn(st, a, nullptr, nullptr));
+      }
+      DSK_TRY(prof_end(&p));
     }
     return DSK_OK;
   }

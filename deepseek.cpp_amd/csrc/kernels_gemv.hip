@@ -110,11 +110,13 @@ DEV void gemv_body(const GemvLaunch* __restrict__ Lp, const void* h_a0, const vo
   if (tl && tid == 0) tl[7] = wall_clock64();
   __syncthreads();
   if (tl && tid == 0) tl[1] = wall_clock64();
+#ifndef DSK_NO_TAPS
   if constexpr (KQ) {
     if (L.tap_qs && !bd && wi == 0)  // parity tap: what this activation group staged
       dump_staged_q8<QT == DSK_QUANT_Q2_K>(smem, L.t[t0].n, L.tap_qs + (size_t)grp_idx * L.tap_stride,
                                           L.tap_d + (size_t)grp_idx * (L.tap_stride >> 8), tid, NW * 64);
   }
+#endif
 
   // this workgroup's share of the group's virtual rows, in multiples of part_unit
   const int vtotal = bd ? L.t[0].rows : L.t[t1 - 1].vrow_end;
@@ -179,7 +181,7 @@ DEV void gemv_body(const GemvLaunch* __restrict__ Lp, const void* h_a0, const vo
           const unsigned old = __hip_atomic_fetch_add(L.comb_counter + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           comb_last = old == (unsigned)L.n_tasks - 1;
           if (comb_last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            FINISHER_ACQUIRE();
             __hip_atomic_store(L.comb_counter + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
           }
         }
@@ -311,12 +313,14 @@ __global__ __launch_bounds__(1024) void head_attn_kernel(const HeadAttnArgs A, c
     else stage_f32<NW>(A.tkv, reinterpret_cast<float*>(act_kv), tid, scratch);
   }
   __syncthreads();
+#ifndef DSK_NO_TAPS
   if constexpr (KQ) {
     if (A.tap_qs && blockIdx.x == 0) {  // parity tap
       if (A.has_q) dump_staged_q8<QT == DSK_QUANT_Q2_K>(act_q, A.tq.n, A.tap_qs, A.tap_d, tid, 1024);
       dump_staged_q8<QT == DSK_QUANT_Q2_K>(act_kv, A.tkv.n, A.tap_qs + A.tap_stride, A.tap_d + (A.tap_stride >> 8), tid, 1024);
     }
   }
+#endif
 
   // head h's rows of one projection: 64/LPR rows per wave and step.  (Dealing both projections' rows to the
   // waves as one unit list, or 2 row sets per lane, measured slower: this stage is VALU-bound on its one CU.)
@@ -366,7 +370,7 @@ __global__ __launch_bounds__(1024) void head_attn_kernel(const HeadAttnArgs A, c
     const unsigned old = __hip_atomic_fetch_add(A.split_counter + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     last_flag = old == (unsigned)(S - 1);
     if (last_flag) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      FINISHER_ACQUIRE();
       __hip_atomic_store(A.split_counter + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
     }
   }
@@ -606,10 +610,12 @@ __global__ __launch_bounds__(1024) void mla_head_kernel(const MlaHeadArgs A, con
     for (int i = tid; i < lora; i += NT) reinterpret_cast<float*>(act)[i] = o_s[i];
   }
   __syncthreads();
+#ifndef DSK_NO_TAPS
   if (A.tap_o) {  // parity tap: this head's latent output and the Q8_K vector staged for wv_b
     for (int i = tid; i < lora; i += NT) A.tap_o[(size_t)h * lora + i] = o_s[i];
     if constexpr (KQ) dump_staged_q8<QT == DSK_QUANT_Q2_K>(act, lora, A.tap_qs + (size_t)h * lora, A.tap_d + (size_t)h * (lora >> 8), tid, NT);
   }
+#endif
   {
     const int lpr_log2 = A.lpr_log2, RPW = 64 >> lpr_log2;
     const int rloc = lane >> lpr_log2, sub = lane & ((1 << lpr_log2) - 1);
@@ -855,6 +861,8 @@ int gemv_plan(GemvLaunch& h, int target_wgs) {
     lpr = h.force_lpr;
   }
   const long rows_eff = h.bd_heads > 0 ? (long)h.t[0].rows * h.bd_heads : total_rows;
+  // (fewer lanes per row so that a 16-wave workgroup's share fits ONE row group -- wo: 32 lanes, one round trip of 8
+  // loads instead of two of 4 -- measured slower: 11.9 -> 12.9 us; two rows per lane likewise: 12.0 -> 13.1)
   h.lpr_log2 = ilog2(lpr);
   // (R, U) variant and grid, from the sweeps of tools/kbench.py on MI355X (DeepSeek-V3 shapes): the
   // geometry moves a launch by < 10 % -- U = 4 column steps in flight is right for plain and GLU
@@ -890,13 +898,6 @@ int gemv_plan(GemvLaunch& h, int target_wgs) {
   if (small_nw16 && h.NW == 4 && !cg && h.bd_heads <= 0 && kq && h.force_NW <= 0 && total_rows >= 32L * 16 * RPW) { h.NW = 16; fill_div = 4; }
   if (h.force_NW == 4 || h.force_NW == 16) h.NW = h.force_NW;
   if (h.fill_div > 0) fill_div = h.fill_div;
-  // (two rows per lane so that a workgroup's share fits ONE step -- wo: 28 rows at 16 per step -- measured slower:
-  // 12.0 -> 13.1 us; kept behind DSK_R2 for A/B runs)
-  static const int r2 = getenv("DSK_R2") ? atoi(getenv("DSK_R2")) : 0;
-  if (r2 && !cg && !h.glu && h.bd_heads <= 0 && h.NW == 16 && h.force_R <= 0 && h.R == 1 && h.quant != DSK_QUANT_Q3_K) {
-    const long per_wg = (total_rows + 255) / 256;
-    if (per_wg > 16L * RPW && per_wg <= 32L * RPW) { h.R = 2; if (h.U > 4) h.U = 4; }
-  }
   // Q3_K items hold three planes per step: under the 128-VGPR budget of a 16-wave workgroup the wide
   // variants spill inside the column loop (hipcc: 172..664 B of scratch), so they take fewer steps in flight
   if (h.quant == DSK_QUANT_Q3_K && h.NW == 16 && h.force_U <= 0) {

@@ -238,6 +238,9 @@ __global__ __launch_bounds__(1024) void moe_ffn_kernel(const MoeFfnArgs a) {
   }
 }
 
+#ifndef MOE_UA
+#define MOE_UA 4
+#endif
 // ---- host side ------------------------------------------------------------------------------------------
 int moe_ffn_plan(MoeFfnArgs& a, int n_cus) {
   const bool q3 = a.quant == DSK_QUANT_Q3_K;
@@ -274,7 +277,7 @@ int launch_moe_ffn(hipStream_t st, const MoeFfnArgs& a, hipEvent_t ev_start, hip
     if (ev_start && ev_stop) hipExtLaunchKernelGGL(k, dim3(a.grid), dim3(1024), (uint32_t)lds, st, ev_start, ev_stop, 0u, a);
     else hipLaunchKernelGGL(k, dim3(a.grid), dim3(1024), lds, st, a);
   };
-  if (a.quant == DSK_QUANT_Q2_K) go(moe_ffn_kernel<DSK_QUANT_Q2_K, 4, 4>);
+  if (a.quant == DSK_QUANT_Q2_K) go(moe_ffn_kernel<DSK_QUANT_Q2_K, MOE_UA, 4>);
   else go(moe_ffn_kernel<DSK_QUANT_Q3_K, 2, 2>);  // (more column steps in flight spill at 16 waves x 128 VGPRs: gemv_plan's caps)
   return DSK_OK;
 }

@@ -249,7 +249,7 @@ RDEV void router_body(const RouterArgs& a, int bid, int nblocks) {
   if (tid == 0) {
     const unsigned old = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     is_last = old == (unsigned)nblocks - 1;
-    if (is_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (is_last) FINISHER_ACQUIRE();
   }
   __syncthreads();
   if (!is_last) return;

@@ -2,6 +2,7 @@
 recorded outputs (tests/golden/model_*.npz), the CPU oracle and -- where the prebuilt
 oracle/_ref/libdskref.so loads -- the unmodified reference running live on the host.
 """
+import os
 import tempfile
 
 import numpy as np
