@@ -19,13 +19,16 @@ import sqlite3
 
 # bench.py kernel class -> substring of the kernel symbol that implements it in the V3 Q2_K bench
 CLASS_KERNEL = {
-    # one kernel, two populations of dispatches (8 routed experts: fewer bytes; dense w1/w3): the lower / upper cluster
+    "moe_ffn": "moe_ffn_kernel",  # routed experts w1/w3 + W2 + the shared expert's W2 + combine: one launch (round 2)
+    # (two-launch form, DSK_NO_FUSE_MOE=1): one kernel, two populations of dispatches (8 routed experts / dense w1/w3)
     "gemv_experts_w13": ("gemv_kernel<3, 1, 4, true, 16>", "lo"),
     "gemv_dense_w13": ("gemv_kernel<3, 1, 4, true, 16>", "hi"),
     "gemv_experts_w2": "gemv_kernel<3, 2, 4, false, 4>",
     "gemv_wo": "gemv_kernel<3, 1, 4, false, 16>",
+    "gemv_qkv_a": "gemv_kernel<3, 1, 8, false, 16>",  # also lm_head (1 dispatch per token, 304 MB) and dense w2: use "lo"
     "router_gate": "router_shared_kernel",  # router + the shared expert's w1/w3 (router_gate_kernel when not fused)
     "attn_mha": "head_attn_kernel",
+    "attn_mla": "mla_head_kernel",
 }
 READ_BW_BYTES = 4 << 30  # bench.py: ctx.measure_read_bw(4 << 30, 5)
 
@@ -99,7 +102,14 @@ def main():
                         f = cs["FETCH_SIZE"]
                         spread = f["max"] > 1.05 * f["min"]  # two populations only if the counter really splits
                         traffic[cls] = round(f[{"lo": "lo_avg", "hi": "hi_avg"}.get(which, "avg") if spread else "avg"] * cal)
-        json.dump(dict(note=a.note, calibration=dict(kernel="read_bw_kernel (16 B/lane streaming read of 4 GiB)", bytes_per_fetch_size_unit=cal),
+        import hashlib
+        h = hashlib.sha256()
+        cs_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "deepseek.cpp_amd", "csrc")
+        for fn in sorted(os.listdir(cs_dir)):
+            if fn.endswith((".hip", ".h", ".cpp")):
+                h.update(fn.encode())
+                h.update(open(os.path.join(cs_dir, fn), "rb").read())
+        json.dump(dict(note=a.note, csrc_sha=h.hexdigest()[:16], calibration=dict(kernel="read_bw_kernel (16 B/lane streaming read of 4 GiB)", bytes_per_fetch_size_unit=cal),
                        traffic_bytes_per_launch=traffic, counters=p), open(a.out + "_pmc.json", "w"), indent=1)
         print("calibration bytes per FETCH_SIZE unit:", cal)
         print("traffic per launch:", traffic)
