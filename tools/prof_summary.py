@@ -25,7 +25,8 @@ CLASS_KERNEL = {
     "gemv_dense_w13": ("gemv_kernel<3, 1, 4, true, 16>", "hi"),
     "gemv_experts_w2": "gemv_kernel<3, 2, 4, false, 4>",
     "gemv_wo": "gemv_kernel<3, 1, 4, false, 16>",
-    "gemv_qkv_a": "gemv_kernel<3, 1, 8, false, 16>",  # also lm_head (1 dispatch per token, 304 MB) and dense w2: use "lo"
+    # gemv_kernel<3, 1, 8, false, 16> serves wq_a || wkv_a (5 MB), dense w2 (43 MB) and lm_head (304 MB): three populations
+    "gemv_qkv_a": ("gemv_kernel<3, 1, 8, false, 16>", "min"),
     "router_gate": "router_shared_kernel",  # router + the shared expert's w1/w3 (router_gate_kernel when not fused)
     "attn_mha": "head_attn_kernel",
     "attn_mla": "mla_head_kernel",
@@ -101,7 +102,10 @@ def main():
                     if sub in name and "FETCH_SIZE" in cs:
                         f = cs["FETCH_SIZE"]
                         spread = f["max"] > 1.05 * f["min"]  # two populations only if the counter really splits
-                        traffic[cls] = round(f[{"lo": "lo_avg", "hi": "hi_avg"}.get(which, "avg") if spread else "avg"] * cal)
+                        traffic[cls] = round(f[{"lo": "lo_avg", "hi": "hi_avg", "min": "min"}.get(which, "avg") if spread else "avg"] * cal)
+            if "moe_ffn" in traffic:  # fused build: gemv_kernel<3,1,4,true,16> is the dense w1/w3 only
+                traffic.pop("gemv_experts_w13", None)
+                traffic.pop("gemv_experts_w2", None)
         import hashlib
         h = hashlib.sha256()
         cs_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "deepseek.cpp_amd", "csrc")
