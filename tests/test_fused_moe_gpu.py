@@ -50,6 +50,17 @@ def test_fused_moe_equals_two_launch_form_bit_for_bit_small_models(ctx, monkeypa
     B.close()
 
 
+def test_fused_moe_without_a_shared_expert_and_with_top1(ctx, monkeypatch):
+    """corner shapes of the fused launch: no shared expert (K slots only), and a single active expert"""
+    for over in (dict(n_shared_experts=0), dict(n_active_routed=1, n_group=1, topk_group=1, topk_method="greedy")):
+        c = synth.preset("tiny_v3", "q2_k", False, **over)
+        T = synth.synth_model(c, seed=23)
+        A, B = _pair(ctx, monkeypatch, c, T)
+        _same(A, B, [5, 9, 700, 3], c)
+        A.close()
+        B.close()
+
+
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("mla", [False, True], ids=["mha", "mla"])
 def test_fused_moe_equals_two_launch_form_at_v3_width(ctx, monkeypatch, mla):

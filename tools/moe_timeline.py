@@ -26,3 +26,14 @@ for i, nm in enumerate(names):
     print(f"{nm:18s} {v.min():8.2f} {np.median(v):8.2f} {v.max():8.2f}")
 d = np.diff(t[:, :7], axis=1)
 print("segment medians (us):", {names[i + 1]: round(float(np.median(d[:, i])), 2) for i in range(6)})
+
+# who is slow?  block b runs on XCD b % 8 (MI355X_MICROARCH.md); phase-A unit b belongs to slot b // 32
+a_done = t[:, 2] - t0
+print("phase A done by XCD  (median us):", [round(float(np.median(a_done[np.arange(n) % 8 == x])), 1) for x in range(8)])
+print("phase A done by slot (median us):", [round(float(np.median(a_done[np.arange(n) // 32 == k])), 1) for k in range(8)])
+print("phase A done by slot (max us):   ", [round(float(np.max(a_done[np.arange(n) // 32 == k])), 1) for k in range(8)])
+order = np.argsort(a_done)
+print("slowest 12 workgroups:", [(int(b), round(float(a_done[b]), 1)) for b in order[-12:]])
+print("fastest 8 workgroups: ", [(int(b), round(float(a_done[b]), 1)) for b in order[:8]])
+ent = t[:, 0] - t0
+print("entry by XCD (median us):", [round(float(np.median(ent[np.arange(n) % 8 == x])), 2) for x in range(8)])
