@@ -130,3 +130,29 @@ def test_router_logits_op_vs_sequential_reference_sum(ctx, oracle):
         ref = oracle.gemv(0, w, E, dim, oracle.rmsnorm(x, nw, 1e-6))
         assert np.max(np.abs(got - ref)) < 2e-5 * max(1.0, float(np.max(np.abs(ref)))), (E, dim, float(np.max(np.abs(got - ref))))
         assert np.array_equal(got, ctx.router_logits(w, x, nw, 1e-6))  # fixed tree: bit-reproducible
+
+
+def test_run_block_and_get_stage_reject_bad_arguments(ctx):
+    """the harness entry points return error codes like the rest of the boundary (never abort)"""
+    import dsk
+    c = synth.preset("tiny_v3", "q2_k", False)
+    M = dsk.Model(ctx, c, None, synth_seed=1)
+    x = np.zeros(c.dim, np.float32)
+    with pytest.raises(dsk.DskError):
+        M.stage("x_mid", c.dim)          # nothing tapped yet
+    with pytest.raises(dsk.DskError):
+        M.run_block(c.n_layers, x, 0)    # no such layer
+    with pytest.raises(dsk.DskError):
+        M.run_block(0, x, -1)
+    M.run_block(1, x, 0)
+    with pytest.raises(dsk.DskError):
+        M.stage("no_such_stage", 4)
+    with pytest.raises(dsk.DskError):
+        M.stage("x_mid", c.dim + 1)      # more than the stage holds
+    assert M.stage("x_mid", c.dim).shape == (c.dim,)
+    # a normal decode step still works (graph replay) and the taps are off: bit-identical to a fresh model
+    a = M.forward(7, 0)
+    M2 = dsk.Model(ctx, c, None, synth_seed=1)
+    assert np.array_equal(a, M2.forward(7, 0))
+    M.close()
+    M2.close()
