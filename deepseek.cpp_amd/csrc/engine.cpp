@@ -655,6 +655,7 @@ extern "C" int dsk_model_finalize(dsk_model* m) {
   HIP_TRY(hipHostMalloc((void**)&m->err_host, 64, hipHostMallocDefault));
   memset(m->err_host, 0, 64);
   m->fuse_moe = getenv("DSK_NO_FUSE_MOE") == nullptr;
+  m->att_q8_in_wo = getenv("DSK_ATT_Q8_IN_WO") != nullptr && atoi(getenv("DSK_ATT_Q8_IN_WO")) != 0;
   if (getenv("DSK_MOE_TIMELINE")) {
     HIP_TRY(hipMalloc((void**)&m->moe_timeline, 1024 * 8 * 8));
     HIP_TRY(hipMemset(m->moe_timeline, 0, 1024 * 8 * 8));

@@ -109,6 +109,7 @@ struct dsk_model {
   std::vector<int> lp_sh13;  // shared expert's w1/w3 GLU riding in the router launch (-1: it is a task of lp_w13)
   // routed experts in one launch (kernels_moe.hip); grid == 0: the layer keeps the two-launch form (lp_w13, lp_w2)
   std::vector<MoeFfnArgs> moe_ffn;
+  bool att_q8_in_wo = false;       // DSK_ATT_Q8_IN_WO=1: wo quantises the attention output in its own prologue (no finisher hand-off in the attention launch)
   bool fuse_moe = true;            // DSK_NO_FUSE_MOE at model creation switches it off (A/B, bit-identity tests)
   unsigned* moe_ctr = nullptr;     // slot_ctr[16] | slot_pass[16]
   unsigned long long* moe_timeline = nullptr;  // DSK_MOE_TIMELINE=1: stamps of the LAST fused expert launch of a token
@@ -138,7 +139,7 @@ struct dsk_model {
   float* tap_latent = nullptr;   // MLA: per-head latent outputs (H, lora)
   float* stage_x_mid = nullptr;  // residual stream after the attention half of the block
   size_t tap_off_xattn = 0, tap_off_qa = 0, tap_off_kva = 0, tap_off_xffn = 0, tap_off_xffn_sh = 0, tap_off_hb = 0,
-         tap_off_latent = 0, tap_off_final = 0, tap_total = 0;
+         tap_off_latent = 0, tap_off_final = 0, tap_off_att = 0, tap_total = 0;
   // profiling
   bool profiling = false;
   std::vector<KTime> ktimes;

@@ -201,7 +201,7 @@ int build_plans(dsk_model* m) {
         a.lora = c.kv_lora_rank; a.is_v3 = c.has_moegate_bias;
         a.q_counter = m->att_counter;
         A.split_part = m->mha_split_part; A.split_counter = m->mha_split_counter;
-        if (kq) { a.q_qs = m->a_att.qs; a.q_d = m->a_att.d; a.q_bsums = m->a_att.bsums; }
+        if (kq && !m->att_q8_in_wo) { a.q_qs = m->a_att.qs; a.q_d = m->a_att.d; a.q_bsums = m->a_att.bsums; }
         DSK_TRY(head_attn_plan(A));
         A.a.out = m->att_out;
         m->head_attn[l] = A;
@@ -228,7 +228,7 @@ int build_plans(dsk_model* m) {
       A.a.out = m->att_out; A.a.n_heads = H; A.a.head_dim = m->head_dim; A.a.rope = c.qk_rope_head_dim; A.a.lora = c.kv_lora_rank;
       A.a.is_v3 = c.has_moegate_bias;
       A.fin.out = m->vb_out; A.fin.v_dim = c.v_head_dim; A.fin.n_heads = H; A.fin.q_counter = m->att_counter;
-      if (kq) { A.fin.q_qs = m->a_att.qs; A.fin.q_d = m->a_att.d; A.fin.q_bsums = m->a_att.bsums; }
+      if (kq && !m->att_q8_in_wo) { A.fin.q_qs = m->a_att.qs; A.fin.q_d = m->a_att.d; A.fin.q_bsums = m->a_att.bsums; }
       if (m->fl_part_o) {  // kv_len >= MLA_FLASH_MIN_KV: scores / values of all heads on the matrix cores, merged per head here
         const int max_kv = std::min(c.max_seq_len, std::max(1, c.rs_original_max_position_embeddings));
         MlaFlashArgs F;
@@ -250,7 +250,7 @@ int build_plans(dsk_model* m) {
       GemvTask& T = h.t[h.n_tasks++];
       task_weights(T, L.t[DSK_ROLE_WO]);
       const float* src = c.use_mla ? m->vb_out : m->att_out;
-      if (kq) task_act_q8(T, m->a_att);
+      if (kq && !m->att_q8_in_wo) task_act_q8(T, m->a_att);
       else task_act_f32(T, src);
       T.out = m->x; T.epilogue = EPI_ADD;
       h.algo_bytes = weight_bytes_2d(m, wq, T.rows, T.n) + io_bytes(wq, T.n, T.rows) + 4.0 * T.rows;
@@ -855,6 +855,7 @@ static int ensure_taps(dsk_model* m) {
   m->tap_off_hb = o; o += up256(hb_n);
   m->tap_off_latent = o; o += up256((size_t)c.n_heads * std::max(1, c.kv_lora_rank));
   m->tap_off_final = o; o += up256(c.dim);
+  m->tap_off_att = o; o += up256((size_t)c.n_heads * c.v_head_dim);
   m->tap_total = o;
   HIP_TRY(hipMalloc((void**)&m->tap_qs, o));
   HIP_TRY(hipMalloc((void**)&m->tap_d, o / 256 * 4));
@@ -882,6 +883,7 @@ static int patch_layer(dsk_model* m, int l, bool on) {
   const int hb_stride = std::max(std::max(c.moe_intermediate_size, shared_n), 1);
   DSK_TRY(patch_plan(m, m->lp_qkv_a[l], m->tap_off_xattn, 0, on));
   if (c.use_mla) DSK_TRY(patch_plan(m, m->lp_qkv_b[l], m->tap_off_qa, 0, on));  // wq_rope_b || wc on norm(q_a)
+  if (m->att_q8_in_wo) DSK_TRY(patch_plan(m, m->lp_wo[l], m->tap_off_att, 0, on));
   DSK_TRY(patch_plan(m, m->lp_w13[l], m->tap_off_xffn, 0, on));
   DSK_TRY(patch_plan(m, m->lp_sh13[l], m->tap_off_xffn_sh, 0, on));
   DSK_TRY(patch_plan(m, m->lp_w2[l], m->tap_off_hb, m->L[l].is_moe ? hb_stride : 0, on));
@@ -984,6 +986,8 @@ extern "C" int dsk_model_get_stage(dsk_model* m, const char* name, void* out, si
   else if (s == "q8.x_ffn_shared.d") tapd(m->tap_off_xffn_sh, c.dim);
   else if (s == "q8.x_ffn.qs") { src = m->a_xb.qs; avail = m->a_xb.qs ? (size_t)c.dim : 0; }
   else if (s == "q8.x_ffn.d") { src = m->a_xb.d; avail = m->a_xb.d ? (size_t)c.dim / 256 * 4 : 0; }
+  else if (s == "q8.att.qs" && m->att_q8_in_wo) tapq(m->tap_off_att, (size_t)H * c.v_head_dim);
+  else if (s == "q8.att.d" && m->att_q8_in_wo) tapd(m->tap_off_att, (size_t)H * c.v_head_dim);
   else if (s == "q8.att.qs") { src = m->a_att.qs; avail = m->a_att.qs ? (size_t)H * c.v_head_dim : 0; }
   else if (s == "q8.att.d") { src = m->a_att.d; avail = m->a_att.d ? (size_t)H * c.v_head_dim / 256 * 4 : 0; }
   else if (s == "q8.hb.qs") tapq(m->tap_off_hb, hb_n);

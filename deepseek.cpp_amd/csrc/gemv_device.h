@@ -707,6 +707,34 @@ DEV void rows_dot_kq(const KQRsrc& B, int items, int sub, int lpr_log2, int q, c
   }
 }
 
+// The same dot products for a row length known at COMPILE time (ITS column steps of 2^LL lanes, exact fit): two
+// 2-step buffers alternate and every bound folds away, so the code is straight-line and hipcc's waitcnt pass counts the
+// loads exactly (vmcnt(N) ladders instead of vmcnt(0)): one buffer is multiplied while the other's loads are in flight.
+// Column steps are consumed in order: same sums, same bits as rows_dot_kq.
+template <int QT, int R, bool GLU, int ITS, int LL>
+DEV void rows_dot_kq_exact(const KQRsrc& B, int sub, int q, const int (&rowblk)[R], const uint8_t* lds_lane, float (&acc)[R], float (&acc2)[R]) {
+  constexpr int ITEMS = ITS << LL;
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = acc2[r] = 0.f;
+  ChunkKQ<QT, R, 2, GLU> ca, cb;
+  load_chunk_kq<QT, R, 2, GLU>(ca, B, ITS, ITEMS, sub, LL, q, rowblk, 0);
+  if (ITS > 2) load_chunk_kq<QT, R, 2, GLU>(cb, B, ITS, ITEMS, sub, LL, q, rowblk, 2);
+#pragma unroll
+  for (int it0 = 0; it0 < ITS; it0 += 4) {
+    compute_chunk_kq<QT, R, 2, GLU>(ca, ITS, ITEMS, sub, LL, q, it0, lds_lane, acc, acc2);
+    if (it0 + 4 < ITS) load_chunk_kq<QT, R, 2, GLU>(ca, B, ITS, ITEMS, sub, LL, q, rowblk, it0 + 4);
+    if (it0 + 2 < ITS) {
+      compute_chunk_kq<QT, R, 2, GLU>(cb, ITS, ITEMS, sub, LL, q, it0 + 2, lds_lane, acc, acc2);
+      if (it0 + 6 < ITS) load_chunk_kq<QT, R, 2, GLU>(cb, B, ITS, ITEMS, sub, LL, q, rowblk, it0 + 6);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    acc[r] = lanes_sum(acc[r], LL);
+    if (GLU) acc2[r] = lanes_sum(acc2[r], LL);
+  }
+}
+
 template <int QT, int R, int U, bool GLU>
 DEV void rows_dot_f(const WPtr& P, int n, int b0, int b1, int lpr_log2, int lane, const int (&row)[R], const uint8_t* lds,
                     float (&acc)[R], float (&acc2)[R]) {

@@ -26,6 +26,13 @@
 #include "dsk_internal.h"
 #include "gemv_device.h"
 
+#ifndef GEMV_EXACT
+#define GEMV_EXACT 1  // -DGEMV_EXACT=0: only the generic chunk loop in gemv_body (A/B builds)
+#endif
+#ifndef HEAD_EXACT
+#define HEAD_EXACT 1  // -DHEAD_EXACT=0: the generic row loop in the per-head attention kernel (A/B builds)
+#endif
+
 // ------------------------------------------------------------------------------------
 // the kernel.  A workgroup belongs to one activation group (tasks sharing an input vector), stages that
 // vector once, and walks its even share of the group's concatenated rows.
@@ -143,6 +150,8 @@ DEV void gemv_body(const GemvLaunch* __restrict__ Lp, const void* h_a0, const vo
     }
     const KQRsrc B = kq_rsrc<QT, GLU>(P);
     const int nb = T.n >> 8;
+    // (wo of DeepSeek-V3 - 28 rows per workgroup = two steps of 16 - with BOTH row groups requested at once and multiplied
+    // as they arrive, straight-line: 12.2 -> 12.7 us; like every deeper burst tried, slower)
     for (int base = lo; base < hi; base += RG) {
       int row[R];
       bool valid[R];
@@ -160,7 +169,14 @@ DEV void gemv_body(const GemvLaunch* __restrict__ Lp, const void* h_a0, const vo
           int rowblk[R];
 #pragma unroll
           for (int r = 0; r < R; ++r) rowblk[r] = row[r] * nb + (sub >> 2);
-          rows_dot_kq<QT, R, U, GLU>(B, nb * 4, sub, lpr_log2, q, rowblk, lds_lane, acc, acc2);
+          if constexpr (GEMV_EXACT && QT == DSK_QUANT_Q2_K && (GLU || GEMV_EXACT > 1) && R == 1 && NW == 16) {
+            // 7168-wide rows at 16 lanes each (dense w1/w3, the shared expert's rider, the two-launch experts): the
+            // software-pipelined straight-line form, same bits (gemv_device.h rows_dot_kq_exact)
+            if (lpr_log2 == 4 && nb == 28) rows_dot_kq_exact<QT, 1, GLU, 7, 4>(B, sub, q, rowblk, lds_lane, acc, acc2);
+            else rows_dot_kq<QT, R, U, GLU>(B, nb * 4, sub, lpr_log2, q, rowblk, lds_lane, acc, acc2);
+          } else {
+            rows_dot_kq<QT, R, U, GLU>(B, nb * 4, sub, lpr_log2, q, rowblk, lds_lane, acc, acc2);
+          }
         } else {
           rows_dot_f<QT, R, U, GLU>(P, T.n, L.b0, L.b1, lpr_log2, lane, row, smem, acc, acc2);
         }
@@ -344,10 +360,54 @@ __global__ __launch_bounds__(1024) void head_attn_kernel(const HeadAttnArgs A, c
       if (sub == 0 && valid) out_lds[lr] = acc[0];
     }
   };
-  if (A.has_q) head_rows(A.tq, act_q, A.lq_log2, a.head_dim, q_s);
-  else
-    for (int i = tid; i < a.head_dim; i += 1024) q_s[i] = a.q[(size_t)h * a.head_dim + i];
-  head_rows(A.tkv, act_kv, A.lkv_log2, a.nope + a.v_dim, kvb_s);
+  bool done_exact = false;
+#if HEAD_EXACT
+  if constexpr (QT == DSK_QUANT_Q2_K) {
+    // DeepSeek-V3 shapes (192 q rows of 1536, 256 kv rows of 512, 8 lanes per row: 3 and 1 column steps, all known at
+    // compile time): every wave requests ALL its rows of both projections at once - q rows w*8.., kv rows w*8.. and
+    // 128 + w*8.., and for waves 0-7 q rows 128 + w*8.. - and multiplies them as they arrive (straight-line code: hipcc
+    // counts the loads exactly), instead of four dependent load -> wait -> multiply round trips.  Same lanes per row and
+    // column order as head_rows: same bits.
+    if (A.has_q && A.lq_log2 == 3 && A.lkv_log2 == 3 && A.tq.n == 1536 && A.tkv.n == 512 && a.head_dim == 192 && a.nope + a.v_dim == 256) {
+      done_exact = true;
+      const int rloc = lane >> 3, sub = lane & 7, q = sub & 3;
+      const KQRsrc Bq = kq_rsrc<QT, false>(resolve(A.tq)), Bk = kq_rsrc<QT, false>(resolve(A.tkv));
+      const int lr0 = wave * 8 + rloc, lr1 = 128 + lr0;
+      const int rbq0[1] = {(h * 192 + lr0) * 6 + (sub >> 2)}, rbq1[1] = {(h * 192 + (lr1 < 192 ? lr1 : 191)) * 6 + (sub >> 2)};
+      const int rbk0[1] = {(h * 256 + lr0) * 2 + (sub >> 2)}, rbk1[1] = {(h * 256 + lr1) * 2 + (sub >> 2)};
+      ChunkKQ<QT, 1, 3, false> cq0, cq1;
+      ChunkKQ<QT, 1, 1, false> ck0, ck1;
+      load_chunk_kq<QT, 1, 3, false>(cq0, Bq, 3, 24, sub, 3, q, rbq0, 0);
+      load_chunk_kq<QT, 1, 1, false>(ck0, Bk, 1, 8, sub, 3, q, rbk0, 0);
+      load_chunk_kq<QT, 1, 1, false>(ck1, Bk, 1, 8, sub, 3, q, rbk1, 0);
+      if (wave < 8) load_chunk_kq<QT, 1, 3, false>(cq1, Bq, 3, 24, sub, 3, q, rbq1, 0);
+      float acc[1] = {0.f}, dummy[1] = {0.f};
+      compute_chunk_kq<QT, 1, 3, false>(cq0, 3, 24, sub, 3, q, 0, act_q + sub * ITEM_LDS, acc, dummy);
+      float v = lanes_sum(acc[0], 3);
+      if (sub == 0) q_s[lr0] = v;
+      acc[0] = 0.f;
+      compute_chunk_kq<QT, 1, 1, false>(ck0, 1, 8, sub, 3, q, 0, act_kv + sub * ITEM_LDS, acc, dummy);
+      v = lanes_sum(acc[0], 3);
+      if (sub == 0) kvb_s[lr0] = v;
+      acc[0] = 0.f;
+      compute_chunk_kq<QT, 1, 1, false>(ck1, 1, 8, sub, 3, q, 0, act_kv + sub * ITEM_LDS, acc, dummy);
+      v = lanes_sum(acc[0], 3);
+      if (sub == 0) kvb_s[lr1] = v;
+      if (wave < 8) {
+        acc[0] = 0.f;
+        compute_chunk_kq<QT, 1, 3, false>(cq1, 3, 24, sub, 3, q, 0, act_q + sub * ITEM_LDS, acc, dummy);
+        v = lanes_sum(acc[0], 3);
+        if (sub == 0) q_s[lr1] = v;
+      }
+    }
+  }
+#endif
+  if (!done_exact) {
+    if (A.has_q) head_rows(A.tq, act_q, A.lq_log2, a.head_dim, q_s);
+    else
+      for (int i = tid; i < a.head_dim; i += 1024) q_s[i] = a.q[(size_t)h * a.head_dim + i];
+    head_rows(A.tkv, act_kv, A.lkv_log2, a.nope + a.v_dim, kvb_s);
+  }
   __syncthreads();
   ad::rope_kv_from_lds<1024>(a, sp, h, tid, q_s, kvb_s, split == 0);
   __syncthreads();  // the rotated q (LDS) and this position's k / v (global, same CU) are read by other threads below
