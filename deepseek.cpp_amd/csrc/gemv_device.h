@@ -711,6 +711,9 @@ DEV void rows_dot_kq(const KQRsrc& B, int items, int sub, int lpr_log2, int q, c
 // 2-step buffers alternate and every bound folds away, so the code is straight-line and hipcc's waitcnt pass counts the
 // loads exactly (vmcnt(N) ladders instead of vmcnt(0)): one buffer is multiplied while the other's loads are in flight.
 // Column steps are consumed in order: same sums, same bits as rows_dot_kq.
+// (A rolling window at single-step granularity - request DEPTH = 4 steps, multiply step u, request step u + 4 in its
+// place - was measured too: slower everywhere (dense w1/w3 21.4 -> 25.3 us, the router launch 10.7 -> 13.1, experts 35.8
+// -> 36.6).  Two-step buffers it is.)
 template <int QT, int R, bool GLU, int ITS, int LL>
 DEV void rows_dot_kq_exact(const KQRsrc& B, int sub, int q, const int (&rowblk)[R], const uint8_t* lds_lane, float (&acc)[R], float (&acc2)[R]) {
   constexpr int ITEMS = ITS << LL;
