@@ -160,6 +160,11 @@ int gemv_launch(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& host);
 
 // The routed experts of one MoE block in ONE launch (kernels_moe.hip): w1/w3 GLU units, per-slot hand-off, W2 units,
 // k-ordered combine.  Planes of the expert stacks + per-expert strides; the shared expert's W2 as a plain matrix.
+#ifndef MOE_CTR_STRIDE
+#define MOE_CTR_STRIDE 64  // words between the slot counters of the fused expert launch: a 256-byte line each (all 8 in one
+                          // line: 35.6 us per launch, apart: 35.2)
+#endif
+#define MOE_CTR_WORDS (16 * MOE_CTR_STRIDE + 16)
 struct MoeFfnArgs {
   int quant;
   const uint8_t *w1_qs, *w1_sc, *w1_hm, *w1_dm, *w3_qs, *w3_sc, *w3_hm, *w3_dm;
@@ -178,7 +183,7 @@ struct MoeFfnArgs {
   float* eout;           // slot outputs [slot][dim]
   float* x;              // residual stream
   int n_experts;         // experts in the stacks (offset range check)
-  unsigned* slot_ctr;    // [K] phase-A arrivals per slot; zeroed by the router launch of the same block
+  unsigned* slot_ctr;    // [K x MOE_CTR_STRIDE] phase-A arrivals per slot; zeroed by the router launch of the same block
   unsigned* err;         // host-visible: set when a bounded spin gives up
   int lprA_log2, lprB_log2;  // lanes per row of the two halves (= the two-launch plans': bit-identical results)
   int UA, rows_wg, lds_a, lds_b, lds_o, grid;  // filled by moe_ffn_plan
@@ -254,6 +259,7 @@ struct RouterArgs {       // F32 router GEMV (+ optional rmsnorm prologue) + moe
   // counters, kernels_moe.hip): their previous users finished before this launch started (stream order)
   unsigned* zero_ctr;
   int zero_n;
+  unsigned long long* timeline;  // debug (DSK_TIMELINE=1): 8 stamps per router workgroup
 };
 int launch_router_gate(hipStream_t st, const RouterArgs& a);
 struct GemvLaunch;
@@ -290,6 +296,7 @@ struct HeadAttnArgs {
   // long contexts: n_split workgroups per head, each over a contiguous share of the cached positions (both
   // redo the head's projections: the other CUs would idle anyway); partial (O, m, l) per (head, split) go to
   // split_part, the LAST split of a head to arrive (split_counter[h]) merges them and finishes the head
+  unsigned long long* timeline;  // debug (DSK_TIMELINE=1): 8 stamps per workgroup
   int n_split;
   float* split_part;        // (H, n_split, v_dim + 2)
   unsigned* split_counter;  // (H), zero between launches
@@ -350,6 +357,7 @@ struct MlaHeadArgs {
   AttnMlaArgs a;          // q_rope (un-rotated), q_c, caches; out unused
   GemvTask twv;           // the (H * v_head_dim, lora) stack; the kernel takes rows [h * v, +v)
   int quant, b0, b1, lpr_log2, lds_act;
+  unsigned long long* timeline;  // debug (DSK_TIMELINE=1): 8 stamps per workgroup
   AttnMhaArgs fin;        // out (H, v), v_dim, n_heads, Q8_K outputs + counter (only these fields are used)
   // long contexts: kv_len >= flash_thresh (> 0) => the attention part is the merge of mla_flash_kernel's partials
   int flash_thresh, fl_chunk_len, fl_n_chunks;

@@ -650,15 +650,15 @@ extern "C" int dsk_model_finalize(dsk_model* m) {
   HIP_TRY(hipMemset(m->att_counter, 0, ((size_t)c.n_heads * c.v_head_dim / 256 + 2) * 4));
   HIP_TRY(hipMalloc((void**)&m->comb_counter, (size_t)c.dim * 4));
   HIP_TRY(hipMemset(m->comb_counter, 0, (size_t)c.dim * 4));
-  HIP_TRY(hipMalloc((void**)&m->moe_ctr, 32 * 4));
-  HIP_TRY(hipMemset(m->moe_ctr, 0, 32 * 4));
+  HIP_TRY(hipMalloc((void**)&m->moe_ctr, MOE_CTR_WORDS * 4));
+  HIP_TRY(hipMemset(m->moe_ctr, 0, MOE_CTR_WORDS * 4));
   HIP_TRY(hipHostMalloc((void**)&m->err_host, 64, hipHostMallocDefault));
   memset(m->err_host, 0, 64);
   m->fuse_moe = getenv("DSK_NO_FUSE_MOE") == nullptr;
   m->att_q8_in_wo = getenv("DSK_ATT_Q8_IN_WO") != nullptr && atoi(getenv("DSK_ATT_Q8_IN_WO")) != 0;
-  if (getenv("DSK_MOE_TIMELINE")) {
-    HIP_TRY(hipMalloc((void**)&m->moe_timeline, 1024 * 8 * 8));
-    HIP_TRY(hipMemset(m->moe_timeline, 0, 1024 * 8 * 8));
+  if (getenv("DSK_MOE_TIMELINE") || getenv("DSK_TIMELINE")) {
+    HIP_TRY(hipMalloc((void**)&m->moe_timeline, 8 * 1024 * 8 * 8));
+    HIP_TRY(hipMemset(m->moe_timeline, 0, 8 * 1024 * 8 * 8));
   }
   m->ride_shared = getenv("DSK_NO_FUSE_SHARED") == nullptr;    // A/B and test knobs: the ride-along launches can be
   m->ride_kvwrite = getenv("DSK_NO_KVWRITE_RIDE") == nullptr;  // switched back to separate launches per model

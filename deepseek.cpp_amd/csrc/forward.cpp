@@ -164,6 +164,7 @@ int build_plans(dsk_model* m) {
       task_act_norm(b, m->x, L.t[DSK_ROLE_ATTN_NORM], c.norm_eps);
       b.out = m->kv_a;
       h.algo_bytes = weight_bytes_2d(m, wq, a.rows, a.n) + weight_bytes_2d(m, wq, b.rows, b.n) + c.dim * 8.0 + 4.0 * (a.rows + b.rows);
+      h.timeline = m->timeline_of(0);
       DSK_TRY(add_plan(m, h, &m->lp_qkv_a[l]));
     }
     {  // 2. second-stage projections on the normed latents
@@ -192,6 +193,7 @@ int build_plans(dsk_model* m) {
         memset(&A, 0, sizeof A);
         A.quant = wq; A.b0 = std::max(1, c.block_size[0]); A.b1 = std::max(1, c.block_size[1]);
         A.has_q = c.q_lora_rank > 0;
+        A.timeline = m->timeline_of(1);
         const GemvLaunch& P = m->plans[m->lp_qkv_b[l]];
         if (A.has_q) { A.tq = P.t[0]; A.tkv = P.t[1]; }
         else A.tkv = P.t[0];
@@ -224,6 +226,7 @@ int build_plans(dsk_model* m) {
       memset(&A, 0, sizeof A);
       A.quant = wq; A.b0 = std::max(1, c.block_size[0]); A.b1 = std::max(1, c.block_size[1]);
       A.twv = m->plans[m->lp_wv_b[l]].t[0];
+      A.timeline = m->timeline_of(1);
       A.a.q_rope = m->q_rope; A.a.q_c = m->q_c; A.a.kv_a = m->kv_a; A.a.nope_cache = L.nope_cache; A.a.rope_cache = L.rope_cache;
       A.a.out = m->att_out; A.a.n_heads = H; A.a.head_dim = m->head_dim; A.a.rope = c.qk_rope_head_dim; A.a.lora = c.kv_lora_rank;
       A.a.is_v3 = c.has_moegate_bias;
@@ -254,6 +257,7 @@ int build_plans(dsk_model* m) {
       else task_act_f32(T, src);
       T.out = m->x; T.epilogue = EPI_ADD;
       h.algo_bytes = weight_bytes_2d(m, wq, T.rows, T.n) + io_bytes(wq, T.n, T.rows) + 4.0 * T.rows;
+      h.timeline = m->timeline_of(2);
       DSK_TRY(add_plan(m, h, &m->lp_wo[l]));
     }
     if (!L.is_moe) {
@@ -322,6 +326,7 @@ int build_plans(dsk_model* m) {
         GemvLaunch trial = hs;
         trial.b0 = std::max(1, c.block_size[0]); trial.b1 = std::max(1, c.block_size[1]); trial.act = c.act;
         if (gemv_plan(trial, m->target_wgs) == DSK_OK && router_shared_supported(probe, trial)) {
+          hs.timeline = m->timeline_of(3);
           DSK_TRY(add_plan(m, hs, &m->lp_sh13[l]));
           ride = true;
         }
@@ -385,7 +390,7 @@ int build_plans(dsk_model* m) {
       a.slot_ctr = m->moe_ctr;
       a.n_experts = c.n_routed_experts;
       a.err = m->err_host;
-      a.timeline = m->moe_timeline;
+      a.timeline = m->timeline_of(4);
       a.lprA_log2 = m->plans[m->lp_w13[l]].lpr_log2;
       a.lprB_log2 = m->plans[m->lp_w2[l]].lpr_log2;
       a.algo_bytes = m->plans[m->lp_w13[l]].algo_bytes + m->plans[m->lp_w2[l]].algo_bytes;
@@ -533,6 +538,7 @@ static int ffn(dsk_model* m, int l) {
   r.x = m->x;
   r.norm_w = reinterpret_cast<const float*>(L.t[DSK_ROLE_FFN_NORM].qs);
   r.eps = c.norm_eps;
+  r.timeline = m->timeline_of(5);
   r.n_routed = E; r.dim = c.dim; r.ksplit = m->router_ksplit;
   r.partial = m->router_partial; r.counter = m->router_counter;
   r.bias = L.t[DSK_ROLE_MOEGATE_BIAS].bound() ? reinterpret_cast<const float*>(L.t[DSK_ROLE_MOEGATE_BIAS].qs) : nullptr;
@@ -567,7 +573,7 @@ static int ffn(dsk_model* m, int l) {
       DSK_TRY(prof_begin(m, "moe_ffn", a.algo_bytes, &p));
       if (!p.skip) {
         // class timing enqueues this class alone: no router launch in front re-arms the slot counters
-        if (m->class_filter) HIP_TRY(hipMemsetAsync(m->moe_ctr, 0, 32 * 4, st));
+        if (m->class_filter) HIP_TRY(hipMemsetAsync(m->moe_ctr, 0, MOE_CTR_WORDS * 4, st));
         DSK_TRY(launch_moe_ffn(st, a, nullptr, nullptr));
       }
       DSK_TRY(prof_end(&p));
@@ -668,7 +674,7 @@ static int run_token(dsk_model* m, int token, int pos, int mode) {
   HIP_TRY(hipGetLastError());
   if (m->err_host && *m->err_host) {  // a bounded in-kernel spin gave up (kernels_moe.hip): the step's results are invalid
     *m->err_host = 0;
-    hipMemset(m->moe_ctr, 0, 32 * 4);  // the arrival counters are in an unknown state: re-arm them
+    hipMemset(m->moe_ctr, 0, MOE_CTR_WORDS * 4);  // the arrival counters are in an unknown state: re-arm them
     hipMemset(m->comb_counter, 0, (size_t)m->c.dim * 4);
     DSK_FAIL(DSK_ERR_HIP, "forward: an in-kernel hand-off timed out");
   }
@@ -1007,10 +1013,11 @@ extern "C" int dsk_model_get_stage(dsk_model* m, const char* name, void* out, si
 }
 
 // debug: the 8 wall-clock stamps (100 MHz) per workgroup of the last fused expert launch (DSK_MOE_TIMELINE=1 at model creation)
-extern "C" int dsk_model_get_moe_timeline(dsk_model* m, unsigned long long* out, int n_wgs) {
-  if (!m || !out || n_wgs < 1 || n_wgs > 1024) DSK_FAIL(DSK_ERR_INVALID, "get_moe_timeline: bad argument");
-  if (!m->moe_timeline) DSK_FAIL(DSK_ERR_STATE, "get_moe_timeline: set DSK_MOE_TIMELINE=1 before creating the model");
+extern "C" int dsk_model_get_timeline(dsk_model* m, int kind, unsigned long long* out, int n_wgs) {
+  if (!m || !out || n_wgs < 1 || n_wgs > 1024 || kind < 0 || kind > 7) DSK_FAIL(DSK_ERR_INVALID, "get_timeline: bad argument");
+  if (!m->moe_timeline) DSK_FAIL(DSK_ERR_STATE, "get_timeline: set DSK_TIMELINE=1 before creating the model");
   HIP_TRY(hipSetDevice(m->ctx->device));
-  HIP_TRY(hipMemcpy(out, m->moe_timeline, (size_t)n_wgs * 64, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out, m->timeline_of(kind), (size_t)n_wgs * 64, hipMemcpyDeviceToHost));
   return DSK_OK;
 }
+extern "C" int dsk_model_get_moe_timeline(dsk_model* m, unsigned long long* out, int n_wgs) { return dsk_model_get_timeline(m, 4, out, n_wgs); }

@@ -202,6 +202,14 @@ DEV void q8k_block_lds(const float (&v)[4], int lane, uint8_t* blk) {
   q8k_round_lds<Q2META>(v, vmax, lane, blk);
 }
 
+// workgroup barrier for LDS traffic only: unlike __syncthreads() (a fence: s_waitcnt vmcnt(0) first) it leaves this wave's
+// global loads in flight -- the weight chunk requested ahead of the staging prologue keeps streaming across it
+DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// orders the workgroup's REQUESTS only (no wait for any data): what was requested before it by any wave is queued in the
+// CU's L1 ahead of what any wave requests after it
+DEV void issue_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
 DEV float wave_sum(float v) {  // fixed order: quads, rows of 16, then the four rows
   v += dpp_f32<DPP_XOR1>(v);
   v += dpp_f32<DPP_XOR2>(v);

@@ -292,52 +292,53 @@ __global__ __launch_bounds__(1024) void head_attn_kernel(const HeadAttnArgs A, c
   const int S = A.n_split;  // workgroups per head (1: the whole context here)
   const int h = S > 1 ? (int)blockIdx.x / S : (int)blockIdx.x, split = S > 1 ? (int)blockIdx.x - h * S : 0;
   const AttnMhaArgs& a = A.a;
+  unsigned long long* tl = A.timeline ? A.timeline + (size_t)blockIdx.x * 8 : nullptr;
+  if (tl && tid == 0) tl[0] = wall_clock64();
   uint8_t* act_q = smem;
   uint8_t* act_kv = smem + A.lds_q;
   float* att = reinterpret_cast<float*>(smem + A.lds_q + A.lds_kv);
   const int nbq = A.has_q ? A.tq.n >> 8 : 0, nbkv = A.tkv.n >> 8;
-  if (KQ && nbq + nbkv <= NW && A.tkv.act_mode == ACT_F32_NORM && (!A.has_q || A.tq.act_mode == ACT_F32_NORM)) {
-    // both latents (q_a: 6 blocks, kv_a: 2 blocks for DeepSeek-V3) normed + quantised in ONE pass: wave w owns
-    // block w of the concatenation; two sums of squares share one barrier (src/infer.cpp:601-611, quant.cpp:616-653)
-    const bool mine = wave < nbq + nbkv, is_q = wave < nbq;
-    const GemvTask& T = is_q ? A.tq : A.tkv;
-    const int b = is_q ? wave : wave - nbq;
-    f32x4 t = {0.f, 0.f, 0.f, 0.f}, wv = {0.f, 0.f, 0.f, 0.f};
-    if (mine) {
-      t = *reinterpret_cast<const f32x4*>(T.a_f32 + b * 256 + lane * 4);
-      wv = *reinterpret_cast<const f32x4*>(T.norm_w + b * 256 + lane * 4);
+  const bool one_pass = KQ && nbq + nbkv <= NW && A.tkv.act_mode == ACT_F32_NORM && (!A.has_q || A.tq.act_mode == ACT_F32_NORM);
+  auto tap_staged = [&]() {
+#ifndef DSK_NO_TAPS
+    if constexpr (KQ) {
+      if (A.tap_qs && blockIdx.x == 0) {  // parity tap
+        if (A.has_q) dump_staged_q8<QT == DSK_QUANT_Q2_K>(act_q, A.tq.n, A.tap_qs, A.tap_d, tid, 1024);
+        dump_staged_q8<QT == DSK_QUANT_Q2_K>(act_kv, A.tkv.n, A.tap_qs + A.tap_stride, A.tap_d + (A.tap_stride >> 8), tid, 1024);
+      }
     }
+#endif
+  };
+  // both latents (q_a: 6 blocks, kv_a: 2 blocks for DeepSeek-V3) normed + quantised in ONE pass: wave w owns block w of
+  // the concatenation; two sums of squares share one barrier (src/infer.cpp:601-611, quant.cpp:616-653).  Branch-free
+  // loads (waves without a block re-read block 0 and drop it), LDS-only barriers.
+  struct Latent { f32x4 t, wv; bool mine, is_q; int b; };
+  auto latent_request = [&]() {
+    Latent Z;
+    Z.mine = wave < nbq + nbkv; Z.is_q = wave < nbq;
+    const GemvTask& T = Z.is_q ? A.tq : A.tkv;
+    Z.b = Z.mine ? (Z.is_q ? wave : wave - nbq) : 0;
+    Z.t = *reinterpret_cast<const f32x4*>(T.a_f32 + Z.b * 256 + lane * 4);
+    Z.wv = *reinterpret_cast<const f32x4*>(T.norm_w + Z.b * 256 + lane * 4);
+    return Z;
+  };
+  auto latent_finish = [&](const Latent& Z) {
+    const GemvTask& T = Z.is_q ? A.tq : A.tkv;
+    const f32x4 t = Z.t, wv = Z.wv;
     float ss = fmaf(t.x, t.x, fmaf(t.y, t.y, fmaf(t.z, t.z, t.w * t.w)));
     ss = wave_sum(ss);
-    if (lane == 0) scratch[wave] = mine ? ss : 0.f;
-    __syncthreads();
+    if (lane == 0) scratch[wave] = Z.mine ? ss : 0.f;
+    lds_barrier();
     float total = 0.f;
-    if (is_q) for (int i = 0; i < nbq; ++i) total += scratch[i];
+    if (Z.is_q) for (int i = 0; i < nbq; ++i) total += scratch[i];
     else for (int i = nbq; i < nbq + nbkv; ++i) total += scratch[i];
-    if (mine) {
+    if (Z.mine) {
       const float scale = 1.0f / sqrtf(total / (float)T.n + T.eps);
       float v[4] = {t.x * scale * wv.x, t.y * scale * wv.y, t.z * scale * wv.z, t.w * scale * wv.w};
-      q8k_block_lds<QT == DSK_QUANT_Q2_K>(v, lane, (is_q ? act_q : act_kv) + (size_t)b * 4 * ITEM_LDS);
+      q8k_block_lds<QT == DSK_QUANT_Q2_K>(v, lane, (Z.is_q ? act_q : act_kv) + (size_t)Z.b * 4 * ITEM_LDS);
     }
-  } else {
-    if (A.has_q) {
-      if (KQ) stage_q8<QT == DSK_QUANT_Q2_K, NW>(A.tq, act_q, tid, scratch);
-      else stage_f32<NW>(A.tq, reinterpret_cast<float*>(act_q), tid, scratch);
-      __syncthreads();  // scratch is reused by the second staging
-    }
-    if (KQ) stage_q8<QT == DSK_QUANT_Q2_K, NW>(A.tkv, act_kv, tid, scratch);
-    else stage_f32<NW>(A.tkv, reinterpret_cast<float*>(act_kv), tid, scratch);
-  }
-  __syncthreads();
-#ifndef DSK_NO_TAPS
-  if constexpr (KQ) {
-    if (A.tap_qs && blockIdx.x == 0) {  // parity tap
-      if (A.has_q) dump_staged_q8<QT == DSK_QUANT_Q2_K>(act_q, A.tq.n, A.tap_qs, A.tap_d, tid, 1024);
-      dump_staged_q8<QT == DSK_QUANT_Q2_K>(act_kv, A.tkv.n, A.tap_qs + A.tap_stride, A.tap_d + (A.tap_stride >> 8), tid, 1024);
-    }
-  }
-#endif
-
+    lds_barrier();
+  };
   // head h's rows of one projection: 64/LPR rows per wave and step.  (Dealing both projections' rows to the
   // waves as one unit list, or 2 row sets per lane, measured slower: this stage is VALU-bound on its one CU.)
   auto head_rows = [&](const GemvTask& T, const uint8_t* act, int lpr_log2, int nrows, float* out_lds) {
@@ -360,17 +361,25 @@ __global__ __launch_bounds__(1024) void head_attn_kernel(const HeadAttnArgs A, c
       if (sub == 0 && valid) out_lds[lr] = acc[0];
     }
   };
-  bool done_exact = false;
+  bool exact = false;
 #if HEAD_EXACT
   if constexpr (QT == DSK_QUANT_Q2_K) {
     // DeepSeek-V3 shapes (192 q rows of 1536, 256 kv rows of 512, 8 lanes per row: 3 and 1 column steps, all known at
     // compile time): every wave requests ALL its rows of both projections at once - q rows w*8.., kv rows w*8.. and
-    // 128 + w*8.., and for waves 0-7 q rows 128 + w*8.. - and multiplies them as they arrive (straight-line code: hipcc
-    // counts the loads exactly), instead of four dependent load -> wait -> multiply round trips.  Same lanes per row and
-    // column order as head_rows: same bits.
-    if (A.has_q && A.lq_log2 == 3 && A.lkv_log2 == 3 && A.tq.n == 1536 && A.tkv.n == 512 && a.head_dim == 192 && a.nope + a.v_dim == 256) {
-      done_exact = true;
+    // 128 + w*8.., and for waves 0-7 q rows 128 + w*8.. - and multiplies them as they arrive, instead of four dependent
+    // load -> wait -> multiply round trips.  Straight-line code: hipcc counts the outstanding loads exactly (vmcnt(N) ladders).  Same
+    // lanes per row and column order as head_rows: same bits.
+    exact = one_pass && A.has_q && A.lq_log2 == 3 && A.lkv_log2 == 3 && A.tq.n == 1536 && A.tkv.n == 512 && a.head_dim == 192 && a.nope + a.v_dim == 256;
+    if (exact) {
       const int rloc = lane >> 3, sub = lane & 7, q = sub & 3;
+      // (Requesting the weights BEFORE the latents are normed and quantised - right after the latents' loads, or after
+      // they have arrived - was measured: the prologue then ends at 6.0 us instead of 1.9 and the launch takes 15.2 us
+      // instead of 12.9.  A wave cannot run ahead of its own requests: issue stalls once the CU's ~48 KB of reads in
+      // flight are taken, so the norm / quantise math waits until most of the 140 KB have arrived and the multiplies,
+      // which need the staged latents, start late.  Small launches are bound by that per-CU window, not by latency.)
+      latent_finish(latent_request());
+      tap_staged();
+      if (tl && tid == 0) tl[1] = wall_clock64();
       const KQRsrc Bq = kq_rsrc<QT, false>(resolve(A.tq)), Bk = kq_rsrc<QT, false>(resolve(A.tkv));
       const int lr0 = wave * 8 + rloc, lr1 = 128 + lr0;
       const int rbq0[1] = {(h * 192 + lr0) * 6 + (sub >> 2)}, rbq1[1] = {(h * 192 + (lr1 < 192 ? lr1 : 191)) * 6 + (sub >> 2)};
@@ -393,7 +402,7 @@ __global__ __launch_bounds__(1024) void head_attn_kernel(const HeadAttnArgs A, c
       compute_chunk_kq<QT, 1, 1, false>(ck1, 1, 8, sub, 3, q, 0, act_kv + sub * ITEM_LDS, acc, dummy);
       v = lanes_sum(acc[0], 3);
       if (sub == 0) kvb_s[lr1] = v;
-      if (wave < 8) {
+      if (wave < 8) {  // (a zero-record descriptor instead of this branch, every wave multiplying 8 steps: rows 5.4 -> 6.4 us, VALU-bound)
         acc[0] = 0.f;
         compute_chunk_kq<QT, 1, 3, false>(cq1, 3, 24, sub, 3, q, 0, act_q + sub * ITEM_LDS, acc, dummy);
         v = lanes_sum(acc[0], 3);
@@ -402,18 +411,36 @@ __global__ __launch_bounds__(1024) void head_attn_kernel(const HeadAttnArgs A, c
     }
   }
 #endif
-  if (!done_exact) {
+  if (!exact) {
+    if (one_pass) {
+      latent_finish(latent_request());
+    } else {
+      if (A.has_q) {
+        if (KQ) stage_q8<QT == DSK_QUANT_Q2_K, NW>(A.tq, act_q, tid, scratch);
+        else stage_f32<NW>(A.tq, reinterpret_cast<float*>(act_q), tid, scratch);
+        __syncthreads();  // scratch is reused by the second staging
+      }
+      if (KQ) stage_q8<QT == DSK_QUANT_Q2_K, NW>(A.tkv, act_kv, tid, scratch);
+      else stage_f32<NW>(A.tkv, reinterpret_cast<float*>(act_kv), tid, scratch);
+      __syncthreads();
+    }
+    tap_staged();
+    if (tl && tid == 0) tl[1] = wall_clock64();
     if (A.has_q) head_rows(A.tq, act_q, A.lq_log2, a.head_dim, q_s);
     else
       for (int i = tid; i < a.head_dim; i += 1024) q_s[i] = a.q[(size_t)h * a.head_dim + i];
     head_rows(A.tkv, act_kv, A.lkv_log2, a.nope + a.v_dim, kvb_s);
   }
   __syncthreads();
+  if (tl && tid == 0) tl[2] = wall_clock64();
   ad::rope_kv_from_lds<1024>(a, sp, h, tid, q_s, kvb_s, split == 0);
   __syncthreads();  // the rotated q (LDS) and this position's k / v (global, same CU) are read by other threads below
+  if (tl && tid == 0) tl[3] = wall_clock64();
   if (S <= 1) {
     const float o = ad::attn_mha_body<1024>(a, q_s, 0, sp->kv_len, h, tid, att, scratch, part);
+    if (tl && tid == 0) tl[4] = wall_clock64();
     ad::attn_out_q8(a, h, tid, o, &last_flag);
+    if (tl && tid == 0) tl[5] = wall_clock64();
     return;
   }
   // ---- split context: this workgroup's share of the positions (every split wrote the same k / v row above)

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(1024) void moe_ffn_kernel(const MoeFfnArgs a) {
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the arrival
       __syncthreads();
-      if (tid == 0) __hip_atomic_fetch_add(a.slot_ctr + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) __hip_atomic_fetch_add(a.slot_ctr + s * MOE_CTR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 
@@ -156,34 +156,31 @@ __global__ __launch_bounds__(1024) void moe_ffn_kernel(const MoeFfnArgs a) {
       return J;
     };
     const int n_jobs = nrows > 0 ? JR + JS : 0;
-    // the first job's weights are requested BEFORE the hand-off: they stream while the slots' producers finish
-    ChunkKQ<QT, 1, UB, false> c0, c1;
-    Job J = make_job(wave < n_jobs ? wave : 0);
-    if (wave < n_jobs) {
-      load_chunk_kq<QT, 1, UB, false>(c0, J.shared ? BS : BR, J.its, J.n_items, sub, lpr_log2, sub & 3, J.rowblk[0], 0);
-      load_chunk_kq<QT, 1, UB, false>(c1, J.shared ? BS : BR, J.its, J.n_items, sub, lpr_log2, sub & 3, J.rowblk[1], 0);
-    }
     float xv = 0.f;
     if (tid < nrows) xv = a.x[r_lo + tid];
     // wait until every phase-A unit of every slot has published its rows (lane k of wave 0 watches slot k)
-    if (wave == 0) {
-      unsigned spins = 0;
-      for (;;) {
-        const bool ok = lane >= K || __hip_atomic_load(a.slot_ctr + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)a.UA;
-        if (__all(ok)) break;
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1u << 20)) { if (lane == 0) *a.err = 1u; break; }
+    auto wait_slots = [&]() {
+      if (wave == 0) {
+        unsigned spins = 0;
+        for (;;) {
+          const bool ok = lane >= K || __hip_atomic_load(a.slot_ctr + lane * MOE_CTR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)a.UA;
+          if (__all(ok)) break;
+          __builtin_amdgcn_s_sleep(1);  // (8 or 32, or ONE counter for all slots: no difference in the time to pass)
+          if (++spins > (1u << 20)) { if (lane == 0) *a.err = 1u; break; }
+        }
       }
-    }
-    __syncthreads();
-    if (tl && tid == 0) tl[3] = wall_clock64();
-    // stage the hidden vectors: 16-byte sc1 loads (written by other CUs during THIS launch: served by L2 / memory, never
-    // by this CU's L1), all of a wave's blocks requested before the first is quantised (one memory round trip, not one
-    // per block); Q8_K per 256-block (quantize_row_q8_K_ref)
-    {
+      __syncthreads();
+      if (tl && tid == 0) tl[3] = wall_clock64();
+    };
+    // stage the hidden vectors: 16-byte loads that bypass this CU's L1 (written by other CUs during THIS launch), all of
+    // a wave's blocks requested before the first is quantised (one memory round trip, not one per block); Q8_K per
+    // 256-block (quantize_row_q8_K_ref).  `more` runs between the requests and the quantisation: further weight requests
+    // queue up behind the hidden vectors' and stream while the blocks are quantised.
+    auto stage_hidden = [&](auto&& more) {
       const int nblk = K * nbR + nbS;
       const rsrc_t hr = make_rsrc(a.hb);
       constexpr int SB = 5;
+      constexpr int HAUX = 16;  // sc1
       for (int b0 = wave; b0 < nblk; b0 += NW * SB) {
         u32x4 hv[SB];
 #pragma unroll
@@ -191,9 +188,10 @@ __global__ __launch_bounds__(1024) void moe_ffn_kernel(const MoeFfnArgs a) {
           const int b = b0 + k * NW;
           if (b < nblk) {
             const int s = b < K * nbR ? b / nbR : K, bb = b < K * nbR ? b - s * nbR : b - K * nbR;
-            hv[k] = __builtin_amdgcn_raw_buffer_load_b128(hr, (s * a.hb_stride + bb * 256 + lane * 4) * 4, 0, 16 /* sc1 */);
+            hv[k] = __builtin_amdgcn_raw_buffer_load_b128(hr, (s * a.hb_stride + bb * 256 + lane * 4) * 4, 0, HAUX);
           }
         }
+        if (b0 == wave) more();
 #pragma unroll
         for (int k = 0; k < SB; ++k) {
           const int b = b0 + k * NW;
@@ -205,35 +203,53 @@ __global__ __launch_bounds__(1024) void moe_ffn_kernel(const MoeFfnArgs a) {
           }
         }
       }
-    }
-    __syncthreads();
-    if (tl && tid == 0) tl[4] = wall_clock64();
-    if (a.tap_qs && bid == 0)  // parity tap: what the slots staged
-      for (int s = 0; s < slots; ++s)
-        dump_staged_q8<Q2>(actB + (size_t)s * a.lds_b, s < K ? a.mi : a.shared_n, a.tap_qs + (size_t)s * a.tap_stride,
-                           a.tap_d + (size_t)s * (a.tap_stride >> 8), tid, 1024);
-    for (int j = wave; j < n_jobs; j += NW) {
-      if (j != wave) {
-        J = make_job(j);
-        load_chunk_kq<QT, 1, UB, false>(c0, J.shared ? BS : BR, J.its, J.n_items, sub, lpr_log2, sub & 3, J.rowblk[0], 0);
-        load_chunk_kq<QT, 1, UB, false>(c1, J.shared ? BS : BR, J.its, J.n_items, sub, lpr_log2, sub & 3, J.rowblk[1], 0);
-      }
-      const KQRsrc& B = J.shared ? BS : BR;
-      float acc0[1] = {0.f}, acc1[1] = {0.f}, dummy[1] = {0.f};
-      const uint8_t* l0 = actB + (size_t)J.slot[0] * a.lds_b + sub * ITEM_LDS;
-      const uint8_t* l1 = actB + (size_t)J.slot[1] * a.lds_b + sub * ITEM_LDS;
-      for (int it0 = 0; it0 < J.its; it0 += UB) {
-        if (it0 > 0) {
-          load_chunk_kq<QT, 1, UB, false>(c0, B, J.its, J.n_items, sub, lpr_log2, sub & 3, J.rowblk[0], it0);
-          load_chunk_kq<QT, 1, UB, false>(c1, B, J.its, J.n_items, sub, lpr_log2, sub & 3, J.rowblk[1], it0);
-        }
-        compute_chunk_kq<QT, 1, UB, false>(c0, J.its, J.n_items, sub, lpr_log2, sub & 3, it0, l0, acc0, dummy);
-        compute_chunk_kq<QT, 1, UB, false>(c1, J.its, J.n_items, sub, lpr_log2, sub & 3, it0, l1, acc1, dummy);
-      }
-      const float o0 = lanes_sum(acc0[0], lpr_log2), o1 = lanes_sum(acc1[0], lpr_log2);
+      __syncthreads();
+      if (tl && tid == 0) tl[4] = wall_clock64();
+      if (a.tap_qs && bid == 0)  // parity tap: what the slots staged
+        for (int s = 0; s < slots; ++s)
+          dump_staged_q8<Q2>(actB + (size_t)s * a.lds_b, s < K ? a.mi : a.shared_n, a.tap_qs + (size_t)s * a.tap_stride,
+                             a.tap_d + (size_t)s * (a.tap_stride >> 8), tid, 1024);
+    };
+    auto finish_job = [&](const Job& J, float o0, float o1) {
       if (sub == 0) {
         if (J.valid[0]) { o_s[J.slot[0] * nrows_max + J.rr[0]] = o0; a.eout[(size_t)J.slot[0] * a.dim + r_lo + J.rr[0]] = o0; }
         if (J.valid[1]) { o_s[J.slot[1] * nrows_max + J.rr[1]] = o1; a.eout[(size_t)J.slot[1] * a.dim + r_lo + J.rr[1]] = o1; }
+      }
+    };
+    {
+      // (All of the workgroup's W2 rows in registers before the hand-off / right behind the hidden vectors' requests - two
+      // jobs per wave as four 2-step chunks - was measured: 36.1 us against 35.7; so was reading the hidden vectors with
+      // plain loads after an agent acquire, so that an XCD's L2 serves its 32 workgroups: 36.2.  From the end of phase A
+      // to the exit this launch moves its 61 MB (W2 + 256 copies of the hidden vectors) at the same ~18 GB/s per CU as
+      // phase A moves the w1/w3 rows: it is bound by what a CU can keep in flight, not by the order of its requests.)
+      // the first job's weights are requested BEFORE the hand-off: they stream while the slots' producers finish
+      ChunkKQ<QT, 1, UB, false> c0, c1;
+      Job J = make_job(wave < n_jobs ? wave : 0);
+      if (wave < n_jobs) {
+        load_chunk_kq<QT, 1, UB, false>(c0, J.shared ? BS : BR, J.its, J.n_items, sub, lpr_log2, sub & 3, J.rowblk[0], 0);
+        load_chunk_kq<QT, 1, UB, false>(c1, J.shared ? BS : BR, J.its, J.n_items, sub, lpr_log2, sub & 3, J.rowblk[1], 0);
+      }
+      wait_slots();
+      stage_hidden([]() {});
+      for (int j = wave; j < n_jobs; j += NW) {
+        if (j != wave) {
+          J = make_job(j);
+          load_chunk_kq<QT, 1, UB, false>(c0, J.shared ? BS : BR, J.its, J.n_items, sub, lpr_log2, sub & 3, J.rowblk[0], 0);
+          load_chunk_kq<QT, 1, UB, false>(c1, J.shared ? BS : BR, J.its, J.n_items, sub, lpr_log2, sub & 3, J.rowblk[1], 0);
+        }
+        const KQRsrc& B = J.shared ? BS : BR;
+        float acc0[1] = {0.f}, acc1[1] = {0.f}, dummy[1] = {0.f};
+        const uint8_t* l0 = actB + (size_t)J.slot[0] * a.lds_b + sub * ITEM_LDS;
+        const uint8_t* l1 = actB + (size_t)J.slot[1] * a.lds_b + sub * ITEM_LDS;
+        for (int it0 = 0; it0 < J.its; it0 += UB) {
+          if (it0 > 0) {
+            load_chunk_kq<QT, 1, UB, false>(c0, B, J.its, J.n_items, sub, lpr_log2, sub & 3, J.rowblk[0], it0);
+            load_chunk_kq<QT, 1, UB, false>(c1, B, J.its, J.n_items, sub, lpr_log2, sub & 3, J.rowblk[1], it0);
+          }
+          compute_chunk_kq<QT, 1, UB, false>(c0, J.its, J.n_items, sub, lpr_log2, sub & 3, it0, l0, acc0, dummy);
+          compute_chunk_kq<QT, 1, UB, false>(c1, J.its, J.n_items, sub, lpr_log2, sub & 3, it0, l1, acc1, dummy);
+        }
+        finish_job(J, lanes_sum(acc0[0], lpr_log2), lanes_sum(acc1[0], lpr_log2));
       }
     }
     __syncthreads();

@@ -194,7 +194,10 @@ RDEV void router_body(const RouterArgs& a, int bid, int nblocks) {
   const int r = wave % RW, sl = wave / RW;
   const int row = bid * RW + r;
   const int dim = a.dim, E = a.n_routed;
+  unsigned long long* tl = a.timeline ? a.timeline + (size_t)bid * 8 : nullptr;
+  if (tl && tid == 0) tl[0] = wall_clock64();
   const float scale = a.norm_w && !(a.dbg & 4) ? router_norm_scale(a, tid, scratch) : 1.0f;
+  if (tl && tid == 0) tl[1] = wall_clock64();
   float acc = 0.f;
   if (row < E && !(a.dbg & 2)) {
     const int chunk = ((dim / 4 + SL - 1) / SL + 63) / 64 * 64 * 4;  // floats per column slice, multiple of 256
@@ -243,6 +246,7 @@ RDEV void router_body(const RouterArgs& a, int bid, int nblocks) {
     // write-through (sc1) store: visible across XCDs once vmcnt drains, no L2 write-back fence needed
     __hip_atomic_store(a.partial + bid * RW + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (tl && tid == 0) tl[2] = wall_clock64();
   // ---- publish the scores; the last workgroup to arrive runs the gate ----
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -252,14 +256,16 @@ RDEV void router_body(const RouterArgs& a, int bid, int nblocks) {
     if (is_last) FINISHER_ACQUIRE();
   }
   __syncthreads();
+  if (tl && tid == 0) tl[3] = wall_clock64();
   if (!is_last) return;
   if (a.dbg & 1) { if (tid == 0) *a.counter = 0; return; }
   if (tid == 0) __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
-  if (a.zero_ctr && tid < a.zero_n) __hip_atomic_store(a.zero_ctr + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (a.zero_ctr && tid < a.zero_n) __hip_atomic_store(a.zero_ctr + tid * MOE_CTR_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   float v = 0.f;
   if (tid < E) v = __hip_atomic_load(a.partial + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   gate_body(tid, v, a.bias, E, a.n_active, a.norm_topk_prob, a.scaling, a.scoring, a.topk_method, a.n_group, a.topk_group,
             a.active_experts, a.active_weights, a.scores_out, s, surv, sel, scratch, 1024);
+  if (tl && tid == 0) tl[4] = wall_clock64();
 }
 // MLA model path, the work of ONE small workgroup: rmsnorm of the latent (src/infer.cpp:1089), f16 cache entries of
 // this position (:1092-1097), rotation of the sink keys (:1103-1110).  Runs either as mla_kv_write_kernel (256 threads)
