@@ -931,12 +931,21 @@ int gemv_plan(GemvLaunch& h, int target_wgs) {
   // (K-quants need an exact fit: a lane's quarter must not change between column steps.  The float paths mask a
   // ragged last step, so they take the widest lane group that wastes <= 1/8 of its slots: V2-Lite's 10944-wide
   // F8 rows are 684 items = 4 x 171 -- 4 lanes per row would leave 32 workgroups for the whole matrix.)
+  // Small plain launches (the first-stage projections: 2112 rows of 7168 = 112 items) are bound by the serial work of a
+  // wave, not by bytes: 64 lanes per row with a ragged second step (1/8 of the lane slots idle) give every wave of a
+  // workgroup one row and two column steps instead of four waves four rows and seven steps each (tools/kbench.py sweep:
+  // wq_a 8.3 -> 6.5 us, wkv_a 8.0 -> 5.9 us; in the model 7.9 -> 7.15 us).  GLU launches keep the exact fit: the shared
+  // expert's rider must produce the bits of the expert-sharded arrangement, where it is the ninth task of the experts'
+  // launch.  (Requesting such a launch's one row group AHEAD of its prologue was measured too: the request needs the
+  // launch descriptor, a cold 1.5 us read that otherwise hides under the staging of x, which the kernel arguments
+  // describe - staged at 4.8 us instead of 2.9, the launch 8.3 us instead of 7.15.)
+  const bool small_plain = kq && !h.glu && !cg && h.bd_heads <= 0 && total_rows <= 4096;
   int lpr = 64;
   while (lpr > 1) {
     bool ok = true;
     for (int i = 0; i < h.n_tasks; ++i) {
       const int items = h.t[i].n / epi;
-      if (kq) ok = ok && (items % lpr == 0 || (lpr >= 32 && (items + lpr - 1) / lpr * lpr * 8 <= items * 9));
+      if (kq) ok = ok && (items % lpr == 0 || (lpr >= 32 && (items + lpr - 1) / lpr * lpr * (small_plain ? 7 : 8) <= items * (small_plain ? 8 : 9)));
       else ok = ok && ((items + lpr - 1) / lpr * lpr * 8 <= items * 9);
     }
     if (ok) break;

@@ -27,6 +27,7 @@ V3 = [
     ("wkv_b 32768x512", 32768, 512, 1, 0, 2),
     ("wq_a 1536x7168", 1536, 7168, 1, 0, 2),
     ("wkv_a 576x7168", 576, 7168, 1, 0, 2),
+    ("shared_w13 (2048x7168)x2", 2048, 7168, 1, 1, 2),
 ]
 
 
