@@ -221,7 +221,9 @@ __global__ __launch_bounds__(1024) void moe_ffn_kernel(const MoeFfnArgs a) {
       // jobs per wave as four 2-step chunks - was measured: 36.1 us against 35.7; so was reading the hidden vectors with
       // plain loads after an agent acquire, so that an XCD's L2 serves its 32 workgroups: 36.2.  From the end of phase A
       // to the exit this launch moves its 61 MB (W2 + 256 copies of the hidden vectors) at the same ~18 GB/s per CU as
-      // phase A moves the w1/w3 rows: it is bound by what a CU can keep in flight, not by the order of its requests.)
+      // phase A moves the w1/w3 rows.  With ALL W2 rows requested before the hand-off (8 us ahead of their use) the
+      // multiplies after the staging still take 5.4 us: they are VALU-bound - 252 virtual rows x 32 items per workgroup at
+      // ~85 wave instructions per item on 4 SIMDs - and nothing is left to stream underneath them.)
       // the first job's weights are requested BEFORE the hand-off: they stream while the slots' producers finish
       ChunkKQ<QT, 1, UB, false> c0, c1;
       Job J = make_job(wave < n_jobs ? wave : 0);
