@@ -351,7 +351,12 @@ def main():
                                        "1 GPU" if world == 1 else f"experts sharded over {world} GPUs (RCCL all-reduce per MoE layer; EXPERIMENTAL: never run on > 1 GPU)"),
                        "hip_graph": not a.no_graph, "model_build_s": round(t_build, 1),
                        "device_gb": round(M_device_gb, 1), "algo_bytes_per_token": round(algo_bytes)},
-            "roofline": roof, "kernels": kernels, "measured_read_gbps": measured_bw, "cpu_baseline": cpu,
+            "roofline": roof, "kernels": kernels, "measured_read_gbps": measured_bw,
+            # the same two fractions against what THIS GPU streams with 16-byte loads (dsk_measure_read_bw), the north
+            # star's "measured HBM-bandwidth roofline"; the per-kernel table carries each GEMV's own GB/s
+            "frac_of_measured": ({"kernel": round(roof["achieved"] / measured_bw, 4), "token": round(roof["token_gbps"] / measured_bw, 4)}
+                                 if roof and measured_bw else None),
+            "cpu_baseline": cpu,
             "csrc_sha": csrc_sha(),
         }
         out.update(extras)

@@ -390,6 +390,15 @@ class Model:
         check(lib().dsk_model_get_stage(self.h, name.encode(), out.ctypes.data, out.nbytes))
         return out
 
+    def timeline(self, kind: int, n_wgs: int = 1024):
+        """(n_wgs, 8) wall-clock stamps (100 MHz ticks) of the LAST launch of one kind in a token; the model must have been
+        created with DSK_TIMELINE=1 in the environment (include/dsk.h dsk_model_get_timeline; rows of unused workgroups are 0)"""
+        out = np.zeros((n_wgs, 8), np.uint64)
+        f = lib().dsk_model_get_timeline
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        check(f(self.h, kind, out.ctypes.data, n_wgs))
+        return out
+
     def stage_q8(self, point: str, n: int):
         """(int8 codes, block scales) the device staged at a Q8_K point"""
         return self.stage(f"q8.{point}.qs", n, np.int8), self.stage(f"q8.{point}.d", n // 256, np.float32)

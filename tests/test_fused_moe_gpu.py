@@ -104,3 +104,33 @@ def test_soak_mla_path_replay_bit_stable(ctx):
     bad = sum(0 if np.array_equal(M.forward_nocopy(5, 0), ref) else 1 for _ in range(2000))
     assert bad == 0, bad
     M.close()
+
+
+def test_timeline_diagnostics_are_off_by_default_and_ordered_when_on(ctx, monkeypatch):
+    """include/dsk.h dsk_model_get_timeline: an error without DSK_TIMELINE, monotone stamps per workgroup with it, and the
+    instrumented model computes the same bits"""
+    import dsk
+    c = synth.preset("tiny_v3", "q2_k", False)
+    M0 = dsk.Model(ctx, c, None, synth_seed=3)
+    with pytest.raises(dsk.DskError):
+        M0.timeline(4)
+    ref = [M0.forward(t, p).copy() for p, t in enumerate((5, 9, 2))]
+    M0.close()
+    monkeypatch.setenv("DSK_TIMELINE", "1")
+    M = dsk.Model(ctx, c, None, synth_seed=3)
+    for p, t in enumerate((5, 9, 2)):
+        assert np.array_equal(M.forward(t, p), ref[p])
+    with pytest.raises(dsk.DskError):
+        M.timeline(9)
+    seen = 0
+    for kind in (0, 1, 2, 3, 4, 5):
+        T = M.timeline(kind)
+        used = T[:, 0] > 0
+        seen += int(used.any())
+        if kind in (1, 4) and used.any():  # kernels whose stamps are consecutive program points
+            n = 6 if kind == 1 else 7
+            S = T[used][:, :n].astype(np.int64)
+            assert np.all(np.diff(S, axis=1) >= 0), kind
+            assert (S[:, -1] - S[:, 0]).max() < 100 * 1000  # < 1 ms
+    assert seen >= 3
+    M.close()

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round evidence, one gpurun call on one box (profiles/README.md): bench line, rocprofv3 kernel traces (MHA, MLA, kv_len 4096),
-# a PMC pass of its own for HBM traffic, the reduced-depth C1 CPU line.   bash tools/collect_profiles.sh r02
+# a PMC pass of its own for HBM traffic, the op-level GEMV table, the in-kernel timelines, the reduced-depth C1 CPU line.   bash tools/collect_profiles.sh r02
 R=${1:-r02}
 mkdir -p gpurun_out profiles
 export TMPDIR=/tmp
@@ -21,6 +21,9 @@ cd $ROOT
 python tools/prof_summary.py --trace gpurun_out/trace_mha --pmc gpurun_out/pmc --out gpurun_out/$R --note "MI355X, round 2 final build, full 61-block DeepSeek-V3 Q2_K, MHA path" > gpurun_out/${R}_summary.log 2>&1
 python tools/prof_summary.py --trace gpurun_out/trace_mla --out gpurun_out/${R}_mla --note "MI355X, round 2 final build, full 61-block DeepSeek-V3 Q2_K, MLA path" >> gpurun_out/${R}_summary.log 2>&1
 python tools/prof_summary.py --trace gpurun_out/trace_kv4096 --out gpurun_out/${R}_kv4096 --note "MI355X, round 2 final build, DeepSeek-V3 Q2_K MHA, 6 decode steps at kv_len 4096 (tools/kv_trace.py)" >> gpurun_out/${R}_summary.log 2>&1
-python tools/cpu_c1.py > gpurun_out/${R}_cpu_c1.json 2> gpurun_out/${R}_cpu_c1.log
+python tools/kbench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_kbench.txt
+python tools/timeline.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_timeline_mha.txt
+python tools/timeline.py --attn mla 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_timeline_mla.txt
+if [ -z "$SKIP_C1" ]; then python tools/cpu_c1.py > gpurun_out/${R}_cpu_c1.json 2> gpurun_out/${R}_cpu_c1.log; fi
 rm -rf gpurun_out/trace_mha gpurun_out/trace_mla gpurun_out/trace_kv4096 gpurun_out/pmc
 ls -la gpurun_out | tail -30
