@@ -25,8 +25,8 @@ CLASS_KERNEL = {
     "gemv_dense_w13": ("gemv_kernel<3, 1, 4, true, 16>", "hi"),
     "gemv_experts_w2": "gemv_kernel<3, 2, 4, false, 4>",
     "gemv_wo": "gemv_kernel<3, 1, 4, false, 16>",
-    # gemv_kernel<3, 1, 8, false, 16> serves wq_a || wkv_a (5 MB), dense w2 (43 MB) and lm_head (304 MB): three populations
-    "gemv_qkv_a": ("gemv_kernel<3, 1, 8, false, 16>", "min"),
+    # wq_a || wkv_a (5 MB): 64 lanes per row, 2 column steps (gemv_kernel<3, 1, 8, false, 16> = dense w2 and lm_head)
+    "gemv_qkv_a": "gemv_kernel<3, 1, 2, false, 16>",
     "router_gate": "router_shared_kernel",  # router + the shared expert's w1/w3 (router_gate_kernel when not fused)
     "attn_mha": "head_attn_kernel",
     "attn_mla": "mla_head_kernel",
