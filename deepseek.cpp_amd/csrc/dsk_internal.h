@@ -323,9 +323,10 @@ struct AttnMlaArgs {
 int launch_rope_kv_mla(hipStream_t st, const AttnMlaArgs& a, const StepParams* sp);
 // MLA attention for LONG contexts on the matrix cores (kernels_misc.hip mla_flash_kernel): all heads share one latent
 // cache, so scores = Q[H x 576] . C^T and out = P . C are GEMMs.  Workgroup (chunk, head group of 32) walks its
-// chunk of positions 32 at a time with exact-f32 MFMA (v_mfma_f32_32x32x2_f32: an fma chain, K/V are f16-exact) and
-// an online softmax, and leaves (m, l, O) partials; they are merged per head by mla_head_kernel / mla_merge_kernel.
-#define MLA_FLASH_MIN_KV 768  // below this the per-head kernel's own attention is faster (measured: 27 us at 512, 43 at 1024 vs ~34 flat)
+// chunk of positions 32 at a time on v_mfma_f32_32x32x8_f16 (the cache entries are f16; q and the softmax weights go in
+// as hi + lo f16 halves: exact products, f32 accumulation) with an online softmax, and leaves (m, l, O) partials; they are merged per head by mla_head_kernel / mla_merge_kernel.
+#define MLA_FLASH_MIN_KV 320  // below this the per-head kernel's own attention is faster (token, ms: 6.12 / 6.20 / 6.31 at 256 /
+                             // 320 / 384 against a flat 6.22-6.24 with this path; DSK_MLA_FLASH_MIN overrides)
 struct MlaFlashArgs {
   const float* q_c;          // (H, lora)
   const float* q_rope;       // (H, rope)
@@ -335,8 +336,13 @@ struct MlaFlashArgs {
   float* part_o;             // (n_chunks, H, lora)
   float* part_ml;            // (n_chunks, H, 2): running max, running sum
   int n_heads, head_dim, lora, rope, is_v3;
-  int chunk_len, n_chunks;   // positions per chunk (multiple of 32), chunks in the grid
+  unsigned long long* timeline;  // debug (DSK_TIMELINE=1): 8 stamps per workgroup (chunk x head group)
+  int chunk_len, n_chunks;   // positions per chunk (multiple of 32; 0: derived from the step's kv_len, MLA_FL_CHUNK), chunks in the grid
 };
+// positions per chunk for a context of kv_len: the grid (n_chunks x head groups) is fixed in the captured graph, the
+// share of each chunk follows the context, so that a 1024-position context occupies 32 chunks of 32 positions instead
+// of 11 chunks of 96 (mla_flash_kernel at kv_len 1024: 31 -> 13 us)
+#define MLA_FL_CHUNK(kv_len, n_chunks) ((((kv_len) + (n_chunks) - 1) / (n_chunks) + 31) / 32 * 32)
 int launch_mla_flash(hipStream_t st, const MlaFlashArgs& a, const StepParams* sp, int kv_len_override);
 int launch_mla_merge(hipStream_t st, const MlaFlashArgs& a, const StepParams* sp, int kv_len_override, float* out);
 // MLA, model path: (1) one workgroup normalises the latent, writes this position's cache entries and rotates the

@@ -622,6 +622,7 @@ extern "C" int dsk_model_finalize(dsk_model* m) {
   HIP_TRY(hipHostMalloc((void**)&m->logits_host, (size_t)c.vocab_size * 4, hipHostMallocDefault));
   memset(m->sp_host, 0, sizeof(StepParams));
   if (c.use_mla && c.kv_lora_rank == 512 && c.qk_rope_head_dim == 64) {  // long-context MLA on the matrix cores
+    if (getenv("DSK_MLA_FLASH_MIN")) m->mla_flash_min_kv = std::max(32, atoi(getenv("DSK_MLA_FLASH_MIN")));
     HIP_TRY(hipMalloc((void**)&m->fl_part_o, (size_t)64 * c.n_heads * c.kv_lora_rank * 4));
     HIP_TRY(hipMalloc((void**)&m->fl_part_ml, (size_t)64 * c.n_heads * 8));
     m->scratch_bytes += (double)64 * c.n_heads * (c.kv_lora_rank * 4 + 8);

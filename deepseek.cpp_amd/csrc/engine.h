@@ -95,6 +95,7 @@ struct dsk_model {
   // graphs
   bool use_graph = true, trace = false;
   hipGraphExec_t graph[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // (hydrate, logits, argmax, sample) x (short, long context)
+  int mla_flash_min_kv = MLA_FLASH_MIN_KV;  // DSK_MLA_FLASH_MIN overrides (A/B)
   float* fl_part_o = nullptr;   // MLA long-context partials (n_chunks, H, lora) / (n_chunks, H, 2)
   float* fl_part_ml = nullptr;
   std::vector<MlaFlashArgs> mla_flash;

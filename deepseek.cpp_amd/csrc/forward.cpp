@@ -238,9 +238,9 @@ int build_plans(dsk_model* m) {
         memset(&F, 0, sizeof F);
         F.q_c = m->q_c; F.q_rope = m->q_rope; F.rotate_q = 1; F.nope_cache = L.nope_cache; F.rope_cache = L.rope_cache;
         F.part_o = m->fl_part_o; F.part_ml = m->fl_part_ml; F.n_heads = H; F.head_dim = m->head_dim; F.lora = c.kv_lora_rank;
-        F.rope = c.qk_rope_head_dim; F.is_v3 = c.has_moegate_bias; F.n_chunks = 64; F.chunk_len = ((max_kv + 63) / 64 + 31) / 32 * 32;
+        F.rope = c.qk_rope_head_dim; F.is_v3 = c.has_moegate_bias; F.timeline = m->timeline_of(6); F.n_chunks = 64; F.chunk_len = 0;  // per step: MLA_FL_CHUNK(kv_len, 64)
         m->mla_flash[l] = F;
-        A.flash_thresh = MLA_FLASH_MIN_KV; A.fl_chunk_len = F.chunk_len; A.fl_n_chunks = F.n_chunks; A.fl_part_o = F.part_o; A.fl_part_ml = F.part_ml;
+        A.flash_thresh = m->mla_flash_min_kv; A.fl_chunk_len = F.chunk_len; A.fl_n_chunks = F.n_chunks; A.fl_part_o = F.part_o; A.fl_part_ml = F.part_ml;
       }
       DSK_TRY(mla_head_plan(A));
       m->mla_head[l] = A;
@@ -508,7 +508,7 @@ static int attention_mla(dsk_model* m, int l, int max_kv) {
       PROFILED("rope_kv", (double)c.kv_lora_rank * 14 + c.qk_rope_head_dim * 6, launch_mla_kv_write(st, kv, m->sp_dev));
     }
   }
-  if (m->mla_flash[l].part_o && m->sp_host->kv_len >= MLA_FLASH_MIN_KV)  // long-context regime (its own graph: dsk_forward)
+  if (m->mla_flash[l].part_o && m->sp_host->kv_len >= m->mla_flash_min_kv)  // long-context regime (its own graph: dsk_forward)
     PROFILED("attn_mla_flash", (double)m->sp_host->kv_len * (c.kv_lora_rank + c.qk_rope_head_dim) * 2, launch_mla_flash(st, m->mla_flash[l], m->sp_dev, 0));
   // q rope + attention over the shared latent cache + per-head wv_b + Q8_K of the outputs: one launch
   MlaHeadArgs MA = m->mla_head[l];
@@ -647,7 +647,7 @@ static int run_token(dsk_model* m, int token, int pos, int mode) {
   // lazily initialised collectives out of stream capture.
   const bool graphable = m->use_graph && !m->trace && !m->profiling && !m->ctx->comm;
   // the long-context MLA regime enqueues one more launch per block: its own captured graph
-  const bool long_mla = m->fl_part_o && m->sp_host->kv_len >= MLA_FLASH_MIN_KV;
+  const bool long_mla = m->fl_part_o && m->sp_host->kv_len >= m->mla_flash_min_kv;
   // ... and so does the long-context MHA regime (split contexts: a different grid)
   const bool long_mha = !m->c.use_mla && m->mha_split > 1 && m->sp_host->kv_len >= m->mha_split_min;
   const int gi = mode + (long_mla || long_mha ? 4 : 0);  // 0 hydrate, 1 logits, 2 argmax, 3 sample

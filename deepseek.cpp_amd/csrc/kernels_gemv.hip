@@ -574,7 +574,8 @@ __global__ __launch_bounds__(1024) void mla_head_kernel(const MlaHeadArgs A, con
   const bool merged = A.flash_thresh > 0 && kv_len >= A.flash_thresh;  // uniform: mla_flash_kernel ran before us
   if (merged) {
     // out = sum_c e^(m_c - M) O_c / sum_c e^(m_c - M) l_c over the chunk partials of this head
-    const int nc = min(A.fl_n_chunks, (kv_len + A.fl_chunk_len - 1) / A.fl_chunk_len);
+    const int fcl = A.fl_chunk_len > 0 ? A.fl_chunk_len : MLA_FL_CHUNK(kv_len, A.fl_n_chunks);
+    const int nc = min(A.fl_n_chunks, (kv_len + fcl - 1) / fcl);
     const int H = a.n_heads;
     float* wc = part;  // per-chunk weights e^(m_c - M) / L, computed once
     if (tid < 64) {
@@ -586,11 +587,28 @@ __global__ __launch_bounds__(1024) void mla_head_kernel(const MlaHeadArgs A, con
       wc[tid] = e / Lsum;
     }
     __syncthreads();
-    if (tid < lora) {
+    // column tid & 511, even chunks in the lower half of the workgroup, odd ones in the upper; 8 partials requested per
+    // round trip (one dependent load per chunk made this merge ~0.4 us x the number of chunks)
+    {
+      const int col = tid & 511, half = tid >> 9;
       float o = 0.f;
-      for (int c = 0; c < nc; ++c) o = fmaf(wc[c], A.fl_part_o[((size_t)c * H + h) * lora + tid], o);
-      o_s[tid] = o;
+      for (int c0 = half; c0 < nc; c0 += 16) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int c = c0 + 2 * j;
+          v[j] = (c < nc && col < lora) ? A.fl_part_o[((size_t)c * H + h) * lora + col] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int c = c0 + 2 * j;
+          if (c < nc) o = fmaf(wc[c], v[j], o);
+        }
+      }
+      part[64 + tid] = o;
     }
+    __syncthreads();
+    if (tid < lora && tid < 512) o_s[tid] = part[64 + tid] + part[64 + 512 + tid];
     __syncthreads();
   } else {
   // ---- scores: 16 lanes per position, 2 positions per group and step ----

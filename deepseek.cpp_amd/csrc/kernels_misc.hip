@@ -894,15 +894,18 @@ int launch_mla_kv_write(hipStream_t st, const MlaKvArgs& a, const StepParams* sp
 
 // ------------------------------------------------------------------------------------
 // MLA attention on the matrix cores (long contexts).  See MlaFlashArgs in dsk_internal.h.
-// v_mfma_f32_32x32x2_f32: A one f32 per lane A[i = l&31][k = l>>5], B one f32 per lane B[k = l>>5][j = l&31],
-// C/D 16 f32 per lane: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+// v_mfma_f32_32x32x8_f16: A four f16 per lane A[i = l&31][k = 4*(l>>5) ..+3], B four f16 per lane B[k = 4*(l>>5) ..+3][j = l&31],
+// C/D 16 f32 per lane: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).  The cache entries ARE f16; the f32 operand of
+// each product (q, the softmax weights) goes in as hi + lo f16 halves, two MFMAs: exact products, f32 accumulation
+// (round 1 used v_mfma_f32_32x32x2_f32: twice the instructions for the same bits to ~1e-7).
 // ------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 #define FL_KSTRIDE 580   // halfs per staged cache row (576 + 4): 290 dwords, odd multiple of 2 -> conflict-free column reads
 #define FL_PSTRIDE 33
 
 // 8 waves per workgroup: the K range of the score GEMM and the latent columns of the value GEMM are split 8 ways, so a
-// wave issues 36 + 32 MFMAs per 32-position block and two waves share a SIMD.  All B operands of a block are read
+// wave issues 18 + 16 MFMAs per 32-position block and two waves share a SIMD.  All B operands of a block are read
 // from LDS into registers BEFORE the MFMA chain (a dependent ds_read -> cvt -> mfma per step tripled the time).
 #define FL_NWV 8
 __global__ __launch_bounds__(FL_NWV * 64) void mla_flash_kernel(MlaFlashArgs a, const StepParams* __restrict__ sp, int kv_len_override) {
@@ -911,53 +914,118 @@ __global__ __launch_bounds__(FL_NWV * 64) void mla_flash_kernel(MlaFlashArgs a, 
   float (*Sp)[32][FL_PSTRIDE] = reinterpret_cast<float (*)[32][FL_PSTRIDE]>(fl_smem + 32 * FL_KSTRIDE * 2);  // [FL_NWV][32][33]
   float (*Pm)[FL_PSTRIDE] = reinterpret_cast<float (*)[FL_PSTRIDE]>(fl_smem + 32 * FL_KSTRIDE * 2 + FL_NWV * 32 * FL_PSTRIDE * 4);
   __shared__ float m_s[32], l_s[32], al_s[32];
-  const int kv_len = kv_len_override > 0 ? kv_len_override : sp->kv_len;
-  const int p0 = blockIdx.x * a.chunk_len;
-  if (p0 >= kv_len) return;
-  const int p1 = min(kv_len, p0 + a.chunk_len);
   const int hg = blockIdx.y, tid = threadIdx.x, w = tid >> 6, l = tid & 63, i = l & 31, kh = l >> 5;
-  const int lora = a.lora, rope = a.rope, KT = lora + rope;  // 576
+  unsigned long long* tl = a.timeline ? a.timeline + (size_t)(blockIdx.x * gridDim.y + blockIdx.y) * 8 : nullptr;
+  if (tl && tid == 0) tl[0] = wall_clock64();
+  constexpr int lora = 512, rope = 64, KT = lora + rope;  // 576: launch_mla_flash admits only these (compile-time: the staging loops unroll)
   const int head = hg * 32 + i;
   const bool hv = head < a.n_heads;
   // ---- this wave's eighth of the K range of Q, one value per (MFMA step, lane): k = 2*(ks0 + s) + kh ----
   constexpr int steps = 288 / FL_NWV;  // k-pairs per wave: (512 + 64) / 2 / 8 (launch_mla_flash admits only these dims)
   const int ks0 = w * steps;
-  // Q tile of this head group through LDS (coalesced row reads; per-lane strided global reads cost 12 us).  The whole
-  // [32][576] tile fits the dynamic LDS of the main loop (not yet in use); row stride 577 floats: conflict-free column
-  // reads.  A lane then picks its strided elements and rotates the rope pairs (src/infer.cpp:648-685).
-  float qa[steps];
-  {
-    constexpr int QST = 577;
-    float* Qs = reinterpret_cast<float*>(fl_smem);
-    for (int c = tid; c < 32 * 144; c += FL_NWV * 64) {  // 144 float4 per row
-      const int r = c / 144, cc = c - r * 144;
-      const int k = cc * 4;
-      const int hh = hg * 32 + r;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (hh < a.n_heads) {
-        if (k < lora) v = *reinterpret_cast<const f32x4*>(a.q_c + (size_t)hh * lora + k);
-        else v = *reinterpret_cast<const f32x4*>(a.q_rope + (size_t)hh * rope + (k - lora));
+  // ---- requests first.  The Q tile of this head group (written a launch ago by other CUs: L2 misses) depends on nothing,
+  // not even on the context length: its 9 float4 per thread leave before kv_len has been read; then the first 32 cache
+  // rows of this chunk (HBM; they do not depend on q) ----
+  constexpr int NQ = 32 * 144 / (FL_NWV * 64);
+  f32x4 qv[NQ], cs[NQ];
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    const int c = tid + j * (FL_NWV * 64);
+    const int r = c / 144, k = (c - r * 144) * 4;
+    const int hh = hg * 32 + r;
+    qv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    cs[j] = f32x4{1.f, 0.f, 1.f, 0.f};
+    if (hh < a.n_heads) {
+      if (k < lora) qv[j] = *reinterpret_cast<const f32x4*>(a.q_c + (size_t)hh * lora + k);
+      else {
+        qv[j] = *reinterpret_cast<const f32x4*>(a.q_rope + (size_t)hh * rope + (k - lora));
+        if (a.rotate_q) cs[j] = *reinterpret_cast<const f32x4*>(sp->rope_cs + (k - lora));  // (cos, sin) of pairs (k - lora) / 2, + 1
       }
-      float* dst = Qs + r * QST + k;
-      dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
+  }
+  const int kv_len = kv_len_override > 0 ? kv_len_override : sp->kv_len;
+  const int chunk_len = a.chunk_len > 0 ? a.chunk_len : MLA_FL_CHUNK(kv_len, a.n_chunks);
+  const int p0 = blockIdx.x * chunk_len;
+  if (p0 >= kv_len) return;  // (uniform; a workgroup past the context drops its Q requests)
+  const int p1 = min(kv_len, p0 + chunk_len);
+  // 32 rows x 72 sixteen-byte pieces over 512 threads: 4.5 per thread, all in flight at once; rows past the chunk are zero
+  constexpr int per_row = KT / 8, NK = (32 * per_row + FL_NWV * 64 - 1) / (FL_NWV * 64);
+  u32x4 kv4[NK];
+  auto request_rows = [&](int b0) {
+    const int nvalid = min(32, p1 - b0);
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+      const int c = tid + j * (FL_NWV * 64);
+      const int r = c / per_row, k = (c - r * per_row) * 8;
+      kv4[j] = u32x4{0u, 0u, 0u, 0u};
+      if (c < 32 * per_row && r < nvalid) {
+        if (k < lora) kv4[j] = *reinterpret_cast<const u32x4*>(a.nope_cache + (size_t)(b0 + r) * lora + k);
+        else kv4[j] = *reinterpret_cast<const u32x4*>(a.rope_cache + (size_t)(b0 + r) * rope + (k - lora));
+      }
+    }
+  };
+  auto store_rows = [&]() {
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+      const int c = tid + j * (FL_NWV * 64);
+      const int r = c / per_row, k = (c - r * per_row) * 8;
+      if (c < 32 * per_row) {  // the staged row stride is 8-byte aligned only: two 8-byte stores
+        *reinterpret_cast<uint2*>(Ks + r * FL_KSTRIDE + k) = uint2{kv4[j].x, kv4[j].y};
+        *reinterpret_cast<uint2*>(Ks + r * FL_KSTRIDE + k + 4) = uint2{kv4[j].z, kv4[j].w};
+      }
+    }
+  };
+  request_rows(p0);
+  // Q tile of this head group through LDS (coalesced row reads; per-lane strided global reads cost 12 us).  The whole
+  // [32][576] tile fits the dynamic LDS of the main loop (not yet in use).  32 x 144 float4 over 512 threads = 9 per
+  // thread, ALL requested before the first is stored (the tile was written by other CUs a launch ago: every load is an L2
+  // miss; one round trip, not nine).  The rope pairs are rotated by the thread that loaded them (src/infer.cpp:648-685),
+  // so that a lane then only picks its strided elements: 8-byte LDS reads, row stride 578 floats.
+  // A operands of the score MFMAs (v_mfma_f32_32x32x8_f16: lane (i, kh) holds 4 consecutive k of row i): this wave's 72
+  // k-values of Q as nine (hi, lo) f16 quadruples, q = hi + lo to 22 bits; the products with the f16 cache entries are
+  // exact in f32 and accumulate in f32, so the scores keep f32 accuracy at half the f32 MFMA's instruction count
+  half4 qh[steps / 4], ql[steps / 4];
+  {
+    constexpr int QST = 578;
+    float* Qs = reinterpret_cast<float*>(fl_smem);
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      const int c = tid + j * (FL_NWV * 64);
+      const int r = c / 144, k = (c - r * 144) * 4;
+      float* row = Qs + r * QST;
+      if (k < lora || !a.rotate_q) {
+        *reinterpret_cast<float2*>(row + k) = float2{qv[j].x, qv[j].y};
+        *reinterpret_cast<float2*>(row + k + 2) = float2{qv[j].z, qv[j].w};
+      } else {
+        const float re0 = qv[j].x * cs[j].x - qv[j].y * cs[j].y, im0 = qv[j].x * cs[j].y + qv[j].y * cs[j].x;
+        const float re1 = qv[j].z * cs[j].z - qv[j].w * cs[j].w, im1 = qv[j].z * cs[j].w + qv[j].w * cs[j].z;
+        if (a.is_v3) {  // rotated in place, interleaved (rope_v3)
+          *reinterpret_cast<float2*>(row + k) = float2{re0, im0};
+          *reinterpret_cast<float2*>(row + k + 2) = float2{re1, im1};
+        } else {        // V2: real parts to [j], imaginary parts to [j + rope / 2]
+          const int j0 = (k - lora) >> 1;
+          *reinterpret_cast<float2*>(row + lora + j0) = float2{re0, re1};
+          *reinterpret_cast<float2*>(row + lora + rope / 2 + j0) = float2{im0, im1};
+        }
+      }
     }
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < steps; ++s) {
-      const int k = 2 * (ks0 + s) + kh;
-      float v = Qs[i * QST + k];
-      if (k >= lora && a.rotate_q) {
-        const int kr = k - lora;
-        const int j = a.is_v3 ? kr >> 1 : (kr < rope / 2 ? kr : kr - rope / 2);
-        const bool im = a.is_v3 ? (kr & 1) : (kr >= rope / 2);
-        const float v0 = Qs[i * QST + lora + 2 * j], v1 = Qs[i * QST + lora + 2 * j + 1];
-        const float c = sp->rope_cs[2 * j], sn = sp->rope_cs[2 * j + 1];
-        v = im ? v0 * sn + v1 * c : v0 * c - v1 * sn;
+    for (int m = 0; m < steps / 4; ++m) {
+      const float* src = Qs + i * QST + 2 * ks0 + 8 * m + 4 * kh;
+      const float2 t0 = *reinterpret_cast<const float2*>(src), t1 = *reinterpret_cast<const float2*>(src + 2);
+      const float f[4] = {t0.x, t0.y, t1.x, t1.y};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = hv ? f[e] : 0.f;
+        const _Float16 hi = (_Float16)v;
+        qh[m][e] = hi;
+        ql[m][e] = (_Float16)(v - (float)hi);
       }
-      qa[s] = hv ? v : 0.f;
     }
     __syncthreads();
   }
+  if (tl && tid == 0) tl[1] = wall_clock64();
   constexpr int NTO = 2;  // 32-column output tiles per wave: 512 / 8 / 32
   f32x16 oacc[NTO];
 #pragma unroll
@@ -966,47 +1034,40 @@ __global__ __launch_bounds__(FL_NWV * 64) void mla_flash_kernel(MlaFlashArgs a, 
     for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
   if (tid < 32) { m_s[tid] = -INFINITY; l_s[tid] = 0.f; }
   const float inv = sqrtf((float)a.head_dim);
+  store_rows();  // the chunk's first 32 cache rows (latent | rope) as f16
   for (int b0 = p0; b0 < p1; b0 += 32) {
     const int nvalid = min(32, p1 - b0);
-    // ---- stage 32 cache rows (latent | rope) as f16, 8 bytes per store; rows past nvalid are zero ----
-    {
-      const int per_row = KT / 4;  // 8-byte chunks per row (144)
-      for (int c = tid; c < 32 * per_row; c += FL_NWV * 64) {
-        const int r = c / per_row, cc = c - r * per_row;
-        uint2 v = {0u, 0u};
-        if (r < nvalid) {
-          const int k = cc * 4;
-          if (k < lora) v = *reinterpret_cast<const uint2*>(a.nope_cache + (size_t)(b0 + r) * lora + k);
-          else v = *reinterpret_cast<const uint2*>(a.rope_cache + (size_t)(b0 + r) * rope + (k - lora));
-        }
-        *reinterpret_cast<uint2*>(Ks + r * FL_KSTRIDE + cc * 4) = v;
-      }
-    }
+    const bool more = b0 + 32 < p1;
     __syncthreads();
+    if (tl && tid == 0 && b0 == p0) tl[2] = wall_clock64();
+    if (more) request_rows(b0 + 32);  // the next 32 rows travel while this block is multiplied
     // ---- partial scores of this wave's K range: S[head][pos] ----
-    uint2 kk[steps / 2];  // 4 halfs (2 steps) per 8-byte LDS read
-    const unsigned short* krow = Ks + i * FL_KSTRIDE + 2 * ks0;
+    half4 kb[steps / 4];  // B operands: 4 consecutive k of cache row i, as stored (f16): one 8-byte LDS read each
+    const unsigned short* krow = Ks + i * FL_KSTRIDE + 2 * ks0 + 4 * kh;
 #pragma unroll
-    for (int s2 = 0; s2 < steps / 2; ++s2) kk[s2] = *reinterpret_cast<const uint2*>(krow + 4 * s2);
+    for (int m = 0; m < steps / 4; ++m) kb[m] = __builtin_bit_cast(half4, *reinterpret_cast<const uint2*>(krow + 8 * m));
     f32x16 sacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
 #pragma unroll
-    for (int s2 = 0; s2 < steps / 2; ++s2) {
-      const float b0v = h2f((unsigned short)(kh ? kk[s2].x >> 16 : kk[s2].x & 0xffff));
-      const float b1v = h2f((unsigned short)(kh ? kk[s2].y >> 16 : kk[s2].y & 0xffff));
-      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[2 * s2], b0v, sacc, 0, 0, 0);
-      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[2 * s2 + 1], b1v, sacc, 0, 0, 0);
+    for (int m = 0; m < steps / 4; ++m) {
+      sacc = __builtin_amdgcn_mfma_f32_32x32x8f16(qh[m], kb[m], sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x8f16(ql[m], kb[m], sacc, 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) Sp[w][(r & 3) + 8 * (r >> 2) + 4 * kh][i] = sacc[r];
-    // value operands of this wave for the whole block: requested now, consumed after the softmax
-    unsigned short vv[16][NTO];
+    // value operands of this wave for the whole block (B of v_mfma_f32_32x32x8_f16: 4 consecutive positions of one latent
+    // column): requested now, consumed after the softmax
+    half4 vb[4][NTO];
 #pragma unroll
-    for (int s = 0; s < 16; ++s)
+    for (int m = 0; m < 4; ++m)
 #pragma unroll
-      for (int t = 0; t < NTO; ++t) vv[s][t] = Ks[(2 * s + kh) * FL_KSTRIDE + w * (NTO * 32) + t * 32 + i];
+      for (int t = 0; t < NTO; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          vb[m][t][e] = __builtin_bit_cast(_Float16, Ks[(8 * m + 4 * kh + e) * FL_KSTRIDE + w * (NTO * 32) + t * 32 + i]);
     __syncthreads();
+    if (tl && tid == 0 && b0 == p0) tl[3] = wall_clock64();
     // ---- sum the partial tiles in wave order, online softmax per head row: threads 0..255 -> (row, 4 columns) ----
     if (tid < 256) {
       const int r = tid >> 3, c4 = (tid & 7) * 4;
@@ -1042,20 +1103,34 @@ __global__ __launch_bounds__(FL_NWV * 64) void mla_flash_kernel(MlaFlashArgs a, 
       }
     }
     __syncthreads();
+    if (tl && tid == 0 && b0 == p0) tl[4] = wall_clock64();
     // ---- O = O * alpha + P . V for this wave's 64 latent columns ----
-    float pa[16];
+    half4 ph[4], pl[4];  // P[i][8m + 4kh ..+3] as (hi, lo) f16 quadruples
 #pragma unroll
-    for (int s = 0; s < 16; ++s) pa[s] = Pm[i][2 * s + kh];
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = Pm[i][8 * m + 4 * kh + e];
+        const _Float16 hi = (_Float16)v;
+        ph[m][e] = hi;
+        pl[m][e] = (_Float16)(v - (float)hi);
+      }
 #pragma unroll
     for (int t = 0; t < NTO; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[t][r] *= al_s[(r & 3) + 8 * (r >> 2) + 4 * kh];
 #pragma unroll
-    for (int s = 0; s < 16; ++s)
+    for (int m = 0; m < 4; ++m)
 #pragma unroll
-      for (int t = 0; t < NTO; ++t) oacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[s], h2f(vv[s][t]), oacc[t], 0, 0, 0);
+      for (int t = 0; t < NTO; ++t) {
+        oacc[t] = __builtin_amdgcn_mfma_f32_32x32x8f16(ph[m], vb[m][t], oacc[t], 0, 0, 0);
+        oacc[t] = __builtin_amdgcn_mfma_f32_32x32x8f16(pl[m], vb[m][t], oacc[t], 0, 0, 0);
+      }
     __syncthreads();  // Ks / Pm are rewritten by the next block
+    if (more) store_rows();
+    if (tl && tid == 0 && b0 == p0) tl[5] = wall_clock64();
   }
+  if (tl && tid == 0) tl[6] = wall_clock64();
   // ---- partials: O (un-normalised), running max and sum ----
   const int chunk = blockIdx.x;
 #pragma unroll
@@ -1070,10 +1145,11 @@ __global__ __launch_bounds__(FL_NWV * 64) void mla_flash_kernel(MlaFlashArgs a, 
     a.part_ml[((size_t)chunk * a.n_heads + hg * 32 + tid) * 2] = m_s[tid];
     a.part_ml[((size_t)chunk * a.n_heads + hg * 32 + tid) * 2 + 1] = l_s[tid];
   }
+  if (tl && tid == 0) tl[7] = wall_clock64();
 }
 int launch_mla_flash(hipStream_t st, const MlaFlashArgs& a, const StepParams* sp, int kv_len_override) {
   if (a.lora != 512 || a.rope != 64) DSK_FAIL(DSK_ERR_UNSUPPORTED, "mla flash attention: kv_lora_rank %d / rope %d (512 / 64 only)", a.lora, a.rope);
-  if (a.chunk_len % 32 || a.n_chunks < 1) DSK_FAIL(DSK_ERR_INVALID, "mla flash attention: chunk_len %d", a.chunk_len);
+  if (a.chunk_len < 0 || a.chunk_len % 32 || a.n_chunks < 1) DSK_FAIL(DSK_ERR_INVALID, "mla flash attention: chunk_len %d", a.chunk_len);
   const size_t lds = 32 * FL_KSTRIDE * 2 + FL_NWV * 32 * FL_PSTRIDE * 4 + 32 * FL_PSTRIDE * 4;
   static bool attr_set = false;
   if (!attr_set) { hipFuncSetAttribute((const void*)mla_flash_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
@@ -1085,7 +1161,8 @@ int launch_mla_flash(hipStream_t st, const MlaFlashArgs& a, const StepParams* sp
 __global__ __launch_bounds__(512) void mla_merge_kernel(MlaFlashArgs a, const StepParams* __restrict__ sp, int kv_len_override, float* __restrict__ out) {
   const int h = blockIdx.x, tid = threadIdx.x;
   const int kv_len = kv_len_override > 0 ? kv_len_override : sp->kv_len;
-  const int nc = min(a.n_chunks, (kv_len + a.chunk_len - 1) / a.chunk_len);
+  const int chunk_len = a.chunk_len > 0 ? a.chunk_len : MLA_FL_CHUNK(kv_len, a.n_chunks);
+  const int nc = min(a.n_chunks, (kv_len + chunk_len - 1) / chunk_len);
   float M = -INFINITY;
   for (int c = 0; c < nc; ++c) M = fmaxf(M, a.part_ml[((size_t)c * a.n_heads + h) * 2]);
   float L = 0.f;

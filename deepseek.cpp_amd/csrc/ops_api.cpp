@@ -280,7 +280,7 @@ extern "C" int dsk_attn_mla(dsk_ctx* ctx, const float* q_c, const float* q_rope,
     memset(&f, 0, sizeof f);
     f.q_c = a.q_c; f.q_rope = a.q_rope; f.rotate_q = 0; f.nope_cache = a.nope_cache; f.rope_cache = a.rope_cache;
     f.n_heads = n_heads; f.head_dim = head_dim; f.lora = kv_lora_rank; f.rope = rope_dim;
-    f.n_chunks = 64; f.chunk_len = ((kv_len + 63) / 64 + 31) / 32 * 32;
+    f.n_chunks = 64; f.chunk_len = 0;  // derived from kv_len in the kernels (MLA_FL_CHUNK), as in the model
     DevBuf po, pml;
     DSK_TRY(po.alloc((size_t)f.n_chunks * n_heads * kv_lora_rank * 4));
     DSK_TRY(pml.alloc((size_t)f.n_chunks * n_heads * 8));

@@ -232,10 +232,11 @@ def test_attn_vs_reference_golden_and_kat(ctx, ops_gold):
         assert np.allclose(out, want, atol=1e-6)
 
 
-@pytest.mark.parametrize("kv_len", [768, 1001, 2100])
+@pytest.mark.parametrize("kv_len", [320, 333, 768, 1001, 2100, 4100])
 def test_attn_mla_long_context_matrix_core_path(ctx, oracle, kv_len):
-    """kv_len >= 768 takes the MFMA path (exact-f32 matrix cores, chunked online softmax + merge): same result as
-    the reference's attn_mla (src/infer.cpp:766-804) up to f32 summation order."""
+    """kv_len >= 320 takes the MFMA path (f16 matrix cores on the f16 cache entries, q and the softmax weights as hi + lo
+    halves: exact products, f32 accumulation; chunked online softmax + merge): same result as the reference's attn_mla
+    (src/infer.cpp:766-804) up to f32 summation order; 1 and 2-3 blocks of 32 positions per chunk, ragged last blocks."""
     rng = np.random.default_rng(kv_len)
     H, lora, rope, hd = 40, 512, 64, 192  # 40 heads: a ragged last head group
     q_c = rng.standard_normal((H, lora)).astype(np.float32) * 0.2
