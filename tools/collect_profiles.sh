@@ -24,6 +24,7 @@ python tools/prof_summary.py --trace gpurun_out/trace_kv4096 --out gpurun_out/${
 python tools/kbench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_kbench.txt
 python tools/timeline.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_timeline_mha.txt
 python tools/timeline.py --attn mla 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_timeline_mla.txt
+python tools/timeline.py --attn mla --kv 4096 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_timeline_mla_kv4096.txt
 if [ -z "$SKIP_C1" ]; then python tools/cpu_c1.py > gpurun_out/${R}_cpu_c1.json 2> gpurun_out/${R}_cpu_c1.log; fi
 rm -rf gpurun_out/trace_mha gpurun_out/trace_mla gpurun_out/trace_kv4096 gpurun_out/pmc
 ls -la gpurun_out | tail -30
