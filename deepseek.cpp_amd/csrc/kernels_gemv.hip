@@ -555,6 +555,12 @@ __global__ __launch_bounds__(1024) void mla_head_kernel(const MlaHeadArgs A, con
   const int lora = a.lora, rope = a.rope, kv_len = sp->kv_len;
   uint8_t* act = smem;
   float* att = reinterpret_cast<float*>(smem + A.lds_act);
+  unsigned long long* tl = A.timeline ? A.timeline + (size_t)h * 8 : nullptr;
+  if (tl && tid == 0) tl[0] = wall_clock64();
+  // (This head's wv_b rows - 21 KB, one row group - requested here, ahead of everything, and multiplied at the end: no
+  // gain, 11.1 -> 12.3 us in the bench.  The tail after the attention is the Q8_K of the latent output, two barriers and
+  // one column step of arithmetic, 2.0 us with the weights already in registers; the 3.9 us in front of it are the two
+  // dependent reads of the cache rows, `python tools/timeline.py --attn mla`.)
   // ---- q: latent part as is, rope part rotated (src/infer.cpp:1075-1084) ----
   for (int i = tid; i < lora; i += NT) q_s[i] = a.q_c[(size_t)h * lora + i];
   if (tid < rope / 2) {
@@ -571,6 +577,7 @@ __global__ __launch_bounds__(1024) void mla_head_kernel(const MlaHeadArgs A, con
     }
   }
   __syncthreads();
+  if (tl && tid == 0) tl[1] = wall_clock64();
   const bool merged = A.flash_thresh > 0 && kv_len >= A.flash_thresh;  // uniform: mla_flash_kernel ran before us
   if (merged) {
     // out = sum_c e^(m_c - M) O_c / sum_c e^(m_c - M) l_c over the chunk partials of this head
@@ -704,6 +711,7 @@ __global__ __launch_bounds__(1024) void mla_head_kernel(const MlaHeadArgs A, con
     __syncthreads();
   }
   }  // !merged
+  if (tl && tid == 0) tl[2] = wall_clock64();
   // ---- this head's wv_b rows on the latent output (src/infer.cpp:1134-1137) ----
   const int vd = A.fin.v_dim;
   if constexpr (KQ) {
@@ -747,7 +755,9 @@ __global__ __launch_bounds__(1024) void mla_head_kernel(const MlaHeadArgs A, con
     }
   }
   __syncthreads();
+  if (tl && tid == 0) tl[3] = wall_clock64();
   ad::attn_out_q8(A.fin, h, tid, tid < vd ? out_s[tid] : 0.f, &last_flag);
+  if (tl && tid == 0) tl[4] = wall_clock64();
 }
 
 int mla_head_plan(MlaHeadArgs& A) {

@@ -19,7 +19,8 @@ for i in range(4 if a.kv else 0):  # a long context: the cache rows below hold z
     M.forward(17 + i, a.kv + i)
 f = dsk.lib().dsk_model_get_timeline; f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
 GEMV = ["entry", "rows[0] done", "", "exit", "stage: loaded", "stage: quantised", "stage begin", "staged", ]
-KINDS = {0: ("first-stage projections (gemv)", None), 1: ("per-head attention", ["entry", "latents staged", "head rows done", "rope + cache row", "attention done", "exit (Q8 of the output)"]),
+KINDS = {0: ("first-stage projections (gemv)", None), 1: ("per-head attention", (["entry", "q staged", "attention (or merge) done", "wv_b rows done", "exit (Q8 of the output)"] if a.attn == "mla" else
+                                    ["entry", "latents staged", "head rows done", "rope + cache row", "attention done", "exit (Q8 of the output)"])),
          2: ("wo (gemv)", None), 3: ("shared expert w1/w3 (rider gemv)", None), 5: ("router", ["entry", "norm scale", "rows done", "arrived", "gate done (last only)"]),
          6: ("MLA long-context scores / values (mla_flash_kernel)", ["entry", "Q tile staged", "first 32 cache rows staged", "scores done", "softmax done", "values done", "all blocks done", "exit (partials written)"]),
          4: ("routed experts", ["entry", "staged x", "phase A done", "hand-off passed", "hidden staged", "rows done", "exit"])}
