@@ -561,6 +561,26 @@ __global__ __launch_bounds__(1024) void mla_head_kernel(const MlaHeadArgs A, con
   // gain, 11.1 -> 12.3 us in the bench.  The tail after the attention is the Q8_K of the latent output, two barriers and
   // one column step of arithmetic, 2.0 us with the weights already in registers; the 3.9 us in front of it are the two
   // dependent reads of the cache rows, `python tools/timeline.py --attn mla`.)
+  // ---- the cache rows of the first scoring step (8 positions per wave, 128 per workgroup: the whole context of a short
+  // one) are requested NOW: they were written by earlier launches and depend on nothing here, so their HBM latency runs
+  // under the staging of q instead of after it ----
+  const int nj = lora >> 6;  // f16x4 loads per lane for the latent part (8 for lora 512)
+  h4 kc[2][8], kr[2];
+  auto request_rows = [&](int t0) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int t = t0 + u * 4 + grp;
+      if (t < kv_len) {
+        const uint16_t* c = a.nope_cache + (size_t)t * lora;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j < nj) kc[u][j] = *reinterpret_cast<const h4*>(c + 64 * j + sl * 4);
+        if (sl * 4 < rope) kr[u] = *reinterpret_cast<const h4*>(a.rope_cache + (size_t)t * rope + sl * 4);
+      }
+    }
+  };
+  const bool merged = A.flash_thresh > 0 && kv_len >= A.flash_thresh;  // uniform: mla_flash_kernel ran before us
+  if (!merged) request_rows(wave * 8);
   // ---- q: latent part as is, rope part rotated (src/infer.cpp:1075-1084) ----
   for (int i = tid; i < lora; i += NT) q_s[i] = a.q_c[(size_t)h * lora + i];
   if (tid < rope / 2) {
@@ -578,7 +598,6 @@ __global__ __launch_bounds__(1024) void mla_head_kernel(const MlaHeadArgs A, con
   }
   __syncthreads();
   if (tl && tid == 0) tl[1] = wall_clock64();
-  const bool merged = A.flash_thresh > 0 && kv_len >= A.flash_thresh;  // uniform: mla_flash_kernel ran before us
   if (merged) {
     // out = sum_c e^(m_c - M) O_c / sum_c e^(m_c - M) l_c over the chunk partials of this head
     const int fcl = A.fl_chunk_len > 0 ? A.fl_chunk_len : MLA_FL_CHUNK(kv_len, A.fl_n_chunks);
@@ -619,7 +638,6 @@ __global__ __launch_bounds__(1024) void mla_head_kernel(const MlaHeadArgs A, con
     __syncthreads();
   } else {
   // ---- scores: 16 lanes per position, 2 positions per group and step ----
-  const int nj = lora >> 6;  // f16x4 loads per lane for the latent part (8 for lora 512)
   float qv[8][4], qr4[4];
 #pragma unroll
   for (int j = 0; j < 8; ++j)
@@ -629,18 +647,7 @@ __global__ __launch_bounds__(1024) void mla_head_kernel(const MlaHeadArgs A, con
   for (int i = 0; i < 4; ++i) qr4[i] = sl * 4 + i < rope ? q_s[lora + sl * 4 + i] : 0.f;
   const float inv = sqrtf((float)a.head_dim);
   for (int t0 = wave * 8; t0 < kv_len; t0 += NW * 8) {
-    h4 kc[2][8], kr[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int t = t0 + u * 4 + grp;
-      if (t < kv_len) {
-        const uint16_t* c = a.nope_cache + (size_t)t * lora;
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (j < nj) kc[u][j] = *reinterpret_cast<const h4*>(c + 64 * j + sl * 4);
-        if (sl * 4 < rope) kr[u] = *reinterpret_cast<const h4*>(a.rope_cache + (size_t)t * rope + sl * 4);
-      }
-    }
+    if (t0 != wave * 8) request_rows(t0);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int t = t0 + u * 4 + grp;
@@ -667,6 +674,8 @@ __global__ __launch_bounds__(1024) void mla_head_kernel(const MlaHeadArgs A, con
   }
   __syncthreads();
   // ---- softmax (src/infer.cpp:472-487) ----
+  // (the latent rows of the first value step requested before it: no gain - every barrier of the softmax is a fence that
+  // waits for them)
   float mx = -INFINITY;
   for (int t = tid; t < kv_len; t += NT) mx = fmaxf(mx, att[t]);
   mx = ad::block_max(mx, scratch, tid, NT);
