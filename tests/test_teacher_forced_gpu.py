@@ -65,8 +65,8 @@ def test_every_block_teacher_forced_on_the_oracle_stream(ctx, oracle, case):
     O.close()
 
 
-def _v3_full_width(mla, seed):
-    c = synth.preset("v3", "q2_k", mla, n_layers=2, first_k_dense_replace=1, max_seq_len=64)
+def _v3_full_width(mla, seed, quant="q2_k"):
+    c = synth.preset("v3", quant, mla, n_layers=2, first_k_dense_replace=1, max_seq_len=64)
     assert c.n_routed_experts == 256 and c.n_group == 8 and c.topk_group == 4 and c.n_active_routed == 8
     T = synth.random_block_model(c, seed=seed, tile_blocks=(1 << 21) + 12345)
     rng = np.random.default_rng(seed + 100)
@@ -79,11 +79,12 @@ def _v3_full_width(mla, seed):
 
 
 @pytest.mark.timeout(1500)
-@pytest.mark.parametrize("mla", [False, True], ids=["mha", "mla"])
-def test_v3_full_width_256_experts_teacher_forced(ctx, oracle, mla):
-    """BASELINE.json configs[3] at full width: 256 routed experts, 8 groups / 4 kept, top-8; 1 dense + 1 MoE block."""
+@pytest.mark.parametrize("mla,quant", [(False, "q2_k"), (True, "q2_k"), (False, "q3_k")], ids=["mha", "mla", "mha-q3_k"])
+def test_v3_full_width_256_experts_teacher_forced(ctx, oracle, mla, quant):
+    """BASELINE.json configs[3] at full width: 256 routed experts, 8 groups / 4 kept, top-8; 1 dense + 1 MoE block.  Q3_K at
+    the same width runs the other instantiation of every K-quant kernel (moe_ffn_kernel<Q3_K, 2, 2>, the generic row loops)."""
     import dsk
-    c, T = _v3_full_width(mla, seed=31)
+    c, T = _v3_full_width(mla, seed=31, quant=quant)
     M, O = dsk.Model(ctx, c, T), oracle.model(c, T)
     aud = teacher.BlockAuditor(oracle, c, T)
     emb = T["model.embed.weight"]

@@ -92,3 +92,25 @@ def test_repack_gpu_layout_planes_roundtrip(tmp_path):
             assert np.array_equal(get(name + ".sc").reshape(-1, 12), blocks[:, 96:108])
             assert np.array_equal(get(name + ".dm").reshape(-1, 2), blocks[:, 108:110])
         assert np.array_equal(get("model.layers.1.moegate.weight").view(np.float32), T["model.layers.1.moegate.weight"].data.reshape(-1))
+
+
+def test_random_block_checkpoints_are_valid_for_the_oracle():
+    """tools/synth.random_block_model (the full-width fixtures of tests/test_teacher_forced_gpu.py and bench.py's CPU leg):
+    random Q2_K / Q3_K blocks with chosen d decode to finite, unit-scale logits through the CPU oracle, and tiling a
+    tensor from a shorter random pattern keeps its shape and byte count."""
+    import numpy as np
+    from oracle import orc
+    from tools import synth
+    O_ = orc.Oracle()
+    for quant, bsz in (("q2_k", 84), ("q3_k", 110)):
+        c = synth.preset("tiny_v3", quant, False)
+        T = synth.random_block_model(c, seed=3)
+        Tt = synth.random_block_model(c, seed=3, tile_blocks=7)
+        for name, t in T.items():
+            assert Tt[name].data.shape == t.data.shape and Tt[name].quant == t.quant, name
+        w = T["model.layers.1.mlp.experts.w1.weight"] if "model.layers.1.mlp.experts.w1.weight" in T else next(t for n, t in T.items() if n.endswith("w1.weight"))
+        assert w.data.dtype == np.uint8 and w.data.shape[-1] % bsz == 0
+        O = O_.model(c, T)
+        lg = O.forward(5, 0)
+        assert np.all(np.isfinite(lg)) and 0.05 < float(lg.std()) < 20.0, (quant, float(lg.std()))
+        O.close()

@@ -440,6 +440,15 @@ def random_block_model(c: Cfg, seed: int = 0, tile_blocks: int = 0) -> Dict[str,
             if gen < nblk:
                 b = np.tile(b, ((nblk + gen - 1) // gen, 1))[:nblk]
             return Tens(b.reshape(*shape[:-1], -1), tuple(shape), QUANT_IDS["q2_k"])
+        if c.quant == "q3_k":  # hmask[32] | qs[64] | scales[12] (6-bit, any bytes are valid) | d f16 = 110 B (src/quant.h:70-76)
+            nblk = rows * (n // 256)
+            gen = nblk if tile_blocks <= 0 or nblk <= tile_blocks else tile_blocks
+            b = rng.integers(0, 256, (gen, 110), dtype=np.uint8)
+            d = (rng.uniform(0.5, 1.5, gen) / np.sqrt(n) / 43.0).astype(np.float16)  # rms of (q - 4 !h) * (scale - 32) ~ 43
+            b[:, 108:110] = d.view(np.uint8).reshape(-1, 2)
+            if gen < nblk:
+                b = np.tile(b, ((nblk + gen - 1) // gen, 1))[:nblk]
+            return Tens(b.reshape(*shape[:-1], -1), tuple(shape), QUANT_IDS["q3_k"])
         w = (rng.standard_normal(shape, dtype=np.float32) / np.sqrt(n)).astype(np.float32)
         return _encode(w, c.quant, c.block_size)
 
