@@ -328,6 +328,32 @@ extern "C" int dsk_measure_read_bw(dsk_ctx* ctx, size_t bytes, int iters, double
 // tools/kbench.py to pick launch geometry).  kind: 0 plain, 1 GLU pair, 2 or 3 per-slot MoE W2 + fused combine.
 // Weight sets are rotated through > 512 MB so that the 256 MB Infinity Cache cannot serve them.
 // ------------------------------------------------------------------------------------
+// The launch planner by itself (host logic, no GPU): the geometry gemv_plan picks for n_tasks equal (rows x n) matrices of
+// one activation group.  kind as in dsk_bench_gemv (0 plain, 1 GLU pair, 2/3 fused-combine tasks); out[8] = lanes per row,
+// R, U, waves per workgroup, grid, LDS bytes, activation groups, rows per workgroup step.
+extern "C" int dsk_plan_gemv(int quant, int rows, int n, int n_tasks, int kind, int act_mode, int target_wgs, int* out) {
+  if (!out || rows < 1 || n < 1 || n_tasks < 1 || n_tasks > GEMV_MAX_TASKS) DSK_FAIL(DSK_ERR_INVALID, "plan_gemv: bad argument");
+  GemvLaunch h;
+  memset(&h, 0, sizeof h);
+  h.quant = quant; h.glu = kind == 1; h.act = DSK_ACT_SILU; h.b0 = h.b1 = 128;
+  static float dummy_x[4], dummy_res[4];
+  static unsigned dummy_cnt[4];
+  static int8_t dummy_q[4];
+  for (int i = 0; i < n_tasks; ++i) {
+    GemvTask& T = h.t[h.n_tasks++];
+    T.qs = T.sc = T.hm = T.dm = reinterpret_cast<const uint8_t*>(dummy_q);  // never dereferenced: planning reads shapes only
+    if (kind == 1) T.qs2 = T.sc2 = T.hm2 = T.dm2 = T.qs;
+    T.rows = rows; T.n = n; T.local_experts = 1; T.act_mode = act_mode;
+    T.a_qs = dummy_q; T.a_f32 = dummy_x + (kind >= 2 ? i : 0); T.norm_w = dummy_x; T.eps = 1e-6f;
+  }
+  if (kind >= 2) { h.comb_x = dummy_res; h.comb_counter = dummy_cnt; }
+  DSK_TRY(gemv_plan(h, target_wgs > 0 ? target_wgs : 1024));
+  const int lpr = 1 << h.lpr_log2;
+  out[0] = lpr; out[1] = h.R; out[2] = h.U; out[3] = h.NW; out[4] = h.grid; out[5] = (int)h.lds_bytes; out[6] = h.n_groups;
+  out[7] = h.NW * (64 / lpr) * h.R;
+  return DSK_OK;
+}
+
 extern "C" int dsk_bench_gemv(dsk_ctx* ctx, int quant, int rows, int n, int n_tasks, int kind, int act_mode, int force_lpr,
                               int force_R, int force_U, int target_wgs, int iters, double* us_per_launch, double* bytes_per_launch) {
   DSK_TRY(begin(ctx));

@@ -149,6 +149,17 @@ def check(r):
         raise DskError(lib().dsk_last_error().decode())
 
 
+def plan_gemv(quant: int, rows: int, n: int, n_tasks: int = 1, kind: int = 0, act_mode: int = 2, target_wgs: int = 0) -> dict:
+    """The launch planner's geometry for n_tasks equal (rows x n) matrices (include/dsk.h dsk_plan_gemv; host only)."""
+    out = (C.c_int * 8)()
+    f = lib().dsk_plan_gemv
+    f.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_int)]
+    check(f(quant, rows, n, n_tasks, kind, act_mode, target_wgs, out))
+    keys = ("lanes_per_row", "R", "U", "waves", "grid", "lds_bytes", "groups", "rows_per_step")
+    return dict(zip(keys, list(out)))
+
+
+
 def _f(a):
     return a.ctypes.data_as(c_f)
 

@@ -314,6 +314,13 @@ int dsk_measure_read_bw(dsk_ctx* ctx, size_t bytes, int iters, double* gbps_out)
 int dsk_time_kernel_class(dsk_model* m, const char* name, int pos, int reps, double* us_per_launch,
                           double* bytes_per_launch, int* launches_per_token);
 
+/* Diagnostics, host only (no GPU needed): the geometry the launch planner picks for n_tasks equal (rows x n) matrices of
+ * one activation group; kind 0 plain, 1 GLU pair (w1 / w3), 2 / 3 tasks with the fused MoE combine; act_mode 0 ready
+ * Q8_K, 1 f32, 2 f32 + rmsnorm.  out[8] = lanes per row, rows per lane group (R), column steps in flight (U), waves per
+ * workgroup, grid, LDS bytes, activation groups, rows per workgroup step.  tests/test_host_logic.py pins the choices for
+ * the DeepSeek-V3 shapes. */
+int dsk_plan_gemv(int quant, int rows, int n, int n_tasks, int kind, int act_mode, int target_wgs, int* out);
+
 /* Diagnostics: time the GEMV kernel on device-resident synthetic weights (rotated through > 512 MB
  * so that the Infinity Cache cannot serve them).  kind: 0 plain, 1 GLU pair, 2 MoE accumulate over
  * n_tasks slots; act_mode: 0 ready Q8_K, 1 f32 (quantised in the prologue), 2 f32 + RMSNorm.

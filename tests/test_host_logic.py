@@ -77,3 +77,32 @@ def test_reference_loads_what_the_writer_wrote(ref, oracle):
     assert S.active_bytes(0) > 0
     S.close()
     M.close()
+
+
+def test_launch_planner_choices_for_the_deepseek_v3_shapes():
+    """gemv_plan (kernels_gemv.hip) is host logic: pin what it picks for the shapes of the headline model, so that a change
+    of the rules shows up here and not as a silent slowdown (the measurements behind each choice: DESIGN.md 4.1 / 7)."""
+    import dsk
+    Q2, Q3, F8 = 3, 4, 2
+    # first-stage projections: a small plain launch -> 64 lanes per row with a ragged second step, 16-wave workgroups
+    p = dsk.plan_gemv(Q2, 1536, 7168)
+    assert (p["lanes_per_row"], p["U"], p["waves"], p["grid"]) == (64, 2, 16, 256), p
+    # big 7168-wide launches keep the exact fit of 16 lanes per row (7 column steps: the straight-line pipelined form)
+    for rows, nt, kind in ((18432, 1, 1), (2048, 9, 1), (129280, 1, 0)):
+        p = dsk.plan_gemv(Q2, rows, 7168, nt, kind)
+        assert (p["lanes_per_row"], p["waves"], p["grid"], p["rows_per_step"]) == (16, 16, 256, 64), (rows, p)
+    assert dsk.plan_gemv(Q2, 2048, 7168, 9, 1)["U"] == 4 and dsk.plan_gemv(Q3, 2048, 7168, 9, 1)["U"] == 2  # Q3_K: 4 steps spill
+    # wo: 256 items = 4 steps of 64 lanes, one workgroup per CU; its input is the ready Q8_K vector (2.5 bytes / 2 values)
+    p = dsk.plan_gemv(Q2, 7168, 16384, 1, 0, 0)
+    assert (p["lanes_per_row"], p["U"], p["waves"], p["grid"]) == (64, 4, 16, 256) and p["lds_bytes"] == 16384 // 64 * 80, p
+    # second-stage projections: 24 items -> 8 lanes per row, 128 rows per step
+    p = dsk.plan_gemv(Q2, 24576, 1536)
+    assert (p["lanes_per_row"], p["rows_per_step"], p["grid"]) == (8, 128, 256), p
+    # the two-launch experts' W2 with the fused combine: one activation group per task, few tall row groups
+    p = dsk.plan_gemv(Q2, 7168, 2048, 9, 3, 1)
+    assert (p["lanes_per_row"], p["R"], p["waves"], p["groups"]) == (8, 2, 4, 9) and p["grid"] == 9 * 112, p
+    # a K-quant row that no power-of-two lane count divides within the waste bound is refused, not mis-planned
+    with pytest.raises(dsk.DskError):
+        dsk.plan_gemv(Q2, 64, 300)
+    with pytest.raises(dsk.DskError):
+        dsk.plan_gemv(Q2, 64, 7168, 13)  # more tasks than a launch descriptor holds
