@@ -44,7 +44,7 @@ def csrc_sha() -> str:
     h = hashlib.sha256()
     d = os.path.join(ROOT, "deepseek.cpp_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h", ".cpp")):
+        if f.endswith((".hip", ".h", ".cpp")) or f == "Makefile":  # the Makefile carries code-generation flags
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]

@@ -110,7 +110,7 @@ def main():
         h = hashlib.sha256()
         cs_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "deepseek.cpp_amd", "csrc")
         for fn in sorted(os.listdir(cs_dir)):
-            if fn.endswith((".hip", ".h", ".cpp")):
+            if fn.endswith((".hip", ".h", ".cpp")) or fn == "Makefile":
                 h.update(fn.encode())
                 h.update(open(os.path.join(cs_dir, fn), "rb").read())
         json.dump(dict(note=a.note, csrc_sha=h.hexdigest()[:16], calibration=dict(kernel="read_bw_kernel (16 B/lane streaming read of 4 GiB)", bytes_per_fetch_size_unit=cal),
