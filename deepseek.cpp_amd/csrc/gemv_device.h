@@ -18,10 +18,12 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 #define DEV __device__ __forceinline__
 
-// (hipcc selects the two-operand v_dot4c for this builtin and zeroes the accumulator of every chain with a v_mov: 4 of the
-// ~75 instructions per Q2_K item.  The three-operand v_dot4_i32_i8 with a literal 0 through inline asm is NOT an option:
-// the compiler's hazard recogniser cannot see a DOT inside an asm statement and omits the wait states gfx950 needs
-// between a DOT write and a different opcode's read of the same register - measured: garbage, then a memory fault.)
+// hipcc would select the two-operand v_dot4c for this builtin and zero the accumulator of every chain with a v_mov: 4 of
+// ~75 instructions per Q2_K item in VALU-bound kernels.  The Makefile therefore builds the kernels without the dot6-insts
+// target feature (NODOT4C): the compiler then picks the three-operand v_dot4_i32_i8 with the literal 0 by itself, hazards
+// handled.  (The same instruction through inline asm is NOT an option: the hazard recogniser cannot see a DOT inside an
+// asm statement and omits the wait states gfx950 needs between a DOT write and a different opcode's read of the same
+// register - measured: garbage, then a memory fault.)
 DEV int sdot4(u32 a, u32 b, int c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, false); }
 DEV float h2f(u32 bits16) { return (float)__builtin_bit_cast(_Float16, (unsigned short)bits16); }
 // NB: __builtin_bit_cast applied directly to an ext_vector component (w.y) is miscompiled by hipcc 7.2

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(1024) void moe_ffn_kernel(const MoeFfnArgs a) {
       // to the exit this launch moves its 61 MB (W2 + 256 copies of the hidden vectors) at the same ~18 GB/s per CU as
       // phase A moves the w1/w3 rows.  With ALL W2 rows requested before the hand-off (8 us ahead of their use) the
       // multiplies after the staging still take 5.4 us: they are VALU-bound - 252 virtual rows x 32 items per workgroup at
-      // ~85 wave instructions per item on 4 SIMDs - and nothing is left to stream underneath them.)
+      // ~70-75 wave instructions per item on 4 SIMDs - and nothing is left to stream underneath them.)
       // the first job's weights are requested BEFORE the hand-off: they stream while the slots' producers finish
       ChunkKQ<QT, 1, UB, false> c0, c1;
       Job J = make_job(wave < n_jobs ? wave : 0);
