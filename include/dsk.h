@@ -332,7 +332,7 @@ int dsk_bench_gemv(dsk_ctx* ctx, int quant, int rows, int n, int n_tasks, int ki
 /* Diagnostics: 8 wall-clock stamps (100 MHz ticks: entry, staged, phase A done, hand-off passed, hidden vectors staged,
    rows done, exit, unused) per workgroup of the LAST fused routed-expert launch; needs DSK_MOE_TIMELINE=1 in the
    environment when the model is created. */
-int dsk_model_get_timeline(dsk_model* m, int kind, unsigned long long* out, int n_wgs);  /* kind: 0 first-stage projections, 1 per-head attention, 2 wo, 3 shared expert w1/w3 (rider), 4 fused routed experts, 5 router */
+int dsk_model_get_timeline(dsk_model* m, int kind, unsigned long long* out, int n_wgs);  /* kind: 0 first-stage projections, 1 per-head attention, 2 wo, 3 shared expert w1/w3 (rider), 4 fused routed experts, 5 router, 6 MLA long-context scores / values; needs DSK_TIMELINE=1 in the environment when the model is created; tools/timeline.py names the stamps */
 int dsk_model_get_moe_timeline(dsk_model* m, unsigned long long* out, int n_wgs);
 
 /* Router (F32 GEMV + rmsnorm prologue) + moe_gate micro-benchmark on synthetic weights; flags: 0 = the
