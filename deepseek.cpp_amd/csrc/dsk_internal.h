@@ -136,6 +136,9 @@ struct GemvLaunch {
   // per group) runs  x[row] += w_k * out_k[row]  in k order, then + shared (src/infer.cpp:874-877,900-903)
   float* comb_x;
   unsigned* comb_counter;
+  int compact_absent; // expert-sharded w1/w3 launch (one activation group): the group's virtual row space is compacted ON THE
+                      // DEVICE over the tasks whose expert lives on this GPU, so that all workgroups share the present rows
+                      // (with the static row space an absent expert's workgroups exit and the launch takes as long as on one GPU)
   int zero_absent;    // expert-sharded W2 launch: a task whose expert lives on another GPU stores zeros (the sum
                       // all-reduce then needs no separate zero-fill of the slot buffer)
   int comb_geometry;  // plan exactly like a fused-combine launch (the expert-sharded W2 launch: same

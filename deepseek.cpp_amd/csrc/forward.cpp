@@ -343,6 +343,7 @@ int build_plans(dsk_model* m) {
         bytes += 2 * weight_bytes_2d(m, wq, shared_n, c.dim) + 4.0 * shared_n;
       }
       h.algo_bytes = bytes;
+      h.compact_absent = m->ctx->world > 1 && getenv("DSK_NO_COMPACT") == nullptr;
       DSK_TRY(add_plan(m, h, &m->lp_w13[l]));
     }
     {  // 9. per-slot W2 into eout[slot]; 1 GPU: the combine rides in the same launch; sharded: all-reduce first

@@ -126,7 +126,29 @@ DEV void gemv_body(const GemvLaunch* __restrict__ Lp, const void* h_a0, const vo
 #endif
 
   // this workgroup's share of the group's virtual rows, in multiples of part_unit
-  const int vtotal = bd ? L.t[0].rows : L.t[t1 - 1].vrow_end;
+  const bool compact = L.compact_absent && !bd && L.comb_x == nullptr;  // sharded experts: only the present tasks' rows count
+  int vtotal = bd ? L.t[0].rows : L.t[t1 - 1].vrow_end;
+  int c_rows = 0, c_base = 0;  // lane k: rows of the group's task k if its expert lives here, and their first compacted row
+  if (compact) {
+    // lane k looks at task k: every expert id is read in ONE round trip (task by task it is a dependent load each: the
+    // compacted launch took 21 us instead of 18)
+    if (lane < t1 - t0) {
+      const GemvTask& Tk = L.t[t0 + lane];
+      bool here = true;
+      if (Tk.e_qs != 0) {
+        const int le = (Tk.expert_ids ? Tk.expert_ids[Tk.slot] : Tk.slot) - Tk.expert_base;
+        here = le >= 0 && le < Tk.local_experts;
+      }
+      c_rows = here ? Tk.vrow_end - Tk.vrow_begin : 0;
+    }
+    vtotal = 0;
+#pragma unroll
+    for (int j = 0; j < GEMV_MAX_TASKS; ++j) {
+      const int rj = __builtin_amdgcn_readlane(c_rows, j);
+      if (lane == j) c_base = vtotal;
+      vtotal += rj;
+    }
+  }
   const int unit = L.part_unit;
   const long long units = (vtotal + unit - 1) / unit;
   const int r_lo = (int)(units * wi / nwg) * unit;
@@ -138,8 +160,14 @@ DEV void gemv_body(const GemvLaunch* __restrict__ Lp, const void* h_a0, const vo
   bool first = true;
 
   for (int ti = t0; ti < t1; ++ti) {
+    int vb, ve;
+    if (compact) {  // (before the task's descriptor is touched: an absent task costs two lane reads)
+      vb = __builtin_amdgcn_readlane(c_base, ti - t0);
+      ve = vb + __builtin_amdgcn_readlane(c_rows, ti - t0);
+      if (r_lo >= ve || r_hi <= vb) continue;
+    }
     const GemvTask T = task_of(ti);
-    const int vb = T.vrow_begin, ve = T.vrow_end;
+    if (!compact) { vb = T.vrow_begin; ve = T.vrow_end; }
     const int lo = (r_lo > vb ? r_lo : vb) - vb, hi = (r_hi < ve ? r_hi : ve) - vb;
     if (lo >= hi) continue;
     const WPtr P = resolve(T);

@@ -22,6 +22,7 @@ python tools/prof_summary.py --trace gpurun_out/trace_mha --pmc gpurun_out/pmc -
 python tools/prof_summary.py --trace gpurun_out/trace_mla --out gpurun_out/${R}_mla --note "MI355X, round 2 final build, full 61-block DeepSeek-V3 Q2_K, MLA path" >> gpurun_out/${R}_summary.log 2>&1
 python tools/prof_summary.py --trace gpurun_out/trace_kv4096 --out gpurun_out/${R}_kv4096 --note "MI355X, round 2 final build, DeepSeek-V3 Q2_K MHA, 6 decode steps at kv_len 4096 (tools/kv_trace.py)" >> gpurun_out/${R}_summary.log 2>&1
 python tools/kbench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_kbench.txt
+for w in 2 4 8; do python bench.py --dry-shard 0/$w --steps 20 --warmup 4 --no-cpu-baseline --no-extras 2>&1 | grep '^{' > gpurun_out/${R}_dry_shard_0of$w.json; done
 python tools/timeline.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_timeline_mha.txt
 python tools/timeline.py --attn mla 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_timeline_mla.txt
 python tools/timeline.py --attn mla --kv 4096 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_timeline_mla_kv4096.txt
