@@ -126,7 +126,9 @@ DEV void gemv_body(const GemvLaunch* __restrict__ Lp, const void* h_a0, const vo
 #endif
 
   // this workgroup's share of the group's virtual rows, in multiples of part_unit
-  const bool compact = L.compact_absent && !bd && L.comb_x == nullptr;  // sharded experts: only the present tasks' rows count
+  // sharded experts: only the present tasks' rows count.  GLU instantiations only (the sharded w1/w3 launch is one): in the
+  // plain ones the code below folds away (with it in, wo and the first-stage projections were 0.25 us slower each)
+  const bool compact = GLU && L.compact_absent && !bd && L.comb_x == nullptr;
   int vtotal = bd ? L.t[0].rows : L.t[t1 - 1].vrow_end;
   int c_rows = 0, c_base = 0;  // lane k: rows of the group's task k if its expert lives here, and their first compacted row
   if (compact) {
