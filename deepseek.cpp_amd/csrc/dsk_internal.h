@@ -7,6 +7,16 @@
 #include "../../include/dsk.h"
 
 #define QK_K 256
+// A/B knobs of the measurement tools (tools/kbench.py, tools/ab_build.sh): read from the environment ONLY in -DDSK_AB
+// builds.  The shipped library never looks at the environment: a stray variable must not change kernels or numerics
+// (every model-level choice is a dsk_model_set_option key).
+#ifdef DSK_AB
+#include <stdlib.h>
+static inline const char* dsk_ab_env(const char* k) { return getenv(k); }
+#else
+static inline const char* dsk_ab_env(const char*) { return nullptr; }
+#endif
+#define DSK_TL_WGS 1024  // workgroups per kind a timeline region holds (8 stamps each; engine.h timeline_of): larger grids stamp their first 1024
 
 // ---- error plumbing (never abort across the boundary; include/dsk.h conventions) ----
 void dsk_set_error(int code, const char* fmt, ...);
@@ -190,6 +200,7 @@ struct MoeFfnArgs {
   unsigned* err;         // host-visible: set when a bounded spin gives up
   int lprA_log2, lprB_log2;  // lanes per row of the two halves (= the two-launch plans': bit-identical results)
   int UA, rows_wg, lds_a, lds_b, lds_o, grid;  // filled by moe_ffn_plan
+  int spin_limit;        // polls before the hand-off wait gives up (0: 2^20); < 0: fault injection (workgroup 0 reports a give-up)
   unsigned long long* timeline;  // debug (DSK_MOE_TIMELINE=1): 8 wall-clock stamps per workgroup (100 MHz ticks)
   int8_t* tap_qs;        // parity taps (dsk_model_run_block): slot s's staged hidden vector at s * tap_stride
   float* tap_d;

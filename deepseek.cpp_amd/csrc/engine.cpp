@@ -161,8 +161,9 @@ extern "C" int dsk_comm_init(dsk_ctx* c, const void* uid128, int rank, int world
   if (!c || world < 1 || rank < 0 || rank >= world) DSK_FAIL(DSK_ERR_INVALID, "comm_init: rank %d / world %d", rank, world);
   c->rank = rank;
   c->world = world;
-  if (world == 1) return DSK_OK;
-  if (!uid128) return DSK_OK;  // dry run of one shard: no communicator, the all-reduce is skipped
+  if (!uid128) return DSK_OK;  // world > 1: dry run of one shard (no communicator, the all-reduce is skipped)
+  // (world == 1 WITH a uid: a one-rank communicator - the exchange of a model created with the option
+  //  "force_exchange" then really calls RCCL on the engine stream: tests/test_comm_gpu.py)
   HIP_TRY(hipSetDevice(c->device));
   ncclUniqueId id;
   memcpy(&id, uid128, 128);
@@ -212,7 +213,55 @@ extern "C" int dsk_model_create(dsk_ctx* ctx, const dsk_config* cfg, dsk_model**
   m->head_dim = c.qk_nope_head_dim + c.qk_rope_head_dim;
   m->L.resize(c.n_layers);
   for (int l = 0; l < c.n_layers; ++l) m->L[l].is_moe = c.n_routed_experts > 0 && l >= c.first_k_dense_replace;
+  m->mha_split_min = 0;  // 0: MHA_SPLIT_MIN_KV (finalize)
+#ifdef DSK_AB
+  // A/B builds only (tools/ab_build.sh): the old environment knobs seed the options, so that one command line can flip a
+  // kernel choice in bench.py / tools/*.py without touching their code.  The shipped library never reads the environment.
+  auto env_i = [](const char* k, int dflt) { const char* v = getenv(k); return v ? atoi(v) : dflt; };
+  if (getenv("DSK_NO_FUSE_MOE")) m->fuse_moe = false;
+  if (getenv("DSK_NO_FUSE_SHARED")) m->ride_shared = false;
+  if (getenv("DSK_NO_KVWRITE_RIDE")) m->ride_kvwrite = false;
+  if (getenv("DSK_NO_COMPACT")) m->compact_absent = false;
+  m->att_q8_in_wo = env_i("DSK_ATT_Q8_IN_WO", 0) != 0;
+  m->rider_fill = env_i("DSK_RIDER_FILL", m->rider_fill);
+  m->mla_flash_min_kv = std::max(32, env_i("DSK_MLA_FLASH_MIN", m->mla_flash_min_kv));
+  m->mha_split_min = env_i("DSK_MHA_SPLIT_MIN", 0);
+  if (getenv("DSK_MOE_TIMELINE") || getenv("DSK_TIMELINE")) m->want_timeline = true;
+#endif
   *out = m;
+  return DSK_OK;
+}
+
+// Per-model options (include/dsk.h).  Everything here selects kernels, launch shapes or diagnostics; all of it must be
+// set between dsk_model_create and dsk_model_finalize (the launch plans are built there).
+extern "C" int dsk_model_set_option(dsk_model* m, const char* key, int value) {
+  if (!m || !key) DSK_FAIL(DSK_ERR_INVALID, "set_option: null argument");
+  if (m->finalized) DSK_FAIL(DSK_ERR_STATE, "set_option('%s') after finalize", key);
+  const std::string k(key);
+  if (k == "fuse_moe") m->fuse_moe = value != 0;
+  else if (k == "fuse_shared") m->ride_shared = value != 0;
+  else if (k == "ride_kvwrite") m->ride_kvwrite = value != 0;
+  else if (k == "att_q8_in_wo") m->att_q8_in_wo = value != 0;
+  else if (k == "compact_absent") m->compact_absent = value != 0;
+  else if (k == "rider_fill") { if (value < 1 || value > 16) DSK_FAIL(DSK_ERR_INVALID, "set_option: rider_fill %d", value); m->rider_fill = value; }
+  else if (k == "mla_flash_min") m->mla_flash_min_kv = std::max(32, value);
+  else if (k == "mha_split_min") m->mha_split_min = std::max(0, value);
+  else if (k == "timeline") m->want_timeline = value != 0;
+  else if (k == "moe_spin_limit") m->moe_spin_limit = value;
+  else if (k == "force_exchange") m->force_exchange = value != 0;
+  else if (k == "graph_with_comm") m->graph_with_comm = value != 0;
+  else DSK_FAIL(DSK_ERR_INVALID, "set_option: unknown option '%s'", key);
+  return DSK_OK;
+}
+
+extern "C" int dsk_model_get_info(dsk_model* m, const char* key, int* value) {
+  if (!m || !key || !value) DSK_FAIL(DSK_ERR_INVALID, "get_info: null argument");
+  const std::string k(key);
+  if (k == "handoff_fallbacks") *value = m->handoff_fallbacks;
+  else if (k == "fused_moe_layers") { int n = 0; for (auto& a : m->moe_ffn) n += a.grid > 0; *value = n; }
+  else if (k == "graph_captured") { int n = 0; for (auto g : m->graph) n += g != nullptr; *value = n; }
+  else if (k == "exchange_calls") *value = m->exchange_calls;
+  else DSK_FAIL(DSK_ERR_INVALID, "get_info: unknown key '%s'", key);
   return DSK_OK;
 }
 
@@ -423,8 +472,9 @@ int bind_src(dsk_model* m, int role, int layer, int quant, const int32_t shape[4
   return upload_tensor(m->ctx, *t, src);
 }
 
-// the plane layout persisted offline (tools/repack.py).  No staging buffer, no repack kernel: every plane
-// of the rank's experts is one contiguous byte range of the file going straight into its device plane.
+// the plane layout persisted offline (tools/repack.py).  No DEVICE staging buffer and no repack kernel:
+// every plane of the rank's experts is one contiguous byte range of the file that travels through the pinned host ring
+// (stage_copy) straight into its device plane.
 int bind_planes(dsk_model* m, int role, int layer, int quant, const HostSrc planes[4], const size_t bytes[4]) {
   if (!m) DSK_FAIL(DSK_ERR_INVALID, "bind: null argument");
   if (m->finalized) DSK_FAIL(DSK_ERR_STATE, "bind after finalize");
@@ -622,7 +672,6 @@ extern "C" int dsk_model_finalize(dsk_model* m) {
   HIP_TRY(hipHostMalloc((void**)&m->logits_host, (size_t)c.vocab_size * 4, hipHostMallocDefault));
   memset(m->sp_host, 0, sizeof(StepParams));
   if (c.use_mla && c.kv_lora_rank == 512 && c.qk_rope_head_dim == 64) {  // long-context MLA on the matrix cores
-    if (getenv("DSK_MLA_FLASH_MIN")) m->mla_flash_min_kv = std::max(32, atoi(getenv("DSK_MLA_FLASH_MIN")));
     HIP_TRY(hipMalloc((void**)&m->fl_part_o, (size_t)64 * c.n_heads * c.kv_lora_rank * 4));
     HIP_TRY(hipMalloc((void**)&m->fl_part_ml, (size_t)64 * c.n_heads * 8));
     m->scratch_bytes += (double)64 * c.n_heads * (c.kv_lora_rank * 4 + 8);
@@ -631,7 +680,7 @@ extern "C" int dsk_model_finalize(dsk_model* m) {
     int S = 256 / std::max(1, c.n_heads);
     S = std::max(1, std::min(S, MHA_SPLIT_MAX));
     m->mha_split = S;
-    m->mha_split_min = getenv("DSK_MHA_SPLIT_MIN") ? atoi(getenv("DSK_MHA_SPLIT_MIN")) : MHA_SPLIT_MIN_KV;
+    if (m->mha_split_min <= 0) m->mha_split_min = MHA_SPLIT_MIN_KV;  // option "mha_split_min" overrides
     if (m->mha_split_min < 16 * S) m->mha_split_min = 16 * S;  // every split keeps >= 16 positions (the sink rows stay in split 0)
     if (S > 1) {
       const size_t pf = (size_t)c.n_heads * S * (c.v_head_dim + 2) * 4;
@@ -655,14 +704,10 @@ extern "C" int dsk_model_finalize(dsk_model* m) {
   HIP_TRY(hipMemset(m->moe_ctr, 0, MOE_CTR_WORDS * 4));
   HIP_TRY(hipHostMalloc((void**)&m->err_host, 64, hipHostMallocDefault));
   memset(m->err_host, 0, 64);
-  m->fuse_moe = getenv("DSK_NO_FUSE_MOE") == nullptr;
-  m->att_q8_in_wo = getenv("DSK_ATT_Q8_IN_WO") != nullptr && atoi(getenv("DSK_ATT_Q8_IN_WO")) != 0;
-  if (getenv("DSK_MOE_TIMELINE") || getenv("DSK_TIMELINE")) {
-    HIP_TRY(hipMalloc((void**)&m->moe_timeline, 8 * 1024 * 8 * 8));
-    HIP_TRY(hipMemset(m->moe_timeline, 0, 8 * 1024 * 8 * 8));
+  if (m->want_timeline) {
+    HIP_TRY(hipMalloc((void**)&m->moe_timeline, (size_t)8 * DSK_TL_WGS * 8 * 8));
+    HIP_TRY(hipMemset(m->moe_timeline, 0, (size_t)8 * DSK_TL_WGS * 8 * 8));
   }
-  m->ride_shared = getenv("DSK_NO_FUSE_SHARED") == nullptr;    // A/B and test knobs: the ride-along launches can be
-  m->ride_kvwrite = getenv("DSK_NO_KVWRITE_RIDE") == nullptr;  // switched back to separate launches per model
   DSK_TRY(build_plans(m));
   HIP_TRY(hipDeviceSynchronize());
   m->finalized = true;
@@ -717,9 +762,14 @@ extern "C" int dsk_model_destroy(dsk_model* m) {
   if (m->logits_host) hipHostFree(m->logits_host);
   for (auto& k : m->ktimes)
     for (auto& e : k.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+  dsk_ctx* ctx = m->ctx;
   delete m;
+  ctx_model_released(ctx);  // frees the context if dsk_ctx_destroy was called while this model was alive
   return DSK_OK;
 }
+
+// diagnostics for the life-cycle tests: models alive on a context
+extern "C" int dsk_ctx_live_models(dsk_ctx* c) { return c ? c->live_models : -1; }
 
 // algorithmic bytes of one forward (corrected analogue of Model::active_bytes, src/model.cpp:885-901)
 extern "C" double dsk_model_active_bytes(const dsk_model* m, int pos) {

@@ -106,7 +106,18 @@ struct dsk_model {
   std::vector<GemvLaunch> plans;
   GemvLaunch* plans_dev = nullptr;
   std::vector<int> lp_qkv_a, lp_qkv_b, lp_wv_b, lp_wo, lp_w13, lp_w2;  // per-layer indices into plans (-1: none)
-  bool ride_shared = true, ride_kvwrite = true;  // DSK_NO_FUSE_SHARED / DSK_NO_KVWRITE_RIDE at model creation switch them off
+  bool ride_shared = true, ride_kvwrite = true;  // options "fuse_shared" / "ride_kvwrite" (dsk_model_set_option)
+  // ---- dsk_model_set_option (include/dsk.h): everything that selects kernels or changes numerics is an explicit,
+  // per-model option; the environment is read only in -DDSK_AB builds (A/B tooling), never by the shipped library
+  int rider_fill = 4;              // "rider_fill": workgroup fill divisor of the shared expert's rider (forward.cpp)
+  bool compact_absent = true;      // "compact_absent": expert-sharded w1/w3 launch compacts its row space on the device
+  bool want_timeline = false;      // "timeline": in-kernel wall-clock stamps (dsk_model_get_timeline)
+  int moe_spin_limit = 0;          // "moe_spin_limit": polls before the fused expert launch's hand-off gives up (0: default 2^20; < 0: fault injection - workgroup 0 reports a give-up)
+  bool force_exchange = false;     // "force_exchange": run the expert-sharded code path (two-launch form, RCCL exchange, combine launch) at world == 1 too
+  bool graph_with_comm = false;    // "graph_with_comm": capture the sharded step into a hipGraph as well (default: eager)
+  int exchange_calls = 0;          // RCCL collectives enqueued by this model (eager path) - diagnostics
+  int handoff_fallbacks = 0;       // times a hand-off give-up switched this model to the two-launch form (dsk_model_get_info)
+  bool sharded() const { return ctx->world > 1 || force_exchange; }
   std::vector<int> lp_sh13;  // shared expert's w1/w3 GLU riding in the router launch (-1: it is a task of lp_w13)
   // routed experts in one launch (kernels_moe.hip); grid == 0: the layer keeps the two-launch form (lp_w13, lp_w2)
   std::vector<MoeFfnArgs> moe_ffn;
@@ -116,7 +127,7 @@ struct dsk_model {
   // DSK_TIMELINE=1 (debug): 8 wall-clock stamps per workgroup of the LAST launch of each kind in a token;
   // kind 0 first-stage projections, 1 per-head attention, 2 wo, 3 router + shared expert, 4 fused routed experts
   unsigned long long* moe_timeline = nullptr;  // base of [8 kinds][1024 workgroups][8]
-  unsigned long long* timeline_of(int kind) const { return moe_timeline ? moe_timeline + (size_t)kind * 8192 : nullptr; }
+  unsigned long long* timeline_of(int kind) const { return moe_timeline ? moe_timeline + (size_t)kind * DSK_TL_WGS * 8 : nullptr; }
   unsigned* err_host = nullptr;    // pinned, device-visible: bounded spins report here
   int lp_head = -1;
   std::vector<MlaHeadArgs> mla_head;   // per layer (MLA path)

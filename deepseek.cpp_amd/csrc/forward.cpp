@@ -307,13 +307,13 @@ int build_plans(dsk_model* m) {
       double bytes = K * e13 + c.dim * 8.0 + 4.0 * K * mi;
       // 1 GPU, K-quants: the shared expert's w1/w3 rides in the router launch (router_shared_kernel) instead
       bool ride = false;
-      if (c.n_shared_experts > 0 && kq && c.dim % 256 == 0 && m->ctx->world == 1 && m->ride_shared) {
+      if (c.n_shared_experts > 0 && kq && c.dim % 256 == 0 && !m->sharded() && m->ride_shared) {
         GemvLaunch hs;
         memset(&hs, 0, sizeof hs);
         hs.quant = wq; hs.glu = 1; hs.force_NW = 16;
         // 128 quarter-filled workgroups next to the router's 128: at 64 the rider was bound by what ONE CU streams
         // (~24 GB/s: 14.5 MB / 64 CUs = 9 us) and the launch by the rider (13.7 -> 12.5 us)
-        hs.fill_div = getenv("DSK_RIDER_FILL") ? atoi(getenv("DSK_RIDER_FILL")) : 4;
+        hs.fill_div = m->rider_fill;  // option "rider_fill"
         GemvTask& T = hs.t[hs.n_tasks++];
         task_weights(T, L.t[DSK_ROLE_SHARED_W1]);
         task_weights2(T, L.t[DSK_ROLE_SHARED_W3]);
@@ -343,7 +343,7 @@ int build_plans(dsk_model* m) {
         bytes += 2 * weight_bytes_2d(m, wq, shared_n, c.dim) + 4.0 * shared_n;
       }
       h.algo_bytes = bytes;
-      h.compact_absent = m->ctx->world > 1 && getenv("DSK_NO_COMPACT") == nullptr;
+      h.compact_absent = m->ctx->world > 1 && m->compact_absent;  // option "compact_absent"
       DSK_TRY(add_plan(m, h, &m->lp_w13[l]));
     }
     {  // 9. per-slot W2 into eout[slot]; 1 GPU: the combine rides in the same launch; sharded: all-reduce first
@@ -365,14 +365,14 @@ int build_plans(dsk_model* m) {
         T.out = m->eout + (size_t)K * c.dim; T.epilogue = EPI_STORE;
         bytes += weight_bytes_2d(m, wq, c.dim, shared_n) + 4.0 * shared_n + 4.0 * c.dim;
       }
-      if (m->ctx->world == 1) { h.comb_x = m->x; h.comb_counter = m->comb_counter; }
+      if (!m->sharded()) { h.comb_x = m->x; h.comb_counter = m->comb_counter; }
       else { h.comb_geometry = 1; h.zero_absent = 1; }
       h.algo_bytes = bytes;
       DSK_TRY(add_plan(m, h, &m->lp_w2[l]));
     }
     // 8+9 in ONE launch (kernels_moe.hip): K-quants, one GPU, the shared expert's w1/w3 riding in the router launch
     // (or no shared expert).  Same lanes per row as the two plans above => bit-identical results.
-    if (kq && m->ctx->world == 1 && m->fuse_moe && c.dim % 256 == 0 && (c.n_shared_experts == 0 || m->lp_sh13[l] >= 0) && K <= 16) {
+    if (kq && !m->sharded() && m->fuse_moe && c.dim % 256 == 0 && (c.n_shared_experts == 0 || m->lp_sh13[l] >= 0) && K <= 16) {
       MoeFfnArgs a;
       memset(&a, 0, sizeof a);
       a.quant = wq;
@@ -393,6 +393,7 @@ int build_plans(dsk_model* m) {
       a.slot_ctr = m->moe_ctr;
       a.n_experts = c.n_routed_experts;
       a.err = m->err_host;
+      a.spin_limit = m->moe_spin_limit;
       a.timeline = m->timeline_of(4);
       a.lprA_log2 = m->plans[m->lp_w13[l]].lpr_log2;
       a.lprB_log2 = m->plans[m->lp_w2[l]].lpr_log2;
@@ -558,7 +559,7 @@ static int ffn(dsk_model* m, int l) {
   } else {
     PROFILED("router_gate", (double)E * c.dim * 4 + c.dim * 8.0, launch_router_gate(st, r));
   }
-  const bool exchange = m->ctx->world > 1 && !m->class_filter;  // (class timing enqueues one kernel class only)
+  const bool exchange = m->sharded() && !m->class_filter;  // (class timing enqueues one kernel class only)
   if (m->moe_ffn[l].grid > 0) {  // routed experts (+ the shared expert's W2) + combine: one launch
     MoeFfnArgs a = m->moe_ffn[l];
     if (m->stage_layer == l && m->tap_qs) {
@@ -585,11 +586,12 @@ static int ffn(dsk_model* m, int l) {
   }
   DSK_TRY(run_plan(m, "gemv_experts_w13", m->lp_w13[l]));
   DSK_TRY(run_plan(m, "gemv_experts_w2", m->lp_w2[l]));
-  if (exchange || (m->ctx->world > 1 && m->class_filter)) {
+  if (exchange || (m->sharded() && m->class_filter)) {
     // every routed slot is non-zero on exactly one rank: a sum all-reduce is exact and order-independent
     if (m->ctx->comm && exchange) {  // (comm is null only in a single-rank dry run of a shard, dsk_comm_init with uid = NULL)
       ncclResult_t rr = ncclAllReduce(m->eout, m->eout, (size_t)K * c.dim, ncclFloat, ncclSum, m->ctx->comm, st);
       if (rr != ncclSuccess) DSK_FAIL(DSK_ERR_COMM, "ncclAllReduce: %s", ncclGetErrorString(rr));
+      m->exchange_calls++;
     }
     PROFILED("moe_combine", (double)c.dim * (K + 3) * 4,
              launch_moe_combine(st, m->x, m->eout, m->route_w + (size_t)l * K, K, c.n_shared_experts > 0, c.dim));
@@ -637,7 +639,25 @@ static int check_forward_args(dsk_model* m, int token, int pos, int mode, float*
   return DSK_OK;
 }
 
-static int run_token(dsk_model* m, int token, int pos, int mode) {
+// A bounded in-kernel spin gave up (kernels_moe.hip): the results of the work just synchronised are invalid.  Clears the
+// flag, re-arms the arrival counters (unknown state), and retires the fused expert launch: every MoE layer falls back to
+// its two-launch plans (still built: lp_w13 / lp_w2), captured graphs are dropped.  Returns whether that happened.
+static bool handoff_gave_up(dsk_model* m) {
+  if (!m->err_host || !*m->err_host) return false;
+  *m->err_host = 0;
+  hipMemset(m->moe_ctr, 0, MOE_CTR_WORDS * 4);
+  hipMemset(m->comb_counter, 0, (size_t)m->c.dim * 4);
+  for (auto& a : m->moe_ffn) a.grid = 0;
+  for (int i = 0; i < 8; ++i) {
+    if (m->graph[i]) hipGraphExecDestroy(m->graph[i]);
+    m->graph[i] = nullptr;
+    m->graph_primed[i] = false;
+  }
+  m->handoff_fallbacks++;
+  return true;
+}
+
+static int run_token(dsk_model* m, int token, int pos, int mode, bool retried = false) {
   HIP_TRY(hipSetDevice(m->ctx->device));
   hipStream_t st = m->ctx->stream;
   DSK_TRY(fill_step_params(m, token, pos));
@@ -646,7 +666,7 @@ static int run_token(dsk_model* m, int token, int pos, int mode) {
   // A sharded model (real communicator) is enqueued eagerly: measured on MI355X an eager stream of these
   // launches is as fast as the graph replay (the host stays ~10 launches ahead), and it keeps RCCL's
   // lazily initialised collectives out of stream capture.
-  const bool graphable = m->use_graph && !m->trace && !m->profiling && !m->ctx->comm;
+  const bool graphable = m->use_graph && !m->trace && !m->profiling && (!m->ctx->comm || m->graph_with_comm);
   // the long-context MLA regime enqueues one more launch per block: its own captured graph
   const bool long_mla = m->fl_part_o && m->sp_host->kv_len >= m->mla_flash_min_kv;
   // ... and so does the long-context MHA regime (split contexts: a different grid)
@@ -675,11 +695,12 @@ static int run_token(dsk_model* m, int token, int pos, int mode) {
   }
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipGetLastError());
-  if (m->err_host && *m->err_host) {  // a bounded in-kernel spin gave up (kernels_moe.hip): the step's results are invalid
-    *m->err_host = 0;
-    hipMemset(m->moe_ctr, 0, MOE_CTR_WORDS * 4);  // the arrival counters are in an unknown state: re-arm them
-    hipMemset(m->comb_counter, 0, (size_t)m->c.dim * 4);
-    DSK_FAIL(DSK_ERR_HIP, "forward: an in-kernel hand-off timed out");
+  if (handoff_gave_up(m)) {
+    // The fused expert launch needs every workgroup resident at once; on a CU-masked or shared GPU its bounded spin gives
+    // up.  The model then switches to the two-launch form (no in-launch waiting) for the rest of its life and THIS token is
+    // run again: its side effects so far (the KV row of `pos`, the activations) are rewritten with the same values.
+    if (retried) DSK_FAIL(DSK_ERR_HIP, "forward: an in-kernel hand-off timed out");
+    return run_token(m, token, pos, mode, true);
   }
   return DSK_OK;
 }
@@ -926,6 +947,7 @@ extern "C" int dsk_model_run_block(dsk_model* m, int layer, const float* x_in, i
   if (e != hipSuccess) DSK_FAIL(DSK_ERR_HIP, "run_block: %s", hipGetErrorString(e));
   DSK_TRY(r2);
   HIP_TRY(hipGetLastError());
+  if (handoff_gave_up(m)) DSK_FAIL(DSK_ERR_HIP, "run_block: an in-kernel hand-off timed out (the model now uses the two-launch form: call again)");
   HIP_TRY(hipMemcpy(x_out, m->x, (size_t)c.dim * 4, hipMemcpyDeviceToHost));
   m->stage_kv_len = m->sp_host->kv_len;
   m->stage_last_layer = layer;
@@ -1012,6 +1034,30 @@ extern "C" int dsk_model_get_stage(dsk_model* m, const char* name, void* out, si
   else DSK_FAIL(DSK_ERR_INVALID, "get_stage: unknown stage '%s'", name);
   if (!src || bytes > avail) DSK_FAIL(DSK_ERR_INVALID, "get_stage: '%s' holds %zu bytes, %zu requested", name, avail, bytes);
   HIP_TRY(hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
+  return DSK_OK;
+}
+
+// Parity harness: overwrite rows [row0, row0 + nrows) of one KV cache of `layer` with caller-supplied f16 bits, so that a
+// block can be audited at a LONG context without decoding thousands of tokens first (tests/test_teacher_forced_gpu.py:
+// the attention regimes that only exist from 320 / 1024 cached positions on, at full DeepSeek-V3 width).
+extern "C" int dsk_model_set_cache_rows(dsk_model* m, int layer, const char* cache, int row0, int nrows, const uint16_t* rows) {
+  if (!m || !m->finalized || !cache || !rows) DSK_FAIL(DSK_ERR_INVALID, "set_cache_rows: bad argument");
+  if (layer < 0 || layer >= m->c.n_layers || row0 < 0 || nrows < 1 || row0 + nrows > m->c.max_seq_len)
+    DSK_FAIL(DSK_ERR_INVALID, "set_cache_rows: layer %d rows [%d, %d) of %d", layer, row0, row0 + nrows, m->c.max_seq_len);
+  HIP_TRY(hipSetDevice(m->ctx->device));
+  const dsk_config& c = m->c;
+  const Layer& L = m->L[layer];
+  const std::string s(cache);
+  uint16_t* base = nullptr;
+  size_t width = 0;
+  if (s == "k_cache") { base = L.key_cache; width = (size_t)c.n_heads * m->head_dim; }
+  else if (s == "v_cache") { base = L.value_cache; width = (size_t)c.n_heads * c.v_head_dim; }
+  else if (s == "nope_cache") { base = L.nope_cache; width = (size_t)c.kv_lora_rank; }
+  else if (s == "rope_cache") { base = L.rope_cache; width = (size_t)c.qk_rope_head_dim; }
+  else DSK_FAIL(DSK_ERR_INVALID, "set_cache_rows: unknown cache '%s'", cache);
+  if (!base) DSK_FAIL(DSK_ERR_INVALID, "set_cache_rows: this model has no '%s'", cache);
+  HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+  HIP_TRY(hipMemcpy(base + (size_t)row0 * width, rows, (size_t)nrows * width * 2, hipMemcpyHostToDevice));
   return DSK_OK;
 }
 

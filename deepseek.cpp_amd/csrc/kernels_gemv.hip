@@ -66,7 +66,7 @@ DEV void gemv_body(const GemvLaunch* __restrict__ Lp, const void* h_a0, const vo
   const int RPW = 64 >> lpr_log2;
   const int rloc = lane >> lpr_log2, sub = lane & ((1 << lpr_log2) - 1);
   const int RG = NW * RPW * R;  // rows per workgroup step
-  unsigned long long* tl = L.timeline ? L.timeline + (size_t)bid * 8 : nullptr;
+  unsigned long long* tl = L.timeline && bid < DSK_TL_WGS ? L.timeline + (size_t)bid * 8 : nullptr;
   if (tl && tid == 0) tl[0] = t_entry;
 
   int t0 = 0, t1 = 1, wi, nwg, head = 0, grp_idx = 0;
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(1024) void head_attn_kernel(const HeadAttnArgs A, c
   const int S = A.n_split;  // workgroups per head (1: the whole context here)
   const int h = S > 1 ? (int)blockIdx.x / S : (int)blockIdx.x, split = S > 1 ? (int)blockIdx.x - h * S : 0;
   const AttnMhaArgs& a = A.a;
-  unsigned long long* tl = A.timeline ? A.timeline + (size_t)blockIdx.x * 8 : nullptr;
+  unsigned long long* tl = A.timeline && blockIdx.x < DSK_TL_WGS ? A.timeline + (size_t)blockIdx.x * 8 : nullptr;  // (split contexts: H * n_split workgroups)
   if (tl && tid == 0) tl[0] = wall_clock64();
   uint8_t* act_q = smem;
   uint8_t* act_kv = smem + A.lds_q;
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(1024) void mla_head_kernel(const MlaHeadArgs A, con
   const int lora = a.lora, rope = a.rope, kv_len = sp->kv_len;
   uint8_t* act = smem;
   float* att = reinterpret_cast<float*>(smem + A.lds_act);
-  unsigned long long* tl = A.timeline ? A.timeline + (size_t)h * 8 : nullptr;
+  unsigned long long* tl = A.timeline && h < DSK_TL_WGS ? A.timeline + (size_t)h * 8 : nullptr;
   if (tl && tid == 0) tl[0] = wall_clock64();
   // (This head's wv_b rows - 21 KB, one row group - requested here, ahead of everything, and multiplied at the end: no
   // gain, 11.1 -> 12.3 us in the bench.  The tail after the attention is the Q8_K of the latent output, two barriers and
@@ -849,7 +849,7 @@ static void launch_one(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& 
   const void *a0 = nullptr, *a1 = nullptr, *a2 = nullptr;
   int hn = 0, hm = 0, gw = 0, gs = 0;
   float he = 0.f;
-  static const bool no_hint = getenv("DSK_NO_HINT") != nullptr;  // A/B knob of tools/kbench.py
+  static const bool no_hint = dsk_ab_env("DSK_NO_HINT") != nullptr;  // A/B knob of tools/kbench.py
   if (h.bd_heads == 0 && h.n_groups == 1 && !no_hint) {
     const GemvTask& T = h.t[h.grp_t0[0]];
     hn = T.n; hm = T.act_mode; he = T.eps;
@@ -1056,7 +1056,7 @@ int gemv_plan(GemvLaunch& h, int target_wgs) {
   if (!cg && h.bd_heads <= 0 && total_rows >= 192L * 16 * RPW * h.R) h.NW = 16;
   // small launches (the first-stage projections: 2112 rows of 7168): 16-wave workgroups quarter-filled with rows still
   // quantise the activation vector four times faster than 4-wave ones (2 instead of 7 blocks per wave)
-  static const int small_nw16 = getenv("DSK_SMALL_NW16") ? atoi(getenv("DSK_SMALL_NW16")) : 1;  // measured: qkv_a 9.7 -> 7.9 us
+  static const int small_nw16 = dsk_ab_env("DSK_SMALL_NW16") ? atoi(dsk_ab_env("DSK_SMALL_NW16")) : 1;  // measured: qkv_a 9.7 -> 7.9 us
   int fill_div = 2;
   if (small_nw16 && h.NW == 4 && !cg && h.bd_heads <= 0 && kq && h.force_NW <= 0 && total_rows >= 32L * 16 * RPW) { h.NW = 16; fill_div = 4; }
   if (h.force_NW == 4 || h.force_NW == 16) h.NW = h.force_NW;

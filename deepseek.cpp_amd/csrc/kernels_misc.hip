@@ -915,7 +915,7 @@ __global__ __launch_bounds__(FL_NWV * 64) void mla_flash_kernel(MlaFlashArgs a, 
   float (*Pm)[FL_PSTRIDE] = reinterpret_cast<float (*)[FL_PSTRIDE]>(fl_smem + 32 * FL_KSTRIDE * 2 + FL_NWV * 32 * FL_PSTRIDE * 4);
   __shared__ float m_s[32], l_s[32], al_s[32];
   const int hg = blockIdx.y, tid = threadIdx.x, w = tid >> 6, l = tid & 63, i = l & 31, kh = l >> 5;
-  unsigned long long* tl = a.timeline ? a.timeline + (size_t)(blockIdx.x * gridDim.y + blockIdx.y) * 8 : nullptr;
+  unsigned long long* tl = a.timeline && blockIdx.x * gridDim.y + blockIdx.y < DSK_TL_WGS ? a.timeline + (size_t)(blockIdx.x * gridDim.y + blockIdx.y) * 8 : nullptr;
   if (tl && tid == 0) tl[0] = wall_clock64();
   constexpr int lora = 512, rope = 64, KT = lora + rope;  // 576: launch_mla_flash admits only these (compile-time: the staging loops unroll)
   const int head = hg * 32 + i;

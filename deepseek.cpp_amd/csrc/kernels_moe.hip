@@ -69,7 +69,7 @@ __global__ __launch_bounds__(1024) void moe_ffn_kernel(const MoeFfnArgs a) {
   uint8_t* actB = smem + a.lds_a;                                            // slots x lds_b item records
   float* o_s = reinterpret_cast<float*>(smem + a.lds_a + (size_t)a.lds_b * (a.K + 1));  // [slot][rows_wg] slot outputs
   const int K = a.K, slots = K + (a.shared_n > 0 ? 1 : 0);
-  unsigned long long* tl = a.timeline ? a.timeline + (size_t)bid * 8 : nullptr;
+  unsigned long long* tl = a.timeline && bid < DSK_TL_WGS ? a.timeline + (size_t)bid * 8 : nullptr;
   if (tl && tid == 0) tl[0] = wall_clock64();
 
   // ---- prologue: the router left Q8_K(rmsnorm(x)) behind (previous launch): copy it into item records ----
@@ -166,8 +166,9 @@ __global__ __launch_bounds__(1024) void moe_ffn_kernel(const MoeFfnArgs a) {
           const bool ok = lane >= K || __hip_atomic_load(a.slot_ctr + lane * MOE_CTR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)a.UA;
           if (__all(ok)) break;
           __builtin_amdgcn_s_sleep(1);  // (8 or 32, or ONE counter for all slots: no difference in the time to pass)
-          if (++spins > (1u << 20)) { if (lane == 0) *a.err = 1u; break; }
+          if (++spins > (unsigned)a.spin_limit) { if (lane == 0) *a.err = 1u; break; }
         }
+        if (a.spin_limit < 0 && bid == 0 && lane == 0) *a.err = 1u;  // fault injection (option "moe_spin_limit" < 0): tests/test_fused_moe_gpu.py
       }
       __syncthreads();
       if (tl && tid == 0) tl[3] = wall_clock64();
@@ -287,6 +288,7 @@ int moe_ffn_plan(MoeFfnArgs& a, int n_cus) {
   if (grid > n_cus) grid = n_cus;
   if (grid > a.dim) grid = a.dim;
   a.grid = grid;
+  if (a.spin_limit == 0) a.spin_limit = 1 << 20;
   a.rows_wg = (a.dim + grid - 1) / grid;  // rows of x a workgroup owns in phase B
   if (a.rows_wg > 1024) DSK_FAIL(DSK_ERR_UNSUPPORTED, "moe_ffn: %d rows per workgroup", a.rows_wg);
   a.lds_a = (int)(((size_t)(a.dim / 64) * ITEM_LDS + 15) & ~(size_t)15);
@@ -294,13 +296,31 @@ int moe_ffn_plan(MoeFfnArgs& a, int n_cus) {
   a.lds_b = (int)(((size_t)(nB / 64) * ITEM_LDS + 15) & ~(size_t)15);
   a.lds_o = (a.K + 1) * a.rows_wg * 4;
   if ((size_t)a.lds_a + (size_t)a.lds_b * (a.K + 1) + a.lds_o > 150 * 1024) DSK_FAIL(DSK_ERR_UNSUPPORTED, "moe_ffn: activations do not fit LDS");
+  // the runtime's own view of residency: one 1024-thread workgroup with this much LDS must fit a CU.  (What the query
+  // cannot see - a CU mask, another process on the GPU - is caught at run time: the bounded spin gives up and the model
+  // falls back to the two-launch form, forward.cpp handoff_gave_up.)
+  {
+    const size_t lds = (size_t)a.lds_a + (size_t)a.lds_b * (a.K + 1) + a.lds_o;
+    int per_cu = 0;
+    hipError_t e;
+    if (q3) {
+      auto k = moe_ffn_kernel<DSK_QUANT_Q3_K, 2, 2>;
+      if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 1024, lds);
+    } else {
+      auto k = moe_ffn_kernel<DSK_QUANT_Q2_K, MOE_UA, 4>;
+      if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 1024, lds);
+    }
+    if (e != hipSuccess || per_cu < 1) DSK_FAIL(DSK_ERR_UNSUPPORTED, "moe_ffn: a workgroup is not resident on one CU (occupancy query: %d)", per_cu);
+  }
   return DSK_OK;
 }
 
 int launch_moe_ffn(hipStream_t st, const MoeFfnArgs& a, hipEvent_t ev_start, hipEvent_t ev_stop) {
   const size_t lds = (size_t)a.lds_a + (size_t)a.lds_b * (a.K + 1) + a.lds_o;
   auto go = [&](auto k) {
-    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (ev_start && ev_stop) hipExtLaunchKernelGGL(k, dim3(a.grid), dim3(1024), (uint32_t)lds, st, ev_start, ev_stop, 0u, a);
     else hipLaunchKernelGGL(k, dim3(a.grid), dim3(1024), lds, st, a);
   };

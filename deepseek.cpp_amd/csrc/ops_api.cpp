@@ -364,7 +364,7 @@ extern "C" int dsk_bench_gemv(dsk_ctx* ctx, int quant, int rows, int n, int n_ta
   int copies = (int)(600e6 / wbytes) + 1;
   if (copies > 48) copies = 48;
   if (copies < 2) copies = 2;
-  if (getenv("DSK_BENCH_COPIES")) copies = std::max(1, atoi(getenv("DSK_BENCH_COPIES")));  // 1: the Infinity Cache serves the weights
+  if (dsk_ab_env("DSK_BENCH_COPIES")) copies = std::max(1, atoi(dsk_ab_env("DSK_BENCH_COPIES")));  // 1: the Infinity Cache serves the weights
   std::vector<TensorGuard> W((size_t)copies * mats);
   for (size_t i = 0; i < W.size(); ++i) {
     DSK_TRY(alloc_tensor(128, 128, W[i].t, quant, 0, rows, n, 1, 0));
@@ -394,7 +394,7 @@ extern "C" int dsk_bench_gemv(dsk_ctx* ctx, int quant, int rows, int n, int n_ta
     memset(&h, 0, sizeof h);
     h.quant = quant; h.glu = kind == 1; h.act = DSK_ACT_SILU;
     h.b0 = h.b1 = 128; h.force_lpr = force_lpr; h.force_R = force_R; h.force_U = force_U;
-    if (getenv("DSK_FORCE_NW")) h.force_NW = atoi(getenv("DSK_FORCE_NW"));  // tuning knob of tools/kbench.py
+    if (dsk_ab_env("DSK_FORCE_NW")) h.force_NW = atoi(dsk_ab_env("DSK_FORCE_NW"));  // tuning knob of tools/kbench.py
     for (int i = 0; i < n_tasks; ++i) {
       GemvTask& T = h.t[h.n_tasks++];
       const DTensor& t = W[(size_t)c * mats + i * (kind == 1 ? 2 : 1)].t;
@@ -429,7 +429,7 @@ extern "C" int dsk_bench_gemv(dsk_ctx* ctx, int quant, int rows, int n, int n_ta
   hipEventDestroy(e1);
   *us_per_launch = (double)ms * 1e3 / iters;
   *bytes_per_launch = wbytes;
-  if (getenv("DSK_TIMELINE")) {  // one more launch with per-workgroup wall-clock stamps, summarised on stderr
+  if (dsk_ab_env("DSK_TIMELINE")) {  // one more launch with per-workgroup wall-clock stamps, summarised on stderr
     DevBuf tlb;
     const int grid = H[0].grid;
     DSK_TRY(tlb.alloc((size_t)grid * 64));

@@ -194,7 +194,7 @@ RDEV void router_body(const RouterArgs& a, int bid, int nblocks) {
   const int r = wave % RW, sl = wave / RW;
   const int row = bid * RW + r;
   const int dim = a.dim, E = a.n_routed;
-  unsigned long long* tl = a.timeline ? a.timeline + (size_t)bid * 8 : nullptr;
+  unsigned long long* tl = a.timeline && bid < DSK_TL_WGS ? a.timeline + (size_t)bid * 8 : nullptr;
   if (tl && tid == 0) tl[0] = wall_clock64();
   const float scale = a.norm_w && !(a.dbg & 4) ? router_norm_scale(a, tid, scratch) : 1.0f;
   if (tl && tid == 0) tl[1] = wall_clock64();

@@ -138,6 +138,9 @@ def lib():
         L.dsk_model_run_head.argtypes = [C.c_void_p, c_f, c_f]
         L.dsk_model_get_stage.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
         L.dsk_router_logits.argtypes = [C.c_void_p, c_f, c_f, c_f, C.c_float, C.c_int, C.c_int, c_f]
+        L.dsk_model_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.dsk_model_get_info.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]
+        L.dsk_ctx_live_models.argtypes = [C.c_void_p]
         L.dsk_bench_router.argtypes = [C.c_void_p] + [C.c_int] * 5 + [C.POINTER(C.c_double)]
         L.dsk_bench_gemv.argtypes = [C.c_void_p] + [C.c_int] * 11 + [C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _lib = L
@@ -186,6 +189,9 @@ class Ctx:
     def comm_init(self, uid: bytes, rank: int, world: int):
         check(lib().dsk_comm_init(self.h, C.c_char_p(uid), rank, world))
         self.rank, self.world = rank, world
+
+    def live_models(self) -> int:
+        return lib().dsk_ctx_live_models(self.h)
 
     def close(self):
         if self.h:
@@ -304,11 +310,13 @@ class Model:
     """dsk_model_* life-cycle.  `tensors`: name -> object with .data/.shape/.quant/.scale (tools.synth.Tens),
     named like the reference's .dseek tensors; or None + synth_seed to generate weights in HBM."""
 
-    def __init__(self, ctx: Ctx, cfg, tensors=None, synth_seed=None):
+    def __init__(self, ctx: Ctx, cfg, tensors=None, synth_seed=None, options=None):
         self.ctx, self.cfg = ctx, cfg
         self.dcfg = make_config(cfg)
         self.h = C.c_void_p()
         check(lib().dsk_model_create(ctx.h, C.byref(self.dcfg), C.byref(self.h)))
+        for k, v in (options or {}).items():  # include/dsk.h dsk_model_set_option: between create and finalize
+            check(lib().dsk_model_set_option(self.h, k.encode(), int(v)))
         if tensors is not None:
             from tools import synth  # name -> role mapping shared with the test generators
 
@@ -401,9 +409,16 @@ class Model:
         check(lib().dsk_model_get_stage(self.h, name.encode(), out.ctypes.data, out.nbytes))
         return out
 
+    def set_cache_rows(self, layer: int, cache: str, row0: int, rows):
+        """dsk_model_set_cache_rows: rows = (n, width) uint16 f16 bits written at cache rows [row0, row0 + n)"""
+        rows = np.ascontiguousarray(rows, np.uint16)
+        f = lib().dsk_model_set_cache_rows
+        f.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_void_p]
+        check(f(self.h, layer, cache.encode(), row0, rows.shape[0], rows.ctypes.data))
+
     def timeline(self, kind: int, n_wgs: int = 1024):
         """(n_wgs, 8) wall-clock stamps (100 MHz ticks) of the LAST launch of one kind in a token; the model must have been
-        created with DSK_TIMELINE=1 in the environment (include/dsk.h dsk_model_get_timeline; rows of unused workgroups are 0)"""
+        created with options={"timeline": 1} (include/dsk.h dsk_model_get_timeline; rows of unused workgroups are 0)"""
         out = np.zeros((n_wgs, 8), np.uint64)
         f = lib().dsk_model_get_timeline
         f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
@@ -439,6 +454,11 @@ class Model:
         us, nb, n = C.c_double(), C.c_double(), C.c_int()
         check(lib().dsk_time_kernel_class(self.h, name.encode(), pos, reps, C.byref(us), C.byref(nb), C.byref(n)))
         return us.value, nb.value, n.value
+
+    def info(self, key: str) -> int:
+        v = C.c_int()
+        check(lib().dsk_model_get_info(self.h, key.encode(), C.byref(v)))
+        return v.value
 
     def active_bytes(self, pos: int) -> float:
         return lib().dsk_model_active_bytes(self.h, pos)

@@ -170,6 +170,32 @@ int dsk_model_synthesize(dsk_model* m, uint64_t seed);
  * and activation scratch (src/model.cpp:677-726). */
 int dsk_model_finalize(dsk_model* m);
 int dsk_model_destroy(dsk_model* m);
+/* Per-model options, set between dsk_model_create and dsk_model_finalize.  Everything that selects kernels, launch
+ * shapes or diagnostics is an explicit option of ONE model: the library never reads the environment (a stray variable
+ * in the host application's environment must not change kernels or numerics; only -DDSK_AB builds, made by
+ * tools/ab_build.sh for measurements, seed these options from DSK_* variables).  Keys (int values):
+ *   "fuse_moe"        1  routed experts of a MoE block in one launch (0: two launches; bit-identical)
+ *   "fuse_shared"     1  the shared expert's w1/w3 rides in the router launch (0: ninth task of the experts' launch)
+ *   "ride_kvwrite"    1  MLA: the latent cache write rides in the second-stage projection launch
+ *   "att_q8_in_wo"    0  wo quantises the attention output in its own prologue (no finisher in the attention launch)
+ *   "compact_absent"  1  expert-sharded w1/w3 launch compacts its row space over the experts present on the rank
+ *   "rider_fill"      4  workgroup fill divisor of the shared expert's rider (1..16)
+ *   "mla_flash_min" 320  context length from which MLA attention runs on the matrix cores
+ *   "mha_split_min" 1024 context length from which MHA attention splits a head's context over workgroups
+ *   "timeline"        0  in-kernel wall-clock stamps for dsk_model_get_timeline
+ *   "moe_spin_limit"  0  polls before the fused expert launch's hand-off wait gives up (0: 2^20); < 0: fault
+ *                        injection (a give-up is reported although the hand-off succeeded: exercises the fallback)
+ *   "force_exchange"  0  run the expert-sharded code path (two-launch experts, RCCL all-reduce when the context has a
+ *                        communicator, separate combine launch) at world == 1 too
+ *   "graph_with_comm" 0  capture the sharded step into a hipGraph as well (default: enqueued eagerly) */
+int dsk_model_set_option(dsk_model* m, const char* key, int value);
+/* Read-only counters: "handoff_fallbacks" (times a hand-off give-up moved the model to the two-launch form; the token
+ * that hit it was re-run transparently), "fused_moe_layers", "graph_captured", "exchange_calls" (RCCL collectives this
+ * model has enqueued eagerly). */
+int dsk_model_get_info(dsk_model* m, const char* key, int* value);
+/* models created on the context and not yet destroyed (a context destroyed while models are alive is freed by the last
+ * dsk_model_destroy) */
+int dsk_ctx_live_models(dsk_ctx* ctx);
 
 /* ---- direct-to-HBM `.dseek` loader ---------------------------
  * Replaces, for this device, YALMData::from_directory (src/codec.cpp:333-365: every file of the directory in
@@ -249,6 +275,11 @@ int dsk_model_run_block(dsk_model* m, int layer, const float* x_in, int pos, flo
 /* final norm + classifier on a given residual stream (src/infer.cpp:1292-1316); taps "q8.x_final.*" */
 int dsk_model_run_head(dsk_model* m, const float* x_in, float* logits);
 int dsk_model_get_stage(dsk_model* m, const char* name, void* out, size_t bytes);
+/* Parity harness: overwrite rows [row0, row0 + nrows) of one KV cache of `layer` ("k_cache" / "v_cache": n_heads * head_dim /
+ * n_heads * v_head_dim f16 per row; "nope_cache" / "rope_cache": kv_lora_rank / qk_rope_head_dim) with the caller's f16
+ * bits, so that ONE block can be audited at a long context (the attention regimes that start at 320 / 1024 cached
+ * positions) without decoding thousands of tokens first. */
+int dsk_model_set_cache_rows(dsk_model* m, int layer, const char* cache, int row0, int nrows, const uint16_t* rows);
 
 /* Per-kernel-class device time of ONE eager forward bracketed by HIP events on the
  * engine stream.  names: up to max_classes pointers to static strings. */
@@ -330,9 +361,8 @@ int dsk_bench_gemv(dsk_ctx* ctx, int quant, int rows, int n, int n_tasks, int ki
                    double* us_per_launch, double* bytes_per_launch);
 
 /* Diagnostics: 8 wall-clock stamps (100 MHz ticks: entry, staged, phase A done, hand-off passed, hidden vectors staged,
-   rows done, exit, unused) per workgroup of the LAST fused routed-expert launch; needs DSK_MOE_TIMELINE=1 in the
-   environment when the model is created. */
-int dsk_model_get_timeline(dsk_model* m, int kind, unsigned long long* out, int n_wgs);  /* kind: 0 first-stage projections, 1 per-head attention, 2 wo, 3 shared expert w1/w3 (rider), 4 fused routed experts, 5 router, 6 MLA long-context scores / values; needs DSK_TIMELINE=1 in the environment when the model is created; tools/timeline.py names the stamps */
+   rows done, exit, unused) per workgroup of the LAST fused routed-expert launch; needs the option "timeline". */
+int dsk_model_get_timeline(dsk_model* m, int kind, unsigned long long* out, int n_wgs);  /* kind: 0 first-stage projections, 1 per-head attention, 2 wo, 3 shared expert w1/w3 (rider), 4 fused routed experts, 5 router, 6 MLA long-context scores / values; needs the option "timeline" (dsk_model_set_option); a region holds the first 1024 workgroups of a launch; tools/timeline.py names the stamps */
 int dsk_model_get_moe_timeline(dsk_model* m, unsigned long long* out, int n_wgs);
 
 /* Router (F32 GEMV + rmsnorm prologue) + moe_gate micro-benchmark on synthetic weights; flags: 0 = the

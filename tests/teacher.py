@@ -235,9 +235,13 @@ class BlockAuditor:
     def run(self, dev, l, x_in, pos):
         c, orc = self.c, self.orc
         x_in = np.ascontiguousarray(x_in, np.float32)
+        # KV ring with KV_SINKS = 2 attention sinks (src/infer.cpp:1271-1277, src/model.h:14).  Past the ring's length the
+        # device re-rotates the two sink keys in place before attending; the audit then checks attention over the cache rows
+        # AS THE DEVICE LEFT THEM and this position's row (the sink rotation itself: tests/test_model_gpu.py, small models).
         W = c.rs_original_max_position_embeddings
-        assert pos < W, "the audit covers the un-wrapped ring"
-        kv_len, kv_pos = pos + 1, pos
+        sink = 2 if pos >= W else 0
+        kv_pos = sink + (pos - sink) % (W - sink)
+        kv_len = W if pos >= W else pos + 1
         A = Audit()
         x_out = dev.run_block(l, x_in, pos)
         H, vd = c.n_heads, c.v_head_dim

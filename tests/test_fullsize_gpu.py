@@ -216,16 +216,12 @@ def test_ride_along_launches_equal_separate_launches_bit_for_bit(ctx, monkeypatc
     """At DeepSeek-V3 width two small jobs ride in a neighbour's launch: the shared expert's w1/w3 GLU in the router launch
     (router_shared_kernel) and, on the MLA path, the latent's cache write in the second-stage projection launch
     (gemv_kvwrite_kernel).  Both are the same arithmetic on other workgroups: logits, routing and slot outputs must be
-    BIT-identical to a model that keeps the separate launches (DSK_NO_FUSE_SHARED / DSK_NO_KVWRITE_RIDE), across a
+    BIT-identical to a model that keeps the separate launches (options "fuse_shared" / "ride_kvwrite" = 0), across a
     free-running sequence (the cache written by the riding workgroup feeds the next tokens), eager and graph replay."""
     import dsk
     c = synth.preset("v3", "q2_k", mla, n_layers=2, first_k_dense_replace=1, n_routed_experts=16, n_group=4, topk_group=2, max_seq_len=64)
     A = dsk.Model(ctx, c, None, synth_seed=3)
-    monkeypatch.setenv("DSK_NO_FUSE_SHARED", "1")
-    monkeypatch.setenv("DSK_NO_KVWRITE_RIDE", "1")
-    B = dsk.Model(ctx, c, None, synth_seed=3)
-    monkeypatch.delenv("DSK_NO_FUSE_SHARED")
-    monkeypatch.delenv("DSK_NO_KVWRITE_RIDE")
+    B = dsk.Model(ctx, c, None, synth_seed=3, options={"fuse_shared": 0, "ride_kvwrite": 0})
     tok = 11
     for pos in range(7):
         la, lb = A.forward(tok, pos), B.forward(tok, pos)

@@ -368,11 +368,10 @@ def test_mha_long_context_regime_matches_oracle(ctx, oracle, monkeypatch):
     captured graph.  Float weights: logits within 1e-3 of the oracle on both sides of the switch, routing identical;
     the ring wraps inside the long regime (attention sinks are rotated by split 0 only)."""
     import dsk
-    monkeypatch.setenv("DSK_MHA_SPLIT_MIN", "256")
     c = synth.preset("tiny_v3", "fp16", False, max_seq_len=320)
     c.rs_original_max_position_embeddings = 288  # ring of 288 positions: wraps at pos 288
     T = synth.synth_model(c, seed=33)
-    M, O = dsk.Model(ctx, c, T), oracle.model(c, T)
+    M, O = dsk.Model(ctx, c, T, options={"mha_split_min": 256}), oracle.model(c, T)
     rng = np.random.default_rng(1)
     toks = rng.integers(0, c.vocab_size, 310)
     worst = 0.0

@@ -103,6 +103,11 @@ def assert_model_parity(st, kquant, what=""):
         frac = float(np.mean(np.array(e0) < 2e-5))
         assert frac >= 0.5, (what, "independent trials without a rounding tie, within 2e-5", frac, e0)
         assert max(seq + e0) < 0.3, (what, seq, e0)
+        # a weak floor on free-running routing agreement: ties move a router logit by ~1e-4 of its scale, so
+        # most decisions survive; the exact statement is the teacher-forced audit
+        (same0, n0), (same, n) = st["routes0"], st["routes"]
+        assert n0 == 0 or same0 >= 0.5 * n0, (what, "routing agreement of the independent pos-0 trials", same0, n0)
+        assert n == 0 or same >= 0.3 * n, (what, "routing agreement over the free-running sequence", same, n)
     else:
         assert max(seq + e0) < 1e-3, (what, seq, e0)
         assert st["routes"][0] == st["routes"][1] and st["routes0"][0] == st["routes0"][1], (what, st["routes"], st["routes0"])

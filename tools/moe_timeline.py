@@ -1,16 +1,15 @@
 """Where the fused routed-expert launch (kernels_moe.hip) spends its time: per-workgroup wall-clock stamps of the last
-MoE block of a token.   DSK_MOE_TIMELINE=1 python tools/moe_timeline.py [--layers 8]"""
+MoE block of a token.   python tools/moe_timeline.py [--layers 8]"""
 import argparse, ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "deepseek.cpp_amd"))
-os.environ.setdefault("DSK_MOE_TIMELINE", "1")
 import dsk
 from tools import synth
 
 ap = argparse.ArgumentParser(); ap.add_argument("--layers", type=int, default=8); a = ap.parse_args()
 c = synth.preset("v3", "q2_k", False, n_layers=a.layers, max_seq_len=64)
-ctx = dsk.Ctx(0); M = dsk.Model(ctx, c, None, synth_seed=0)
+ctx = dsk.Ctx(0); M = dsk.Model(ctx, c, None, synth_seed=0, options={"timeline": 1})
 for pos in range(6):
     M.forward(17 + pos, pos)
 n = 256

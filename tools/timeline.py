@@ -4,7 +4,6 @@ import argparse, ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "deepseek.cpp_amd"))
-os.environ.setdefault("DSK_TIMELINE", "1")
 import dsk
 from tools import synth
 
@@ -12,7 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--layers", type=int, default=8); ap.add_argument("--attn", default="mha"); ap.add_argument("--pos", type=int, default=6); ap.add_argument("--kv", type=int, default=0)
 a = ap.parse_args()
 c = synth.preset("v3", "q2_k", a.attn == "mla", n_layers=a.layers, max_seq_len=max(64, a.pos + 8, a.kv + 16))
-ctx = dsk.Ctx(0); M = dsk.Model(ctx, c, None, synth_seed=0)
+ctx = dsk.Ctx(0); M = dsk.Model(ctx, c, None, synth_seed=0, options={"timeline": 1})
 for pos in range(a.pos):
     M.forward(17 + pos, pos)
 for i in range(4 if a.kv else 0):  # a long context: the cache rows below hold zeros, the kernels stream them all the same
