@@ -112,7 +112,7 @@ def cpu_baseline(cfg_full, seconds: float):
     T = synth.random_block_model(c, seed=0, tile_blocks=1 << 20)
     d = tempfile.mkdtemp(prefix="dsk_cpu_baseline_")
     try:
-        synth.write_dseek(d, c, T)
+        synth.write_dseek(d, c, T, tokenizer=True)
         del T
         S = R.session(d, c, context=1024)
         import ctypes as C
@@ -144,16 +144,78 @@ def cpu_baseline(cfg_full, seconds: float):
                 best = (t_tok, threads, n, t_dense, t_moe, acc[c.n_layers])
         t_tok, threads, n, t_dense, t_moe, t_head = best
         S.close()
+        main_cli = main_cli_tok_s(d, threads)
     finally:
         for f in os.listdir(d):
             os.unlink(os.path.join(d, f))
         os.rmdir(d)
-    return dict(value=round(1.0 / t_tok, 4), unit="tok/s", cores=threads, kind=kind,
+    return dict(value=round(1.0 / t_tok, 4), unit="tok/s", cores=threads, kind=kind, main_cli_tok_s=main_cli,
                 sample=(f"unmodified reference (oracle/_ref, OpenMP, best of {sweep} threads on {ncpu} cpus = {threads}): {n} tokens on a "
                         f"{cfg_full.model_name}-shaped {c.quant} checkpoint with {c.n_layers} blocks "
                         f"({c.n_routed_experts} experts resident), per-block times "
                         f"[dense {t_dense*1e3:.2f} ms, moe {t_moe*1e3:.2f} ms, head {t_head*1e3:.2f} ms] "
                         f"extrapolated to {n_dense}+{n_moe} blocks"))
+
+
+def main_cli_tok_s(ckpt_dir: str, threads: int):
+    """the reference's own binary, `main DIR -m c -n 128 -t 0`, on the SAME reduced-depth checkpoint
+    the shim was timed on (oracle/_ref/main: the unmodified reference built by oracle/Makefile).  Its printed throughput
+    is for that checkpoint (2 blocks), NOT extrapolated: it sits beside the per-block figures as a cross-check of the shim."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "main")
+    if not os.path.exists(exe):
+        return None
+    try:
+        r = subprocess.run([exe, ckpt_dir, "-m", "c", "-n", "128", "-t", "0", "-i", "the quick brown fox jumps over the lazy dog"],
+                           capture_output=True, env=dict(os.environ, OMP_NUM_THREADS=str(threads)), timeout=120)
+        m = re.search(r"Generation stats:\s+(\d+) tokens\s+throughput: ([0-9.eE+-]+)tok/s", r.stdout.decode("latin-1"))
+        return dict(tok_s=float(m.group(2)), tokens=int(m.group(1)), threads=threads,
+                    note="reference main -m c -n 128 -t 0 on the reduced-depth checkpoint itself (not extrapolated)") if m else None
+    except Exception as e:  # noqa: BLE001 - a baseline helper must never fail the bench line
+        return dict(error=repr(e)[:120])
+
+
+# name -> (rows, n, tasks, kind, act_mode) of dsk_bench_gemv: the quantised GEMVs of a DeepSeek-V3 Q2_K token, as the model
+# launches them (kind 0 plain, 1 GLU pair, 3 W2 of all slots with the fused combine; act 0 ready Q8_K, 1 f32, 2 f32 + rmsnorm)
+GEMV_SHAPES = {"lm_head": (129280, 7168, 1, 0, 2), "wo": (7168, 16384, 1, 0, 0), "dense_w13": (18432, 7168, 1, 1, 2),
+               "dense_w2": (7168, 18432, 1, 0, 1), "experts_w13": (2048, 7168, 9, 1, 0), "experts_w2": (7168, 2048, 9, 3, 1)}
+
+
+def gemv_fracs(ctx, measured_bw):
+    """north_star: ">= 70 % of the measured HBM roofline for the quantized GEMV", per shape, driver-checkable: each GEMV of
+    the token alone on rotating weight sets (> 512 MB, so HBM and not the Infinity Cache), GB/s = weight bytes / launch."""
+    out = {}
+    for name, (rows, n, nt, kind, act) in GEMV_SHAPES.items():
+        try:
+            us, nb = ctx.bench_gemv(3, rows, n, nt, kind, act, 0, 0, 0, 0, 30)
+            out[name] = dict(us=round(us, 2), gbps=round(nb / us / 1e3, 1), frac=round(nb / us / 1e3 / measured_bw, 4) if measured_bw else None)
+        except Exception as e:  # noqa: BLE001
+            out[name] = dict(error=repr(e)[:100])
+    return out
+
+
+def small_model_line(dsk, synth, ctx, torch, tokens, quant, measured_bw):
+    """BASELINE.json configs C2 / C3: DeepSeek-V2-Lite (27 blocks, 64 experts top-6) on one GPU, full depth."""
+    c = synth.preset("v2lite", quant, False)
+    c.max_seq_len = 256
+    M = dsk.Model(ctx, c, None, synth_seed=0)
+    pos = 0
+    for _ in range(8):
+        M.forward_nocopy(int(tokens[pos]) % c.vocab_size, pos)
+        pos += 1
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 64
+    for _ in range(n):
+        M.forward_nocopy(int(tokens[pos % len(tokens)]) % c.vocab_size, pos)
+        pos += 1
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    ab = M.active_bytes(8 + n // 2)
+    M.close()
+    return dict(tok_s=round(1.0 / dt, 1), ms_per_step=round(dt * 1e3, 4), algo_bytes_per_token=round(ab),
+                token_frac=round(ab / dt / 1e9 / HBM_PEAK_GBPS, 4), frac_of_measured=round(ab / dt / 1e9 / measured_bw, 4) if measured_bw else None)
 
 
 def main():
@@ -328,6 +390,18 @@ def main():
             M2.close()
         except Exception as e:
             extras["mla"] = {"error": repr(e)[:160]}
+    if rank == 0 and world == 1 and not a.no_extras and not a.dry_shard and full_v3:
+        try:
+            extras["gemv_frac_of_measured"] = gemv_fracs(ctx, measured_bw)
+        except Exception as e:  # noqa: BLE001
+            extras["gemv_frac_of_measured"] = {"error": repr(e)[:160]}
+        v2 = {}
+        for q in ("q2_k", "f8e5m2"):
+            try:
+                v2[q] = small_model_line(dsk, synth, ctx, torch, tokens, q, measured_bw)
+            except Exception as e:  # noqa: BLE001
+                v2[q] = {"error": repr(e)[:160]}
+        extras["v2lite"] = v2
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
