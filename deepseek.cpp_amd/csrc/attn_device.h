@@ -104,6 +104,44 @@ ADEV void q8k_block(const float (&v)[4], int lane, int8_t* qs_blk, float* d_out,
 }
 
 
+// the same block quantisation with WRITE-THROUGH stores (sc1): for a block whose readers sit on other CUs of the SAME launch
+// (kernels_moe.hip: the hidden vectors of the fused expert launch); the caller drains (s_waitcnt vmcnt(0)) before it arrives
+ADEV void q8k_block_wt(const float (&v)[4], int lane, int8_t* qs_blk, float* d_out, int16_t* bsums_blk) {
+  float amax = 0.f, vmax = 0.f;
+  int imax = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float ax = fabsf(v[i]);
+    if (ax > amax) { amax = ax; vmax = v[i]; imax = lane * 4 + i; }
+  }
+  if (amax == 0.f) imax = lane * 4;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float oa = __shfl_xor(amax, off), ov = __shfl_xor(vmax, off);
+    const int oi = __shfl_xor(imax, off);
+    if (oa > amax || (oa == amax && oi < imax)) { amax = oa; vmax = ov; imax = oi; }
+  }
+  int q[4] = {0, 0, 0, 0};
+  float d = 0.f;
+  if (amax != 0.f) {
+    const float iscale = __fdiv_rn(-127.f, vmax);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = (int)rintf(__fmul_rn(iscale, v[i]));
+      q[i] = r < 127 ? r : 127;
+    }
+    d = __fmul_rn(vmax, 1.0f / -127.f);
+  }
+  const u32 packed = (u32)(q[0] & 0xff) | ((u32)(q[1] & 0xff) << 8) | ((u32)(q[2] & 0xff) << 16) | ((u32)(q[3] & 0xff) << 24);
+  __hip_atomic_store(reinterpret_cast<u32*>(qs_blk) + lane, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int s = q[0] + q[1] + q[2] + q[3];
+  s += __shfl_xor(s, 1);
+  s += __shfl_xor(s, 2);
+  const int s2 = __shfl_down(s, 4);  // the next sub-block's sum: two int16 go out as one dword
+  if ((lane & 7) == 0) __hip_atomic_store(reinterpret_cast<u32*>(bsums_blk) + (lane >> 3), (u32)(s & 0xffff) | ((u32)s2 << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane == 0) __hip_atomic_store(d_out, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // RoPE of the head's query (in LDS, in place), key / value assembly from the LDS copy of this head's
 // kv_b rows, f16 cache write at kv_pos, rotation of the attention-sink keys (src/infer.cpp:956-1020).
 template <int NT>

@@ -178,6 +178,7 @@ int gemv_launch(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& host);
                           // line: 35.6 us per launch, apart: 35.2)
 #endif
 #define MOE_CTR_WORDS (16 * MOE_CTR_STRIDE + 16)
+#define MOE_BLK_CTRS 1024  // per-block arrival counters of the fused expert launch (K x mi / 256 <= 1024)
 struct MoeFfnArgs {
   int quant;
   const uint8_t *w1_qs, *w1_sc, *w1_hm, *w1_dm, *w3_qs, *w3_sc, *w3_hm, *w3_dm;
@@ -197,6 +198,14 @@ struct MoeFfnArgs {
   float* x;              // residual stream
   int n_experts;         // experts in the stacks (offset range check)
   unsigned* slot_ctr;    // [K x MOE_CTR_STRIDE] phase-A arrivals per slot; zeroed by the router launch of the same block
+  // the hidden vectors are handed over ALREADY QUANTISED (hq != null): the last phase-A unit of a 256-block of h_k to
+  // arrive (blk_ctr, re-armed by that unit) quantises the block (quantize_row_q8_K_ref) and only then arrives on the slot's
+  // counter, which therefore counts blocks; phase B copies 292 bytes per block instead of reading 1 KB and quantising it
+  // in each of the 256 workgroups
+  int8_t* hq_qs;         // [slot][hb_stride]
+  float* hq_d;           // [slot][hb_stride / 256]
+  int16_t* hq_bsums;     // [slot][hb_stride / 16]
+  unsigned* blk_ctr;     // [K x (mi / 256)] arrivals per block; zero between launches
   unsigned* err;         // host-visible: set when a bounded spin gives up
   int lprA_log2, lprB_log2;  // lanes per row of the two halves (= the two-launch plans': bit-identical results)
   int UA, rows_wg, lds_a, lds_b, lds_o, grid;  // filled by moe_ffn_plan

@@ -227,6 +227,7 @@ extern "C" int dsk_model_create(dsk_ctx* ctx, const dsk_config* cfg, dsk_model**
   m->mla_flash_min_kv = std::max(32, env_i("DSK_MLA_FLASH_MIN", m->mla_flash_min_kv));
   m->mha_split_min = env_i("DSK_MHA_SPLIT_MIN", 0);
   if (getenv("DSK_MOE_TIMELINE") || getenv("DSK_TIMELINE")) m->want_timeline = true;
+  if (getenv("DSK_NO_MOE_Q8_HANDOFF")) m->moe_q8_handoff = false;
 #endif
   *out = m;
   return DSK_OK;
@@ -248,6 +249,7 @@ extern "C" int dsk_model_set_option(dsk_model* m, const char* key, int value) {
   else if (k == "mha_split_min") m->mha_split_min = std::max(0, value);
   else if (k == "timeline") m->want_timeline = value != 0;
   else if (k == "moe_spin_limit") m->moe_spin_limit = value;
+  else if (k == "moe_q8_handoff") m->moe_q8_handoff = value != 0;
   else if (k == "force_exchange") m->force_exchange = value != 0;
   else if (k == "graph_with_comm") m->graph_with_comm = value != 0;
   else DSK_FAIL(DSK_ERR_INVALID, "set_option: unknown option '%s'", key);
@@ -702,6 +704,8 @@ extern "C" int dsk_model_finalize(dsk_model* m) {
   HIP_TRY(hipMemset(m->comb_counter, 0, (size_t)c.dim * 4));
   HIP_TRY(hipMalloc((void**)&m->moe_ctr, MOE_CTR_WORDS * 4));
   HIP_TRY(hipMemset(m->moe_ctr, 0, MOE_CTR_WORDS * 4));
+  HIP_TRY(hipMalloc((void**)&m->moe_blk_ctr, MOE_BLK_CTRS * 4));
+  HIP_TRY(hipMemset(m->moe_blk_ctr, 0, MOE_BLK_CTRS * 4));
   HIP_TRY(hipHostMalloc((void**)&m->err_host, 64, hipHostMallocDefault));
   memset(m->err_host, 0, 64);
   if (m->want_timeline) {
@@ -750,6 +754,7 @@ extern "C" int dsk_model_destroy(dsk_model* m) {
   for (void* p : {(void*)m->tap_qs, (void*)m->tap_d, (void*)m->tap_latent, (void*)m->stage_x_mid})
     if (p) hipFree(p);
   if (m->moe_ctr) hipFree(m->moe_ctr);
+  if (m->moe_blk_ctr) hipFree(m->moe_blk_ctr);
   if (m->moe_timeline) hipFree(m->moe_timeline);
   if (m->err_host) hipHostFree(m->err_host);
   if (m->router_counter) hipFree(m->router_counter);

@@ -124,6 +124,8 @@ struct dsk_model {
   bool att_q8_in_wo = false;       // DSK_ATT_Q8_IN_WO=1: wo quantises the attention output in its own prologue (no finisher hand-off in the attention launch)
   bool fuse_moe = true;            // DSK_NO_FUSE_MOE at model creation switches it off (A/B, bit-identity tests)
   unsigned* moe_ctr = nullptr;     // slot_ctr[16] | slot_pass[16]
+  unsigned* moe_blk_ctr = nullptr; // per-block arrivals of the fused expert launch (hidden vectors quantised by their producers)
+  bool moe_q8_handoff = true;      // option "moe_q8_handoff"
   // DSK_TIMELINE=1 (debug): 8 wall-clock stamps per workgroup of the LAST launch of each kind in a token;
   // kind 0 first-stage projections, 1 per-head attention, 2 wo, 3 router + shared expert, 4 fused routed experts
   unsigned long long* moe_timeline = nullptr;  // base of [8 kinds][1024 workgroups][8]

@@ -391,6 +391,9 @@ int build_plans(dsk_model* m) {
       a.a_qs = m->a_xb.qs; a.a_d = m->a_xb.d; a.a_bsums = m->a_xb.bsums;
       a.hb = m->hb; a.hb_stride = hb_stride; a.eout = m->eout; a.x = m->x;
       a.slot_ctr = m->moe_ctr;
+      if (m->moe_q8_handoff && K * (mi / 256) <= MOE_BLK_CTRS) {  // hidden vectors handed over as Q8_K (kernels_moe.hip)
+        a.hq_qs = m->a_hb.qs; a.hq_d = m->a_hb.d; a.hq_bsums = m->a_hb.bsums; a.blk_ctr = m->moe_blk_ctr;
+      }
       a.n_experts = c.n_routed_experts;
       a.err = m->err_host;
       a.spin_limit = m->moe_spin_limit;
@@ -577,7 +580,7 @@ static int ffn(dsk_model* m, int l) {
       DSK_TRY(prof_begin(m, "moe_ffn", a.algo_bytes, &p));
       if (!p.skip) {
         // class timing enqueues this class alone: no router launch in front re-arms the slot counters
-        if (m->class_filter) HIP_TRY(hipMemsetAsync(m->moe_ctr, 0, MOE_CTR_WORDS * 4, st));
+        if (m->class_filter) HIP_TRY(hipMemsetAsync(m->moe_ctr, 0, MOE_CTR_WORDS * 4, st));  // (the block counters re-arm themselves)
         DSK_TRY(launch_moe_ffn(st, a, nullptr, nullptr));
       }
       DSK_TRY(prof_end(&p));
@@ -646,6 +649,7 @@ static bool handoff_gave_up(dsk_model* m) {
   if (!m->err_host || !*m->err_host) return false;
   *m->err_host = 0;
   hipMemset(m->moe_ctr, 0, MOE_CTR_WORDS * 4);
+  hipMemset(m->moe_blk_ctr, 0, MOE_BLK_CTRS * 4);
   hipMemset(m->comb_counter, 0, (size_t)m->c.dim * 4);
   for (auto& a : m->moe_ffn) a.grid = 0;
   for (int i = 0; i < 8; ++i) {

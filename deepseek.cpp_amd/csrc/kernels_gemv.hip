@@ -1067,6 +1067,16 @@ int gemv_plan(GemvLaunch& h, int target_wgs) {
     const int cap = h.glu ? 2 : 4;
     if (h.U > cap) h.U = cap;
   }
+  // (Round 3, measured and rejected - an L2 warm-up rider: 128 extra workgroups of the per-head attention launch (the CUs
+  // it leaves idle) READ the first 32 / 64 / 112 KB of every wo workgroup's rows with cacheable loads, XCD-matched
+  // (workgroup b runs on XCD b % 8): wo 12.3 -> 11.4 / 11.2 / 10.8 us, attention 16.8 -> 17.9 / 18.0 / 18.7, first-stage
+  // projections 7.1 -> 7.9 / 8.0 / 8.3 (their x and norm weights leave the L2): 5.19 -> 5.34 / 5.35 / 5.45 ms.  A GEMV whose
+  // weights sit in its XCD's L2 is ~10 % faster, no more: these launches are bound on the CU side, not by HBM latency.)
+  // (Round 3, measured and rejected: for short rows whose per-workgroup share spans 2.25 row groups - the MLA path's
+  // second-stage projections, 73 728 rows of 1536 - three row sets per lane with the whole share requested at once
+  // (R = 3, U = 3, 114 VGPRs, no scratch) instead of three dependent round trips: the launch went 12.6 -> 13.5 us and the
+  // MLA token 5.58 -> 5.75 ms.  Like every deeper burst before it: a CU's read window is full either way, and the
+  // arithmetic of the first rows then waits for the whole burst.)
   const int RG = h.NW * RPW * h.R;
   h.part_unit = cg ? RG : 1;
   if (h.bd_heads > 0) {

@@ -109,7 +109,31 @@ __global__ __launch_bounds__(1024) void moe_ffn_kernel(const MoeFfnArgs a) {
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the arrival
       __syncthreads();
-      if (tid == 0) __hip_atomic_fetch_add(a.slot_ctr + s * MOE_CTR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!a.hq_qs) {
+        if (tid == 0) __hip_atomic_fetch_add(a.slot_ctr + s * MOE_CTR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else if (wave == NW - 1) {
+        // Q8_K hand-over.  The units of a 256-block of h_k (256 / RG of them) arrive on the block's counter; the LAST one
+        // quantises the block - one wave, quantize_row_q8_K_ref on the f32 values every unit published (sc1 loads: the
+        // other units ran on other CUs) -, publishes codes / sums / scale write-through, re-arms the block counter and
+        // only then arrives on the slot's counter (which counts blocks).  Only THIS wave waits for the returning atomic:
+        // the other 15 go on to phase B and request their W2 rows.
+        const int upb = 256 / RG > 0 ? 256 / RG : 1;   // units per block (RG = 16 x rows per wave divides 256)
+        const int blk = (u * RG) >> 8;                 // block of h_k this unit belongs to (RG > 256 never happens: 16 x 16)
+        unsigned old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(a.blk_ctr + s * (a.mi >> 8) + blk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old == (unsigned)upb - 1) {
+          if (lane == 0) __hip_atomic_store(a.blk_ctr + s * (a.mi >> 8) + blk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+          // (ONE 16-byte sc1 load per lane: four dword sc1 loads are four fabric reads each)
+          const u32x4 hv = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(a.hb), (int)(((size_t)s * a.hb_stride + blk * 256 + lane * 4) * 4), 0, 16);
+          const u32 h0 = hv.x, h1 = hv.y, h2 = hv.z, h3 = hv.w;
+          const float v[4] = {u2f(h0), u2f(h1), u2f(h2), u2f(h3)};
+          const size_t e0 = (size_t)s * a.hb_stride + blk * 256;
+          ad::q8k_block_wt(v, lane, a.hq_qs + e0, a.hq_d + (e0 >> 8), a.hq_bsums + (e0 >> 4));
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0) __hip_atomic_fetch_add(a.slot_ctr + s * MOE_CTR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
     }
   }
 
@@ -159,11 +183,12 @@ __global__ __launch_bounds__(1024) void moe_ffn_kernel(const MoeFfnArgs a) {
     float xv = 0.f;
     if (tid < nrows) xv = a.x[r_lo + tid];
     // wait until every phase-A unit of every slot has published its rows (lane k of wave 0 watches slot k)
+    const unsigned slot_target = a.hq_qs ? (unsigned)(a.mi >> 8) : (unsigned)a.UA;  // arrivals per slot: blocks, or units
     auto wait_slots = [&]() {
       if (wave == 0) {
         unsigned spins = 0;
         for (;;) {
-          const bool ok = lane >= K || __hip_atomic_load(a.slot_ctr + lane * MOE_CTR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)a.UA;
+          const bool ok = lane >= K || __hip_atomic_load(a.slot_ctr + lane * MOE_CTR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= slot_target;
           if (__all(ok)) break;
           __builtin_amdgcn_s_sleep(1);  // (8 or 32, or ONE counter for all slots: no difference in the time to pass)
           if (++spins > (unsigned)a.spin_limit) { if (lane == 0) *a.err = 1u; break; }
@@ -177,8 +202,38 @@ __global__ __launch_bounds__(1024) void moe_ffn_kernel(const MoeFfnArgs a) {
     // a wave's blocks requested before the first is quantised (one memory round trip, not one per block); Q8_K per
     // 256-block (quantize_row_q8_K_ref).  `more` runs between the requests and the quantisation: further weight requests
     // queue up behind the hidden vectors' and stream while the blocks are quantised.
-    auto stage_hidden = [&](auto&& more) {
-      const int nblk = K * nbR + nbS;
+    // hidden vectors handed over as Q8_K: routed slots are COPIED into item records (one 16-byte run + its sum per thread and
+    // pass, sc1 loads: written by other CUs during this launch); the shared expert's f32 vector (the router launch wrote it)
+    // is quantised here as before - it is staged BEFORE the hand-off, in the shadow of the W2 requests
+    auto stage_routed_q8 = [&]() {
+      const rsrc_t qr = make_rsrc(a.hq_qs), br = make_rsrc(a.hq_bsums), dr = make_rsrc(a.hq_d);
+      const int runs_per_slot = a.mi >> 4, nruns = K * runs_per_slot;
+      for (int i = tid; i < nruns; i += NW * 64) {
+        const int s = i / runs_per_slot, r = i - s * runs_per_slot;    // run r of slot s = sub-block r
+        const int b = r >> 4, j = r & 15, h = j >> 3, sidx = (j >> 1) & 3, lh = j & 1;
+        const int e16 = s * (a.hb_stride >> 4) + r;                    // index of the run in the [slot][stride] arrays
+        const u32x4 codes = __builtin_amdgcn_raw_buffer_load_b128(qr, e16 * 16, 0, 16);
+        const int bs = (int)(short)__builtin_amdgcn_raw_buffer_load_b16(br, e16 * 2, 0, 16);
+        uint8_t* rec = actB + (size_t)s * a.lds_b + (size_t)(b * 4 + 2 * h + lh) * ITEM_LDS;
+        *reinterpret_cast<u32x4*>(rec + sidx * 16) = codes;
+        if (Q2) {
+          rec[64 + sidx] = (uint8_t)(bs >> 8);
+          rec[68 + sidx] = (uint8_t)(bs & 0xff);
+        } else {
+          reinterpret_cast<short*>(rec + 64)[sidx] = (short)bs;
+        }
+      }
+      for (int i = tid; i < K * nbR * 4; i += NW * 64) {  // block scales: one per quarter record
+        const int s = i / (nbR * 4), q4 = i - s * (nbR * 4);
+        const float d = u2f(__builtin_amdgcn_raw_buffer_load_b32(dr, (s * (a.hb_stride >> 8) + (q4 >> 2)) * 4, 0, 16));
+        float* mrec = reinterpret_cast<float*>(actB + (size_t)s * a.lds_b + (size_t)q4 * ITEM_LDS + 72);
+        if (Q2) { mrec[0] = d * 0.0625f; mrec[1] = d; }
+        else mrec[0] = d;
+      }
+    };
+    auto stage_hidden = [&](bool routed, bool shared, auto&& more) {
+      const int nblk = (routed ? K * nbR : 0) + (shared ? nbS : 0);
+      const int boff = routed ? 0 : K * nbR;  // (block index space: routed slots first, then the shared expert)
       const rsrc_t hr = make_rsrc(a.hb);
       constexpr int SB = 5;
       constexpr int HAUX = 16;  // sc1
@@ -186,8 +241,8 @@ __global__ __launch_bounds__(1024) void moe_ffn_kernel(const MoeFfnArgs a) {
         u32x4 hv[SB];
 #pragma unroll
         for (int k = 0; k < SB; ++k) {
-          const int b = b0 + k * NW;
-          if (b < nblk) {
+          const int b = b0 + k * NW + boff;
+          if (b0 + k * NW < nblk) {
             const int s = b < K * nbR ? b / nbR : K, bb = b < K * nbR ? b - s * nbR : b - K * nbR;
             hv[k] = __builtin_amdgcn_raw_buffer_load_b128(hr, (s * a.hb_stride + bb * 256 + lane * 4) * 4, 0, HAUX);
           }
@@ -195,8 +250,8 @@ __global__ __launch_bounds__(1024) void moe_ffn_kernel(const MoeFfnArgs a) {
         if (b0 == wave) more();
 #pragma unroll
         for (int k = 0; k < SB; ++k) {
-          const int b = b0 + k * NW;
-          if (b < nblk) {
+          const int b = b0 + k * NW + boff;
+          if (b0 + k * NW < nblk) {
             const int s = b < K * nbR ? b / nbR : K, bb = b < K * nbR ? b - s * nbR : b - K * nbR;
             const u32 w0 = hv[k].x, w1 = hv[k].y, w2 = hv[k].z, w3 = hv[k].w;
             const float v[4] = {u2f(w0), u2f(w1), u2f(w2), u2f(w3)};
@@ -204,6 +259,8 @@ __global__ __launch_bounds__(1024) void moe_ffn_kernel(const MoeFfnArgs a) {
           }
         }
       }
+    };
+    auto staged = [&]() {
       __syncthreads();
       if (tl && tid == 0) tl[4] = wall_clock64();
       if (a.tap_qs && bid == 0)  // parity tap: what the slots staged
@@ -232,8 +289,15 @@ __global__ __launch_bounds__(1024) void moe_ffn_kernel(const MoeFfnArgs a) {
         load_chunk_kq<QT, 1, UB, false>(c0, J.shared ? BS : BR, J.its, J.n_items, sub, lpr_log2, sub & 3, J.rowblk[0], 0);
         load_chunk_kq<QT, 1, UB, false>(c1, J.shared ? BS : BR, J.its, J.n_items, sub, lpr_log2, sub & 3, J.rowblk[1], 0);
       }
-      wait_slots();
-      stage_hidden([]() {});
+      if (a.hq_qs) {
+        if (slots > K) stage_hidden(false, true, []() {});  // the shared expert's vector is ready since the router launch
+        wait_slots();
+        stage_routed_q8();
+      } else {
+        wait_slots();
+        stage_hidden(true, slots > K, []() {});
+      }
+      staged();
       for (int j = wave; j < n_jobs; j += NW) {
         if (j != wave) {
           J = make_job(j);
