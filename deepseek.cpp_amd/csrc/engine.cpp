@@ -412,6 +412,26 @@ extern "C" int dsk_expert_shard(int n_experts, int world, int rank, int* base, i
   return DSK_OK;
 }
 
+// SURVEY 8 row f-4 (tensor parallelism, DESIGN.md 4.4: design + host arithmetic, not yet an engine mode): output rows of a
+// replicated GEMV are dealt to the ranks in contiguous ranges that are multiples of `unit` rows (unit = 256 where the
+// output is quantised to Q8_K blocks downstream, the head size for per-head projections, 1 otherwise); rows are independent
+// dot products, so an all-gather of the ranks' ranges reproduces the one-GPU vector bit for bit.  The first
+// (units % world) ranks take one unit more.  Pure host arithmetic (tests/test_dist_cpu.py).
+extern "C" int dsk_tp_rows(int rows, int unit, int world, int rank, int* row0, int* count) {
+  if (rows < 0 || unit < 1 || world < 1 || rank < 0 || rank >= world || !row0 || !count || rows % unit) DSK_FAIL(DSK_ERR_INVALID, "tp_rows: bad argument");
+  const int units = rows / unit, q = units / world, r = units % world;
+  const int u0 = rank * q + std::min(rank, r), n = q + (rank < r ? 1 : 0);
+  *row0 = u0 * unit;
+  *count = n * unit;
+  return DSK_OK;
+}
+// attention heads of rank `rank`: [*head0, *head0 + *count); with them go the head's rows of wq_b / wkv_b (or wc, wq_rope_b,
+// wv_b), its KV-cache columns (each rank keeps n_heads / world of the cache) and its 128 columns of wo's INPUT - which is
+// why wo is split by output rows instead and preceded by an all-gather of the attention output
+extern "C" int dsk_tp_heads(int n_heads, int world, int rank, int* head0, int* count) {
+  return dsk_tp_rows(n_heads, 1, world, rank, head0, count);
+}
+
 static void shard_range(const dsk_model* m, int role, int e, int* base, int* local) {
   *base = 0;
   *local = e;

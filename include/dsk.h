@@ -155,6 +155,12 @@ int dsk_comm_init(dsk_ctx* ctx, const void* uid128, int rank, int world);
 /* Which experts of an E-expert routed stack rank `rank` of `world` owns: [*base, *base + *count).
    Host arithmetic only (no GPU needed). */
 int dsk_expert_shard(int n_experts, int world, int rank, int* base, int* count);
+/* Tensor-parallel partitions (DESIGN.md 4.4 - host arithmetic of the design, no engine mode yet):
+   output rows [*row0, *row0 + *count) of a `rows`-row GEMV for rank `rank` of `world`, in multiples of `unit` rows
+   (rows % unit == 0); heads likewise.  Rows are independent dot products: the all-gather of the ranges equals the one-GPU
+   vector bit for bit.  No GPU needed. */
+int dsk_tp_rows(int rows, int unit, int world, int rank, int* row0, int* count);
+int dsk_tp_heads(int n_heads, int world, int rank, int* head0, int* count);
 
 /* ---- model life-cycle (replaces Model::Model binding, src/model.cpp:756-872) */
 int dsk_model_create(dsk_ctx* ctx, const dsk_config* cfg, dsk_model** out);

@@ -54,6 +54,46 @@ def test_expert_shard_rejects_bad_arguments():
     assert dsk.lib().dsk_expert_shard(8, 2, 0, None, C.byref(c)) == -1
 
 
+def tp_rows(rows, unit, world, rank):
+    import dsk
+    f = dsk.lib().dsk_tp_rows
+    f.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_int)] * 2
+    r0, n = C.c_int(), C.c_int()
+    dsk.check(f(rows, unit, world, rank, C.byref(r0), C.byref(n)))
+    return r0.value, n.value
+
+
+# every GEMV of a DeepSeek-V3 token (rows, unit): unit = 256 where the consumer quantises the vector in Q8_K blocks (a block
+# must come from ONE rank to be quantised before the gather), the head size for per-head projections, 1 for the classifier
+V3_GEMVS = [(1536, 256), (576, 64), (128 * 192, 192), (128 * 256, 256), (7168, 256), (18432, 256), (2048, 256), (256, 1), (129280, 1)]
+
+
+@pytest.mark.parametrize("rows,unit", V3_GEMVS)
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_tensor_parallel_row_ranges_partition_every_gemv(rows, unit, world):
+    got, sizes = [], []
+    for r in range(world):
+        r0, n = tp_rows(rows, unit, world, r)
+        assert r0 % unit == 0 and n % unit == 0
+        got.extend(range(r0, r0 + n))
+        sizes.append(n)
+    assert got == list(range(rows))                 # contiguous, disjoint, complete, in rank order
+    assert max(sizes) - min(sizes) <= unit          # balanced to one unit
+    import dsk
+    h0, hn = C.c_int(), C.c_int()
+    f = dsk.lib().dsk_tp_heads
+    f.argtypes = [C.c_int] * 3 + [C.POINTER(C.c_int)] * 2
+    heads = []
+    for r in range(world):
+        dsk.check(f(128, world, r, C.byref(h0), C.byref(hn)))
+        heads.extend(range(h0.value, h0.value + hn.value))
+    assert heads == list(range(128))
+    r0, n = C.c_int(), C.c_int()
+    g = dsk.lib().dsk_tp_rows
+    assert g(100, 256, 2, 0, C.byref(r0), C.byref(n)) == -1     # rows not a multiple of the unit
+    assert g(512, 256, 2, 2, C.byref(r0), C.byref(n)) == -1     # rank out of range
+
+
 # ---------------------------------------------------------------------------------------------
 # two ranks over gloo
 # ---------------------------------------------------------------------------------------------
@@ -148,3 +188,51 @@ def test_two_rank_expert_sharded_layer_is_bit_identical_to_one_rank(oracle):
         out = np.frombuffer(blob, np.float32)
         assert np.array_equal(out, ref), f"rank {rank}: sharded result differs from the single-rank result"
         assert tmax == 2.0  # every rank sees the slowest rank's time
+
+
+def _tp_worker(rank, world, port, seed, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from oracle import orc as orcmod
+    from tools import synth
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        orc = orcmod.Oracle()
+        rng = np.random.default_rng(seed)
+        rows, n = 1024, 512
+        w = synth.encode_q2k(rng.standard_normal((rows, n)).astype(np.float32) / np.sqrt(n))
+        x = rng.standard_normal(n).astype(np.float32)
+        r0, cnt = tp_rows(rows, 256, world, rank)
+        part = orc.gemv(Q2K, np.ascontiguousarray(w[r0:r0 + cnt]), cnt, n, x)   # this rank's rows only
+        parts = [torch.zeros(tp_rows(rows, 256, world, r)[1], dtype=torch.float32) for r in range(world)]
+        dist.all_gather(parts, torch.from_numpy(part.copy()))                       # equal ranges here: a plain all-gather
+        q.put((rank, torch.cat(parts).numpy().tobytes()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_row_split_gemv_all_gather_is_bit_identical(oracle):
+    """DESIGN.md 4.4 (row f-4): a replicated GEMV split by OUTPUT rows over the ranks and re-assembled with an all-gather of
+    the token's vector - what the north star words - is bit-identical to the one-rank GEMV (rows are independent)."""
+    import torch.multiprocessing as mp
+    from tools import synth
+    seed = 5
+    rng = np.random.default_rng(seed)
+    w = synth.encode_q2k(rng.standard_normal((1024, 512)).astype(np.float32) / np.sqrt(512))
+    x = rng.standard_normal(512).astype(np.float32)
+    ref = oracle.gemv(Q2K, w, 1024, 512, x)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tp_worker, args=(r, 2, port, seed, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, blob in res:
+        assert np.array_equal(np.frombuffer(blob, np.float32), ref), rank
