@@ -1032,12 +1032,16 @@ int gemv_plan(GemvLaunch& h, int target_wgs) {
   // launches alike, big launches (> 64 MB) want ~8 workgroups per CU.  The fused MoE combine pays one
   // arrival (barrier + atomic round trip) per row group, so it wants FEW, tall groups: 8 lanes per row,
   // 2 row sets => 64 rows per group (experts_w2: 16.7 us vs 46 us at 32 lanes per row).
+  // Float weights (F8E5M2 / F16 / F32: 16 bytes = 16 / 8 / 4 weights per item, so rows are 4-16x longer in items than
+  // a K-quant row of the same width) want 16 lanes per row and ONE row set: V2-Lite F8 experts' W2 (7 x 2048 x 1408), sweep of
+  // tools/kbench-style runs: 14.7 us with the K-quant geometry, 11.9-12.2 us at 16 lanes x 1 row set.
+  const bool cg_float = cg && !kq;
   if (cg && h.force_lpr <= 0) {
-    while (lpr > 8) lpr >>= 1;
+    while (lpr > (cg_float ? 16 : 8)) lpr >>= 1;
     h.lpr_log2 = ilog2(lpr);
   }
   const int its = (min_items + lpr - 1) / lpr;
-  h.R = cg ? 2 : 1;
+  h.R = cg && !cg_float ? 2 : 1;
   // one HBM round trip per row group when the row fits: U = column steps of a row, rounded up to a power
   // of two (<= 8; the GLU pair holds two matrices per step: <= 4); longer rows take chunks of 4
   h.U = 1;
