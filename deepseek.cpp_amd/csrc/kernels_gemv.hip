@@ -27,7 +27,8 @@
 #include "gemv_device.h"
 
 #ifndef GEMV_EXACT
-#define GEMV_EXACT 1  // -DGEMV_EXACT=0: only the generic chunk loop in gemv_body (A/B builds)
+#define GEMV_EXACT 2  // 0: only the generic chunk loop in gemv_body; 1: straight-line form for the 7168-wide GLU rows; 2: also for the
+                      // plain 7168-wide rows at 16 lanes (the classifier) and for wo's 16384-wide rows at 64 lanes (A/B builds)
 #endif
 #ifndef HEAD_EXACT
 #define HEAD_EXACT 1  // -DHEAD_EXACT=0: the generic row loop in the per-head attention kernel (A/B builds)
@@ -199,9 +200,18 @@ DEV void gemv_body(const GemvLaunch* __restrict__ Lp, const void* h_a0, const vo
           int rowblk[R];
 #pragma unroll
           for (int r = 0; r < R; ++r) rowblk[r] = row[r] * nb + (sub >> 2);
-          if constexpr (GEMV_EXACT && QT == DSK_QUANT_Q2_K && (GLU || GEMV_EXACT > 1) && R == 1 && NW == 16) {
+          // (the plain forms are compiled into the ONE variant that runs each shape - U = 8: the classifier, U = 4: wo - :
+          // instantiated in every plain variant they cost the first-stage projections' U = 2 kernel 0.85 us per launch)
+          if constexpr (GEMV_EXACT > 1 && QT == DSK_QUANT_Q2_K && !GLU && R == 1 && NW == 16 && U == 4) {
+            if (lpr_log2 == 6 && nb == 64) rows_dot_kq_exact<QT, 1, GLU, 4, 6>(B, sub, q, rowblk, lds_lane, acc, acc2);
+            else rows_dot_kq<QT, R, U, GLU>(B, nb * 4, sub, lpr_log2, q, rowblk, lds_lane, acc, acc2);
+          } else if constexpr (GEMV_EXACT && QT == DSK_QUANT_Q2_K && (GLU || (GEMV_EXACT > 1 && U == 8)) && R == 1 && NW == 16) {
             // 7168-wide rows at 16 lanes each (dense w1/w3, the shared expert's rider, the two-launch experts): the
             // software-pipelined straight-line form, same bits (gemv_device.h rows_dot_kq_exact)
+            // (round 3: the generic loop costs ~10 of its ~72 VALU instructions per item on bounds, ragged-step selects and
+            // 64-bit record addressing, plus ~14 scalar instructions and two branches per step; a launch whose SIMDs are busy
+            // issuing - the classifier: SQ_ACTIVE_INST_VALU 68 % of wave time, profiles/r03_pmc_gemv.txt - gets faster without
+            // them: lm_head 59.4 -> 55.9 us alone.  Column steps are consumed in the same order: same bits.)
             if (lpr_log2 == 4 && nb == 28) rows_dot_kq_exact<QT, 1, GLU, 7, 4>(B, sub, q, rowblk, lds_lane, acc, acc2);
             else rows_dot_kq<QT, R, U, GLU>(B, nb * 4, sub, lpr_log2, q, rowblk, lds_lane, acc, acc2);
           } else {

@@ -285,6 +285,11 @@ __global__ __launch_bounds__(1024) void moe_ffn_kernel(const MoeFfnArgs a) {
       // the first job's weights are requested BEFORE the hand-off: they stream while the slots' producers finish
       ChunkKQ<QT, 1, UB, false> c0, c1;
       Job J = make_job(wave < n_jobs ? wave : 0);
+      // (Round 3, measured and rejected: the DeepSeek-V3 shape of this phase - 2048-wide rows, 8 lanes per row, ONE chunk of
+      // 4 column steps - passed as compile-time constants, so that the bounds, ragged-step selects and record addressing of
+      // the generic chunk code fold away (~10 of ~72 VALU instructions per item in a VALU-bound stretch): the launch went
+      // 33.7 -> 37.9 us, every workgroup passing the hand-off 2 us later: hipcc schedules the now straight-line requests and
+      // the staging differently.  Kept generic.)
       if (wave < n_jobs) {
         load_chunk_kq<QT, 1, UB, false>(c0, J.shared ? BS : BR, J.its, J.n_items, sub, lpr_log2, sub & 3, J.rowblk[0], 0);
         load_chunk_kq<QT, 1, UB, false>(c1, J.shared ? BS : BR, J.its, J.n_items, sub, lpr_log2, sub & 3, J.rowblk[1], 0);
