@@ -210,6 +210,16 @@ struct MoeFfnArgs {
   int lprA_log2, lprB_log2;  // lanes per row of the two halves (= the two-launch plans': bit-identical results)
   int UA, rows_wg, lds_a, lds_b, lds_o, grid;  // filled by moe_ffn_plan
   int spin_limit;        // polls before the hand-off wait gives up (0: 2^20); < 0: fault injection (workgroup 0 reports a give-up)
+  // float-weight models (F8E5M2 / F16 / F32; moe_ffn_f_kernel): block scales (F8 only, per-expert strides in floats), the
+  // shared expert's w1 / w3 (computed in phase A too: these models have no rider in the router launch), the FFN norm (x is
+  // normalised in the prologue; K-quant models get the router launch's Q8_K copy instead)
+  const float *w1_scale, *w3_scale, *w2_scale, *sw1_scale, *sw3_scale, *sw2_scale;
+  size_t e13_scale, e2_scale;
+  const uint8_t *sw1_qs, *sw3_qs;
+  const float* norm_w;
+  float eps;
+  int b0, b1;
+  int US;                // phase-A units of the shared expert (float-weight kernel)
   unsigned long long* timeline;  // debug (DSK_MOE_TIMELINE=1): 8 wall-clock stamps per workgroup (100 MHz ticks)
   int8_t* tap_qs;        // parity taps (dsk_model_run_block): slot s's staged hidden vector at s * tap_stride
   float* tap_d;

@@ -125,6 +125,7 @@ struct dsk_model {
   bool fuse_moe = true;            // DSK_NO_FUSE_MOE at model creation switches it off (A/B, bit-identity tests)
   unsigned* moe_ctr = nullptr;     // slot_ctr[16] | slot_pass[16]
   unsigned* moe_blk_ctr = nullptr; // per-block arrivals of the fused expert launch (hidden vectors quantised by their producers)
+  bool fuse_moe_float = true;      // option "fuse_moe_float": the fused expert launch for F8E5M2 / F16 / F32 weights too
   bool moe_q8_handoff = true;      // option "moe_q8_handoff"
   // DSK_TIMELINE=1 (debug): 8 wall-clock stamps per workgroup of the LAST launch of each kind in a token;
   // kind 0 first-stage projections, 1 per-head attention, 2 wo, 3 router + shared expert, 4 fused routed experts

@@ -372,7 +372,10 @@ int build_plans(dsk_model* m) {
     }
     // 8+9 in ONE launch (kernels_moe.hip): K-quants, one GPU, the shared expert's w1/w3 riding in the router launch
     // (or no shared expert).  Same lanes per row as the two plans above => bit-identical results.
-    if (kq && !m->sharded() && m->fuse_moe && c.dim % 256 == 0 && (c.n_shared_experts == 0 || m->lp_sh13[l] >= 0) && K <= 16) {
+    // Float weights (F8E5M2 / F16 / F32): moe_ffn_f_kernel, the shared expert's w1 / w3 computed in the same launch.
+    const bool fuse_kq = kq && c.dim % 256 == 0 && (c.n_shared_experts == 0 || m->lp_sh13[l] >= 0);
+    const bool fuse_f = !kq && m->fuse_moe_float;
+    if ((fuse_kq || fuse_f) && !m->sharded() && m->fuse_moe && K + 1 <= 16) {
       MoeFfnArgs a;
       memset(&a, 0, sizeof a);
       a.quant = wq;
@@ -393,6 +396,16 @@ int build_plans(dsk_model* m) {
       a.slot_ctr = m->moe_ctr;
       if (m->moe_q8_handoff && K * (mi / 256) <= MOE_BLK_CTRS) {  // hidden vectors handed over as Q8_K (kernels_moe.hip)
         a.hq_qs = m->a_hb.qs; a.hq_d = m->a_hb.d; a.hq_bsums = m->a_hb.bsums; a.blk_ctr = m->moe_blk_ctr;
+      }
+      if (!kq) {
+        const DTensor &s1 = L.t[DSK_ROLE_SHARED_W1], &s3 = L.t[DSK_ROLE_SHARED_W3], &s2 = L.t[DSK_ROLE_SHARED_W2];
+        a.w1_scale = w1.scale; a.w3_scale = w3.scale; a.w2_scale = w2.scale;
+        a.e13_scale = w1.e_scale; a.e2_scale = w2.e_scale;
+        if (c.n_shared_experts > 0) { a.sw1_qs = s1.qs; a.sw3_qs = s3.qs; a.sw1_scale = s1.scale; a.sw3_scale = s3.scale; a.sw2_scale = s2.scale; }
+        a.norm_w = reinterpret_cast<const float*>(L.t[DSK_ROLE_FFN_NORM].qs);
+        a.eps = c.norm_eps;
+        a.b0 = std::max(1, c.block_size[0]); a.b1 = std::max(1, c.block_size[1]);
+        a.hq_qs = nullptr;
       }
       a.n_experts = c.n_routed_experts;
       a.err = m->err_host;
@@ -555,7 +568,7 @@ static int ffn(dsk_model* m, int l) {
   r.active_weights = m->route_w + (size_t)l * K;
   r.scores_out = m->gate_scores + (size_t)l * E;
   if (is_kq(c.weight_quant) && c.dim % 256 == 0) { r.q_qs = m->a_xb.qs; r.q_d = m->a_xb.d; r.q_bsums = m->a_xb.bsums; }
-  if (m->moe_ffn[l].grid > 0) { r.zero_ctr = m->moe_ffn[l].slot_ctr; r.zero_n = K; }  // re-arm the expert launch's slot counters
+  if (m->moe_ffn[l].grid > 0) { r.zero_ctr = m->moe_ffn[l].slot_ctr; r.zero_n = std::min(16, std::max(K, m->n_slots)); }  // re-arm the expert launch's slot counters
   if (m->lp_sh13[l] >= 0) {
     const GemvLaunch& hs = m->plans[m->lp_sh13[l]];
     PROFILED("router_gate", (double)E * c.dim * 4 + c.dim * 8.0 + hs.algo_bytes, launch_router_shared(st, r, m->plans_dev + m->lp_sh13[l], hs));

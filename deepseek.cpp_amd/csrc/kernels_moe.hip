@@ -335,13 +335,213 @@ __global__ __launch_bounds__(1024) void moe_ffn_kernel(const MoeFfnArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The same launch for float weights (F8E5M2 with 128 x 128 block scales, F16, F32; src/infer.cpp:238-313, 423-469): f32
+// activations in LDS instead of Q8_K item records, rows_dot_f (f32 FMAs like the reference) instead of the integer dots,
+// and the shared expert's w1 / w3 as further phase-A units (these models have no rider in the router launch).  Same
+// phases, same hand-off, same combine; lanes per row come from the two-launch plans, so the per-row sums are theirs.
+// ------------------------------------------------------------------------------------------------------------
+template <int QT>
+__global__ __launch_bounds__(1024) void moe_ffn_f_kernel(const MoeFfnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ float scratch[16];
+  constexpr int NW = 16;
+  constexpr int ESZ = FTraits<QT>::ESZ;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int bid = blockIdx.x, G = gridDim.x;
+  float* actA = reinterpret_cast<float*>(smem);                                  // rmsnorm(x), dim floats
+  float* actB = reinterpret_cast<float*>(smem + a.lds_a);                        // [slot][lds_b / 4] hidden vectors
+  float* o_s = reinterpret_cast<float*>(smem + a.lds_a + (size_t)a.lds_b * (a.K + 1));  // [slot][rows_wg] slot outputs
+  const int K = a.K, slots = K + (a.shared_n > 0 ? 1 : 0);
+  unsigned long long* tl = a.timeline && bid < DSK_TL_WGS ? a.timeline + (size_t)bid * 8 : nullptr;
+  if (tl && tid == 0) tl[0] = wall_clock64();
+  {  // prologue: rmsnorm(x, ffn_norm) (src/infer.cpp:839, 601-611) into LDS, like the two-launch form's w1/w3 launch
+    ActSrc S;
+    S.act_mode = ACT_F32_NORM; S.n = a.dim; S.a_f32 = a.x; S.norm_w = a.norm_w; S.eps = a.eps; S.pre_scale = 0.f;
+    S.a_qs = nullptr; S.a_d = nullptr; S.a_bsums = nullptr;
+    stage_f32<NW>(S, actA, tid, scratch);
+  }
+  __syncthreads();
+  if (tl && tid == 0) tl[1] = wall_clock64();
+  // ---- phase A: the w1/w3 GLU rows of the K routed slots and of the shared expert, concatenated slot-major into one
+  // virtual row space that the workgroups split EVENLY (to the row: V2-Lite's 11 264 rows are 44 per workgroup; dealing
+  // 16-row units left some workgroups three units and others two).  A lane resolves its own (slot, row): the rows of one
+  // wave may belong to different experts.  Arrivals count ROWS: each workgroup adds, per slot it touched, the rows it
+  // finished; a slot is complete at mi (shared_n) rows. ----
+  {
+    const int lpr_log2 = a.lprA_log2, RPW = 64 >> lpr_log2;
+    const int rloc = lane >> lpr_log2, sub = lane & ((1 << lpr_log2) - 1);
+    const int RG = NW * RPW;
+    const int vtotal = K * a.mi + a.shared_n;
+    const int v_lo = (int)((long long)vtotal * bid / G), v_hi = (int)((long long)vtotal * (bid + 1) / G);
+    for (int base = v_lo; base < v_hi; base += RG) {
+      const int row0 = base + wave * RPW;
+      if (row0 < v_hi) {  // wave-uniform
+        const int vr = row0 + rloc;
+        const bool valid = vr < v_hi;
+        const int vv = valid ? vr : v_hi - 1;
+        const bool sh = vv >= K * a.mi;
+        const int s = sh ? K : vv / a.mi, rr = sh ? vv - K * a.mi : vv - s * a.mi;
+        WPtr P;
+        P.present = true;
+        P.sc = P.hm = P.dm = P.sc2 = P.hm2 = P.dm2 = nullptr;
+        if (sh) {
+          P.qs = a.sw1_qs; P.qs2 = a.sw3_qs; P.scale = a.sw1_scale; P.scale2 = a.sw3_scale;
+        } else {
+          const int e = a.route_e[s];
+          P.qs = a.w1_qs + (size_t)e * a.e13_qs; P.qs2 = a.w3_qs + (size_t)e * a.e13_qs;
+          P.scale = a.w1_scale ? a.w1_scale + (size_t)e * a.e13_scale : nullptr;
+          P.scale2 = a.w3_scale ? a.w3_scale + (size_t)e * a.e13_scale : nullptr;
+        }
+        int row[1] = {rr};
+        float acc[1], acc2[1];
+        rows_dot_f<QT, 1, 4, true>(P, a.dim, a.b0, a.b1, lpr_log2, lane, row, reinterpret_cast<const uint8_t*>(actA), acc, acc2);
+        if (sub == 0 && valid)  // src/infer.cpp:859-872, 882-897; write-through: the consumers sit on other CUs
+          __hip_atomic_store(a.hb + (size_t)s * a.hb_stride + rr, act_fn(acc[0], a.act) * acc2[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the arrivals
+    __syncthreads();
+    if (tid < slots) {  // thread s: this workgroup's rows of slot s
+      const int s_lo = tid * a.mi, s_hi = tid < K ? s_lo + a.mi : s_lo + a.shared_n;
+      const int lo = v_lo > s_lo ? v_lo : s_lo, hi = v_hi < s_hi ? v_hi : s_hi;
+      if (hi > lo) __hip_atomic_fetch_add(a.slot_ctr + tid * MOE_CTR_STRIDE, (unsigned)(hi - lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (tl && tid == 0) tl[2] = wall_clock64();
+  // ---- phase B: this workgroup's rows of x, for all slots ----
+  {
+    const int lpr_log2 = a.lprB_log2, RPW = 64 >> lpr_log2;
+    const int rloc = lane >> lpr_log2, sub = lane & ((1 << lpr_log2) - 1);
+    const int nrows_max = a.rows_wg;
+    const int r_lo = bid * nrows_max;
+    const int nrows = max(0, min(a.dim, r_lo + nrows_max) - r_lo);
+    float xv = 0.f;
+    if (tid < nrows) xv = a.x[r_lo + tid];
+    // routed steps over the virtual rows (slot, row) slot-major, then the shared expert's steps (a step never mixes the two
+    // kinds: the row lengths differ).  A lane resolves its own expert: the rows of one wave may belong to different slots.
+    const int WR = (nrows * K + RPW - 1) / RPW, WS = slots > K ? (nrows + RPW - 1) / RPW : 0;
+    struct StepF { WPtr P; int n, slot, rr; bool valid; };
+    auto make_step = [&](int st) {
+      StepF S;
+      const bool sh = st >= WR;
+      const int v = (sh ? st - WR : st) * RPW + rloc;
+      S.valid = st < WR + WS && (sh ? v < nrows : v < nrows * K);
+      const int vv = S.valid ? v : 0;
+      S.slot = sh ? K : vv / (nrows > 0 ? nrows : 1);
+      S.rr = sh ? vv : vv - S.slot * nrows;
+      S.n = sh ? a.shared_n : a.mi;
+      S.P.present = true;
+      S.P.sc = S.P.hm = S.P.dm = S.P.qs2 = S.P.sc2 = S.P.hm2 = S.P.dm2 = nullptr;
+      S.P.scale2 = nullptr;
+      if (sh) {
+        S.P.qs = a.sw2_qs; S.P.scale = a.sw2_scale;
+      } else {
+        const int e = a.route_e[S.slot];
+        S.P.qs = a.w2_qs + (size_t)e * a.e2_qs;
+        S.P.scale = a.w2_scale ? a.w2_scale + (size_t)e * a.e2_scale : nullptr;
+      }
+      return S;
+    };
+    // the first step's first 8 column steps are requested BEFORE the hand-off: they depend on the routing only
+    constexpr int UB = 8;
+    ChunkF<QT, 1, UB, false> c0;
+    StepF S0 = make_step(wave);
+    const int row0[1] = {r_lo + S0.rr};
+    if (wave < WR + WS) load_chunk_f<QT, 1, UB, false>(c0, S0.P, S0.n, a.b0, a.b1, lpr_log2, lane, row0, 0);
+    // hand-off: lane k of wave 0 watches slot k's counter (the shared expert's is slot K); bounded like the K-quant kernel's
+    if (wave == 0) {
+      unsigned spins = 0;
+      for (;;) {
+        const unsigned want = lane < K ? (unsigned)a.mi : (unsigned)a.shared_n;
+        const bool ok = lane >= slots || __hip_atomic_load(a.slot_ctr + lane * MOE_CTR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
+        if (__all(ok)) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (unsigned)a.spin_limit) { if (lane == 0) *a.err = 1u; break; }
+      }
+      if (a.spin_limit < 0 && bid == 0 && lane == 0) *a.err = 1u;  // fault injection
+    }
+    __syncthreads();
+    if (tl && tid == 0) tl[3] = wall_clock64();
+    {  // the hidden vectors: 16-byte loads that bypass this CU's L1 (written by other CUs during this launch)
+      const rsrc_t hr = make_rsrc(a.hb);
+      const int per = a.lds_b >> 4;  // 16-byte pieces per slot in LDS
+      for (int i = tid; i < slots * per; i += NW * 64) {
+        const int s = i / per, j = i - s * per;
+        const int n = s < K ? a.mi : a.shared_n;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (j * 4 < n) v = __builtin_amdgcn_raw_buffer_load_b128(hr, (s * a.hb_stride + j * 4) * 4, 0, 16);
+        *reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(actB) + (size_t)s * a.lds_b + (size_t)j * 16) = v;
+      }
+    }
+    __syncthreads();
+    if (tl && tid == 0) tl[4] = wall_clock64();
+    for (int st = wave; st < WR + WS; st += NW) {
+      StepF S = st == wave ? S0 : make_step(st);
+      const int row[1] = {r_lo + S.rr};
+      const float* lx = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(actB) + (size_t)S.slot * a.lds_b);
+      const int its = (S.n / FTraits<QT>::EPI + (1 << lpr_log2) - 1) >> lpr_log2;
+      float acc[1] = {0.f}, acc2[1] = {0.f};
+      for (int it0 = 0; it0 < its; it0 += UB) {  // column steps in order: the sums of rows_dot_f
+        if (st != wave || it0 > 0) load_chunk_f<QT, 1, UB, false>(c0, S.P, S.n, a.b0, a.b1, lpr_log2, lane, row, it0);
+        compute_chunk_f<QT, 1, UB, false>(c0, S.n, lpr_log2, it0, lx, acc, acc2);
+      }
+      const float o = lanes_sum(acc[0], lpr_log2);
+      if (sub == 0 && S.valid) { o_s[S.slot * nrows_max + S.rr] = o; a.eout[(size_t)S.slot * a.dim + r_lo + S.rr] = o; }
+    }
+    __syncthreads();
+    if (tl && tid == 0) tl[5] = wall_clock64();
+    if (tid < nrows) {  // x += w_k * o_k in k order (src/infer.cpp:874-877), then the shared expert (:900-903)
+      for (int k = 0; k < K; ++k) xv = fmaf(o_s[k * nrows_max + tid], a.route_w[k], xv);
+      if (slots > K) xv += o_s[K * nrows_max + tid];
+      a.x[r_lo + tid] = xv;
+    }
+    if (tl && tid == 0) tl[6] = wall_clock64();
+  }
+}
+
 #ifndef MOE_UA
 #define MOE_UA 4
 #endif
 // ---- host side ------------------------------------------------------------------------------------------
+static int moe_ffn_plan_f(MoeFfnArgs& a, int n_cus) {
+  const int epi = a.quant == DSK_QUANT_F32 ? 4 : (a.quant == DSK_QUANT_F16 ? 8 : 16);
+  if (a.dim % 16 || a.mi % 4 || a.shared_n % 4 || a.dim % epi || a.mi % epi || a.shared_n % epi)
+    DSK_FAIL(DSK_ERR_UNSUPPORTED, "moe_ffn (float weights): row lengths %d / %d / %d", a.dim, a.mi, a.shared_n);
+  const int lprA = 1 << a.lprA_log2;
+  const int RG = 16 * (64 / lprA);
+  a.UA = (a.mi + RG - 1) / RG;
+  a.US = a.shared_n > 0 ? (a.shared_n + RG - 1) / RG : 0;
+  int grid = a.K * a.UA + a.US;
+  if (grid > n_cus) grid = n_cus;
+  if (grid > a.dim) grid = a.dim;
+  a.grid = grid;
+  if (a.spin_limit == 0) a.spin_limit = 1 << 20;
+  a.rows_wg = (a.dim + grid - 1) / grid;
+  if (a.rows_wg > 1024) DSK_FAIL(DSK_ERR_UNSUPPORTED, "moe_ffn: %d rows per workgroup", a.rows_wg);
+  a.lds_a = (a.dim * 4 + 15) & ~15;
+  const int nB = a.mi > a.shared_n ? a.mi : a.shared_n;
+  a.lds_b = (nB * 4 + 15) & ~15;
+  a.lds_o = (a.K + 1) * a.rows_wg * 4;
+  const size_t lds = (size_t)a.lds_a + (size_t)a.lds_b * (a.K + 1) + a.lds_o;
+  if (lds > 150 * 1024) DSK_FAIL(DSK_ERR_UNSUPPORTED, "moe_ffn: activations do not fit LDS");
+  int per_cu = 0;
+  hipError_t e = hipErrorUnknown;
+  auto occ = [&](auto k) {
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 1024, lds);
+  };
+  if (a.quant == DSK_QUANT_F32) occ(moe_ffn_f_kernel<DSK_QUANT_F32>);
+  else if (a.quant == DSK_QUANT_F16) occ(moe_ffn_f_kernel<DSK_QUANT_F16>);
+  else occ(moe_ffn_f_kernel<DSK_QUANT_F8E5M2>);
+  if (e != hipSuccess || per_cu < 1) DSK_FAIL(DSK_ERR_UNSUPPORTED, "moe_ffn: a workgroup is not resident on one CU (occupancy query: %d)", per_cu);
+  return DSK_OK;
+}
+
 int moe_ffn_plan(MoeFfnArgs& a, int n_cus) {
   const bool q3 = a.quant == DSK_QUANT_Q3_K;
-  if (a.quant != DSK_QUANT_Q2_K && !q3) DSK_FAIL(DSK_ERR_UNSUPPORTED, "moe_ffn: k-quants only");
+  if (a.quant == DSK_QUANT_F32 || a.quant == DSK_QUANT_F16 || a.quant == DSK_QUANT_F8E5M2) return moe_ffn_plan_f(a, n_cus);
+  if (a.quant != DSK_QUANT_Q2_K && !q3) DSK_FAIL(DSK_ERR_UNSUPPORTED, "moe_ffn: bad quant %d", a.quant);
   if (a.dim % 256 || a.mi % 256 || a.shared_n % 256) DSK_FAIL(DSK_ERR_UNSUPPORTED, "moe_ffn: lengths must be multiples of 256");
   const int itemsA = a.dim / 64, itemsB = a.mi / 64, itemsS = a.shared_n / 64;
   const int lprA = 1 << a.lprA_log2, lprB = 1 << a.lprB_log2;
@@ -394,6 +594,9 @@ int launch_moe_ffn(hipStream_t st, const MoeFfnArgs& a, hipEvent_t ev_start, hip
     else hipLaunchKernelGGL(k, dim3(a.grid), dim3(1024), lds, st, a);
   };
   if (a.quant == DSK_QUANT_Q2_K) go(moe_ffn_kernel<DSK_QUANT_Q2_K, MOE_UA, 4>);
+  else if (a.quant == DSK_QUANT_F8E5M2) go(moe_ffn_f_kernel<DSK_QUANT_F8E5M2>);
+  else if (a.quant == DSK_QUANT_F16) go(moe_ffn_f_kernel<DSK_QUANT_F16>);
+  else if (a.quant == DSK_QUANT_F32) go(moe_ffn_f_kernel<DSK_QUANT_F32>);
   else go(moe_ffn_kernel<DSK_QUANT_Q3_K, 2, 2>);  // (more column steps in flight spill at 16 waves x 128 VGPRs: gemv_plan's caps)
   return DSK_OK;
 }

@@ -49,6 +49,27 @@ def test_fused_moe_equals_two_launch_form_bit_for_bit_small_models(ctx, monkeypa
     B.close()
 
 
+FLOAT_CASES = [("tiny_v3", "f8e5m2", False), ("tiny_v3", "f8e5m2", True), ("tiny_v3", "fp16", False), ("tiny_v2lite", "fp32", False),
+               ("tiny_v2lite", "f8e5m2", False)]
+
+
+@pytest.mark.parametrize("preset,quant,mla", FLOAT_CASES, ids=[f"{p}-{q}-{'mla' if m else 'mha'}" for p, q, m in FLOAT_CASES])
+def test_fused_moe_float_weights_equal_two_launch_form_bit_for_bit(ctx, monkeypatch, preset, quant, mla):
+    """the fused expert launch for F8E5M2 / F16 / F32 weights (moe_ffn_f_kernel: f32 activations in
+    LDS, rows_dot_f, the shared expert's w1 / w3 as further phase-A units) against the two-launch form: the same lanes per
+    row and the same f32 FMA order per row, so logits, routing and slot outputs must be identical bit for bit."""
+    c = synth.preset(preset, quant, mla)
+    T = synth.synth_model(c, seed=19)
+    A, B = _pair(ctx, monkeypatch, c, T)
+    assert A.info("fused_moe_layers") == c.n_layers - c.first_k_dense_replace
+    _same(A, B, [5, 9, 700, 3, 44, 1000, 12, 8], c)
+    A.set_graph(False)
+    B.set_graph(False)
+    _same(A, B, [1, 2, 3], c)
+    A.close()
+    B.close()
+
+
 def test_fused_moe_without_a_shared_expert_and_with_top1(ctx, monkeypatch):
     """corner shapes of the fused launch: no shared expert (K slots only), and a single active expert"""
     for over in (dict(n_shared_experts=0), dict(n_active_routed=1, n_group=1, topk_group=1, topk_method="greedy")):
