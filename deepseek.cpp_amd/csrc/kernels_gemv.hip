@@ -182,7 +182,10 @@ DEV void gemv_body(const GemvLaunch* __restrict__ Lp, const void* h_a0, const vo
     const KQRsrc B = kq_rsrc<QT, GLU>(P);
     const int nb = T.n >> 8;
     // (wo of DeepSeek-V3 - 28 rows per workgroup = two steps of 16 - with BOTH row groups requested at once and multiplied
-    // as they arrive, straight-line: 12.2 -> 12.7 us; like every deeper burst tried, slower)
+    // as they arrive, straight-line: 12.2 -> 12.7 us; like every deeper burst tried, slower;
+    // round 3, the two groups as ONE two-buffer stream - group 2's first buffer requested after group 1's first has been
+    // multiplied, never more than two in flight -: 11.8 -> 11.9-12.0 us, 128 VGPRs; the drain between the groups is not what
+    // the launch waits for)
     for (int base = lo; base < hi; base += RG) {
       int row[R];
       bool valid[R];
