@@ -282,6 +282,14 @@ __global__ __launch_bounds__(1024) void moe_ffn_kernel(const MoeFfnArgs a) {
       // phase A moves the w1/w3 rows.  With ALL W2 rows requested before the hand-off (8 us ahead of their use) the
       // multiplies after the staging still take 5.4 us: they are VALU-bound - 252 virtual rows x 32 items per workgroup at
       // ~70-75 wave instructions per item on 4 SIMDs - and nothing is left to stream underneath them.)
+      // (Round 3, measured and rejected: the hand-over WITHOUT counters - every value an 8-byte granule {payload, tag}, the
+      // block's last unit polls the block's granules, quantises, publishes tagged Q8_K granules, phase B polls those; no drain,
+      // no barrier, no arrival.  On an idle chip a hop costs 2.1 us this way against 4.3 us (tools/ll_probe.hip).  In situ,
+      // bit-identical and 36.9 us (all threads poll), 34.6 us (one wave polls the blocks' scale granules), 33-35 us with the
+      // producers' W2 requests held back - against 33.8: a CU serves its waves' memory requests in order, so whatever is
+      // polled queues up behind the 128 KB of W2 rows requested below, and a workgroup's exit is its last w1 / w3 row plus
+      // ~270 KB of W2 rows and hidden vectors at ~20 GB/s per CU whichever way the hand-off is signalled.  The wait is not
+      // idle time: it is W2 streaming.)
       // the first job's weights are requested BEFORE the hand-off: they stream while the slots' producers finish
       ChunkKQ<QT, 1, UB, false> c0, c1;
       Job J = make_job(wave < n_jobs ? wave : 0);
