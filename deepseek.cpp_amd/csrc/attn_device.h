@@ -142,6 +142,16 @@ ADEV void q8k_block_wt(const float (&v)[4], int lane, int8_t* qs_blk, float* d_o
   if (lane == 0) __hip_atomic_store(d_out, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// One rotated pair (src/infer.cpp:659-666) with every product and sum rounded on its own: hipcc contracts `v0 * c - v1 * s` into
+// an fma whose choice of operand depends on the surrounding code, so two instantiations of the same source line can differ in
+// the last bit (round 3: seen between two instantiations of mla_head_kernel).  This is the oracle's arithmetic (-ffp-contract=off).
+// (HIP's __fmul_rn / __fsub_rn are plain operators and contract like them: the pragma is what pins the rounding.)
+ADEV void rope_rot(float v0, float v1, float c, float s, float& re, float& im) {
+#pragma clang fp contract(off)
+  const float a = v0 * c, b = v1 * s, d = v0 * s, e = v1 * c;
+  re = a - b;
+  im = d + e;
+}
 // RoPE of the head's query (in LDS, in place), key / value assembly from the LDS copy of this head's
 // kv_b rows, f16 cache write at kv_pos, rotation of the attention-sink keys (src/infer.cpp:956-1020).
 template <int NT>
@@ -154,8 +164,7 @@ ADEV void rope_kv_from_lds(const AttnMhaArgs& a, const StepParams* __restrict__ 
   if (tid < rope / 2) {  // rope (V2: de-interleaving) src/infer.cpp:648-668; rope_v3 :670-685
     const float v0 = q_s[nope + 2 * tid], v1 = q_s[nope + 2 * tid + 1];
     const float c = sp->rope_cs[2 * tid], s = sp->rope_cs[2 * tid + 1];
-    qre = v0 * c - v1 * s;
-    qim = v0 * s + v1 * c;
+    rope_rot(v0, v1, c, s, qre, qim);
   }
   __syncthreads();
   if (tid < rope / 2) {
@@ -176,7 +185,8 @@ ADEV void rope_kv_from_lds(const AttnMhaArgs& a, const StepParams* __restrict__ 
     const float* kr = a.kv_a + a.lora;
     const float v0 = kr[2 * tid], v1 = kr[2 * tid + 1];
     const float c = sp->rope_cs[2 * tid], s = sp->rope_cs[2 * tid + 1];
-    const float re = v0 * c - v1 * s, im = v0 * s + v1 * c;
+    float re, im;
+    rope_rot(v0, v1, c, s, re, im);
     if (a.is_v3) {
       kc[nope + 2 * tid] = f2h(re);
       kc[nope + 2 * tid + 1] = f2h(im);
@@ -193,8 +203,7 @@ ADEV void rope_kv_from_lds(const AttnMhaArgs& a, const StepParams* __restrict__ 
     if (tid < rope / 2) {
       const float v0 = h2f(kh[2 * tid]), v1 = h2f(kh[2 * tid + 1]);
       const float c = sp->rope_cs1[2 * tid], s = sp->rope_cs1[2 * tid + 1];
-      re = v0 * c - v1 * s;
-      im = v0 * s + v1 * c;
+      rope_rot(v0, v1, c, s, re, im);
     }
     __syncthreads();
     if (tid < rope / 2) {

@@ -579,6 +579,12 @@ int launch_head_attn(hipStream_t st, const HeadAttnArgs& A0, const StepParams* s
 // scores the shared latent cache (every head reads the same (kv_len x 576) f16 rows: L2 / Infinity-Cache hits),
 // softmax, mixes the latent values, applies the head's wv_b rows (128 x 512) and leaves the Q8_K copy for wo.
 // ------------------------------------------------------------------------------------
+// (Round 3, measured and rejected: the second-stage projections FOLDED into this launch the way the MHA launch consumes
+// wq_b || wkv_b - head h normalises / quantises q_a itself and computes its 64 + 512 rows of wq_rope_b || wc straight into
+// LDS, the latent's cache write as workgroup 0 of the same launch publishing a per-step tag, the heads scoring the rows written
+// during the launch last (write-through stores + sc1 loads; an agent acquire in 2048 waves cost 14 us).  Bit-identical to
+// the separate launch, and 24.6 us against 11.0 + 11.5: 290 KB of rows per head at the ~26 GB/s one CU streams are 11 us on
+// 128 CUs - exactly what the 256-CU launch and its boundary cost.  scratch/exp_mla_fold/ in the builder's tree)
 template <int QT>
 __global__ __launch_bounds__(1024) void mla_head_kernel(const MlaHeadArgs A, const StepParams* __restrict__ sp) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -630,7 +636,8 @@ __global__ __launch_bounds__(1024) void mla_head_kernel(const MlaHeadArgs A, con
     const float* qr = a.q_rope + (size_t)h * rope;
     const float v0 = qr[2 * tid], v1 = qr[2 * tid + 1];
     const float c = sp->rope_cs[2 * tid], s = sp->rope_cs[2 * tid + 1];
-    const float re = v0 * c - v1 * s, im = v0 * s + v1 * c;
+    float re, im;
+    ad::rope_rot(v0, v1, c, s, re, im);
     if (a.is_v3) {
       q_s[lora + 2 * tid] = re;
       q_s[lora + 2 * tid + 1] = im;

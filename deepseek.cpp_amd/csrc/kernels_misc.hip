@@ -376,8 +376,7 @@ DEV void rope_pairs(float* vec, int d, const float* cs, int is_v3, int tid, int 
   if (p < d / 2) {
     const float v0 = vec[2 * p], v1 = vec[2 * p + 1];
     const float c = cs[2 * p], s = cs[2 * p + 1];
-    re = v0 * c - v1 * s;
-    im = v0 * s + v1 * c;
+    ad::rope_rot(v0, v1, c, s, re, im);
   }
   __syncthreads();
   if (p < d / 2) {
@@ -639,7 +638,8 @@ DEV void rope_kv_mha_body(const AttnMhaArgs& a, const StepParams* __restrict__ s
     if (tid < rope / 2) {  // rope (V2: de-interleaving) src/infer.cpp:648-668; rope_v3 :670-685
       const float v0 = qg[nope + 2 * tid], v1 = qg[nope + 2 * tid + 1];
       const float c = sp->rope_cs[2 * tid], s = sp->rope_cs[2 * tid + 1];
-      const float re = v0 * c - v1 * s, im = v0 * s + v1 * c;
+      float re, im;
+      ad::rope_rot(v0, v1, c, s, re, im);
       if (a.is_v3) {
         q_lds[nope + 2 * tid] = re;
         q_lds[nope + 2 * tid + 1] = im;
@@ -661,7 +661,8 @@ DEV void rope_kv_mha_body(const AttnMhaArgs& a, const StepParams* __restrict__ s
     const float* kr = a.kv_a + a.lora;
     const float v0 = kr[2 * tid], v1 = kr[2 * tid + 1];
     const float c = sp->rope_cs[2 * tid], s = sp->rope_cs[2 * tid + 1];
-    const float re = v0 * c - v1 * s, im = v0 * s + v1 * c;
+    float re, im;
+    ad::rope_rot(v0, v1, c, s, re, im);
     if (a.is_v3) {
       kc[nope + 2 * tid] = f2h(re);
       kc[nope + 2 * tid + 1] = f2h(im);
@@ -678,8 +679,7 @@ DEV void rope_kv_mha_body(const AttnMhaArgs& a, const StepParams* __restrict__ s
     if (tid < rope / 2) {
       const float v0 = h2f(kh[2 * tid]), v1 = h2f(kh[2 * tid + 1]);
       const float c = sp->rope_cs1[2 * tid], s = sp->rope_cs1[2 * tid + 1];
-      re = v0 * c - v1 * s;
-      im = v0 * s + v1 * c;
+      ad::rope_rot(v0, v1, c, s, re, im);
     }
     __syncthreads();
     if (tid < rope / 2) {
@@ -850,7 +850,8 @@ __global__ __launch_bounds__(256) void rope_kv_mla_kernel(AttnMlaArgs a, const S
     const float* kr = a.kv_a + lora;
     const float v0 = kr[2 * tid], v1 = kr[2 * tid + 1];
     const float c = sp->rope_cs[2 * tid], s = sp->rope_cs[2 * tid + 1];
-    const float re = v0 * c - v1 * s, im = v0 * s + v1 * c;
+    float re, im;
+    ad::rope_rot(v0, v1, c, s, re, im);
     if (a.is_v3) {
       rc[2 * tid] = f2h(re);
       rc[2 * tid + 1] = f2h(im);
@@ -865,8 +866,7 @@ __global__ __launch_bounds__(256) void rope_kv_mla_kernel(AttnMlaArgs a, const S
     if (tid < rope / 2) {
       const float v0 = h2f(kh[2 * tid]), v1 = h2f(kh[2 * tid + 1]);
       const float c = sp->rope_cs1[2 * tid], s = sp->rope_cs1[2 * tid + 1];
-      re = v0 * c - v1 * s;
-      im = v0 * s + v1 * c;
+      ad::rope_rot(v0, v1, c, s, re, im);
     }
     __syncthreads();
     if (tid < rope / 2) {

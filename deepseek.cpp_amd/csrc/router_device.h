@@ -284,12 +284,21 @@ RDEV void mla_kv_write_body(const MlaKvArgs& a, const StepParams* __restrict__ s
   uint16_t* nc = a.nope_cache + (size_t)kv_pos * lora;
   uint16_t* rc = a.rope_cache + (size_t)kv_pos * rope;
   if (work)
-    for (int i = tid; i < lora; i += 256) nc[i] = ad::f2h(a.kv_a[i] * scale * a.norm_w[i]);
+    for (int i = tid; i < lora; i += 256) {
+      // The reference rounds the product to f32 and THEN to f16 (src/infer.cpp:1092-1095, _cvtss_sh).  hipcc folds the last
+      // product into the conversion (v_fma_mixlo_f16: ONE rounding) in the scalar form of this loop and not in its two-wide
+      // form (v_pk_mul_f32 + v_cvt_pk_f16_f32), so instantiations of this body disagreed in one entry of ~500 by one f16
+      // place (round 3: seen when the body was instantiated with write-through stores).  The empty asm pins the f32 rounding.
+      float y = a.kv_a[i] * scale * a.norm_w[i];
+      asm volatile("" : "+v"(y));
+      nc[i] = ad::f2h(y);
+    }
   if (tid < rope / 2) {
     const float* kr = a.kv_a + lora;
     const float v0 = kr[2 * tid], v1 = kr[2 * tid + 1];
     const float c = sp->rope_cs[2 * tid], s = sp->rope_cs[2 * tid + 1];
-    const float re = v0 * c - v1 * s, im = v0 * s + v1 * c;
+    float re, im;
+    ad::rope_rot(v0, v1, c, s, re, im);
     if (a.is_v3) {
       rc[2 * tid] = ad::f2h(re);
       rc[2 * tid + 1] = ad::f2h(im);
@@ -304,8 +313,7 @@ RDEV void mla_kv_write_body(const MlaKvArgs& a, const StepParams* __restrict__ s
     if (tid < rope / 2) {
       const float v0 = ad::h2f(kh[2 * tid]), v1 = ad::h2f(kh[2 * tid + 1]);
       const float c = sp->rope_cs1[2 * tid], s = sp->rope_cs1[2 * tid + 1];
-      re = v0 * c - v1 * s;
-      im = v0 * s + v1 * c;
+      ad::rope_rot(v0, v1, c, s, re, im);
     }
     __syncthreads();
     if (tid < rope / 2) {
