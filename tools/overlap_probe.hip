@@ -14,6 +14,11 @@
 //   mode 2  two alternating streams + counters, eager launches
 //   mode 3  two alternating streams + counters, each stream's launches captured in its own hipGraph
 //   mode 4  one stream, hipExtAnyOrderLaunch + counters (documented as unsupported on gfx9: probe)
+//   mode 5  as 1, arrival counters sharded over 8 words 256 B apart (workgroup index & 7)
+//   mode 6  as 4 with the sharded counters
+// Each mode with prefetch = 0 / 1 (1: a kernel requests its first weight chunk BEFORE it waits for its predecessor).
+// MI355X, round 3, us per layer at prefetch 0 / 1: mode 0 76.8 / 74.1, 1 94.5 / 92.7, 2 159 / 137, 3 160 / 136, 4 88.2 / 81.9,
+// 5 80.8 / 77.6, 6 77.9 / 73.7: any-order launches do overlap on gfx950, and the best counter scheme equals plain boundaries.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/_build/overlap_probe tools/overlap_probe.hip
 #include <hip/hip_runtime.h>
