@@ -8,7 +8,8 @@ tensor out on the GPU at load time.  This tool persists that layout: for every K
 `X.qs`, `X.sc`, (`X.hm`,) `X.dm` -- per plane all experts back to back, so an expert-sharded rank reads one contiguous
 range per plane -- and a 1-byte marker under the original name; everything else (norms, router, F8 / F16 / F32 tensors,
 the tokenizer) is copied verbatim; `__metadata__` gains `gpu_layout = planes-v1`.  dsk_model_load_dseek recognises the
-key and copies the planes straight into HBM (no staging buffer, no repack kernels: csrc/loader.cpp bind_plane_set).
+key and copies the planes through the pinned ring straight into their device planes (no DEVICE staging buffer, no repack
+kernels: csrc/loader.cpp bind_plane_set).
 The reference format stays the interchange format: the reference itself cannot read the repacked directory.
 """
 from __future__ import annotations
