@@ -207,6 +207,14 @@ struct MoeFfnArgs {
   int16_t* hq_bsums;     // [slot][hb_stride / 16]
   unsigned* blk_ctr;     // [K x (mi / 256)] arrivals per block; zero between launches
   unsigned* err;         // host-visible: set when a bounded spin gives up
+  // tail prefetch (option "tail_prefetch"): pf_wgs extra workgroups behind the grid (one per XCD: workgroup b runs on XCD
+  // b % 8; they start when the grid's first workgroups have left) READ the cold lines the NEXT launch of the token opens
+  // with - the next block's attention-norm weights and the descriptor of its first-stage projections - into their XCD's L2:
+  // first-stage projections 7.12 -> 6.77 us, this launch unchanged.  (The same behind wo for the router launch and behind
+  // the dense w2: no gain for the consumer, +0.7 us for the producer - its tail is short.)
+  int pf_wgs;
+  const void* pf_p[3];
+  int pf_n[3];
   int lprA_log2, lprB_log2;  // lanes per row of the two halves (= the two-launch plans': bit-identical results)
   int UA, rows_wg, lds_a, lds_b, lds_o, grid;  // filled by moe_ffn_plan
   int spin_limit;        // polls before the hand-off wait gives up (0: 2^20); < 0: fault injection (workgroup 0 reports a give-up)

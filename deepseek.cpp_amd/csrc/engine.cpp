@@ -228,6 +228,7 @@ extern "C" int dsk_model_create(dsk_ctx* ctx, const dsk_config* cfg, dsk_model**
   m->mha_split_min = env_i("DSK_MHA_SPLIT_MIN", 0);
   if (getenv("DSK_MOE_TIMELINE") || getenv("DSK_TIMELINE")) m->want_timeline = true;
   if (getenv("DSK_NO_MOE_Q8_HANDOFF")) m->moe_q8_handoff = false;
+  if (getenv("DSK_TAIL_PF")) m->tail_prefetch = atoi(getenv("DSK_TAIL_PF"));
   if (getenv("DSK_NO_FUSE_MOE_FLOAT")) m->fuse_moe_float = false;
 #endif
   *out = m;
@@ -251,6 +252,7 @@ extern "C" int dsk_model_set_option(dsk_model* m, const char* key, int value) {
   else if (k == "timeline") m->want_timeline = value != 0;
   else if (k == "moe_spin_limit") m->moe_spin_limit = value;
   else if (k == "moe_q8_handoff") m->moe_q8_handoff = value != 0;
+  else if (k == "tail_prefetch") m->tail_prefetch = value;
   else if (k == "fuse_moe_float") m->fuse_moe_float = value != 0;
   else if (k == "force_exchange") m->force_exchange = value != 0;
   else if (k == "graph_with_comm") m->graph_with_comm = value != 0;

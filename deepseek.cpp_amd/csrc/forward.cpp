@@ -431,6 +431,17 @@ int build_plans(dsk_model* m) {
   }
   (void)H;
   HIP_TRY(hipMalloc((void**)&m->plans_dev, m->plans.size() * sizeof(GemvLaunch)));
+  if (m->tail_prefetch > 0 && !m->sharded()) {  // the fused expert launch's tail reads what the NEXT block opens with (MoeFfnArgs::pf_wgs)
+    for (int l = 0; l < nl; ++l) {
+      if (m->moe_ffn[l].grid <= 0) continue;
+      MoeFfnArgs& a = m->moe_ffn[l];
+      const int nplan = l + 1 < nl ? m->lp_qkv_a[l + 1] : m->lp_head;
+      a.pf_wgs = m->tail_prefetch;
+      a.pf_p[0] = l + 1 < nl ? (const void*)m->L[l + 1].t[DSK_ROLE_ATTN_NORM].qs : (const void*)m->g[DSK_ROLE_FINAL_NORM].qs;
+      a.pf_n[0] = c.dim * 4;
+      if (nplan >= 0) { a.pf_p[1] = m->plans_dev + nplan; a.pf_n[1] = (int)sizeof(GemvLaunch); }
+    }
+  }
   HIP_TRY(hipMemcpy(m->plans_dev, m->plans.data(), m->plans.size() * sizeof(GemvLaunch), hipMemcpyHostToDevice));
   m->scratch_bytes += (double)m->plans.size() * sizeof(GemvLaunch);
   return DSK_OK;

@@ -752,6 +752,21 @@ DEV void rows_dot_kq_exact(const KQRsrc& B, int sub, int q, const int (&rowblk)[
   }
 }
 
+// tail prefetch workgroup (MoeFfnArgs::pf_wgs): plain cacheable 16-byte loads over up to three ranges, results discarded
+DEV void tail_prefetch(const void* const (&p)[3], const int (&n)[3], int tid, int nthreads) {
+  u32 acc = 0;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const uint8_t* b = static_cast<const uint8_t*>(p[r]);
+    if (!b) continue;
+    for (int off = tid * 16; off + 16 <= n[r]; off += nthreads * 16) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(b + off);
+      acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+  }
+  asm volatile("" ::"v"(acc));
+}
+
 template <int QT, int R, int U, bool GLU>
 DEV void rows_dot_f(const WPtr& P, int n, int b0, int b1, int lpr_log2, int lane, const int (&row)[R], const uint8_t* lds,
                     float (&acc)[R], float (&acc2)[R]) {

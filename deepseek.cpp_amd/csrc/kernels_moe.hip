@@ -64,7 +64,11 @@ __global__ __launch_bounds__(1024) void moe_ffn_kernel(const MoeFfnArgs a) {
   constexpr int NW = 16;
   constexpr bool Q2 = QT == DSK_QUANT_Q2_K;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int bid = blockIdx.x, G = gridDim.x;
+  const int bid = blockIdx.x, G = a.grid;
+  if (bid >= G) {  // tail prefetch workgroups (MoeFfnArgs::pf_wgs): run when the first workgroups of the grid have left
+    tail_prefetch(a.pf_p, a.pf_n, tid, 1024);
+    return;
+  }
   uint8_t* actA = smem;
   uint8_t* actB = smem + a.lds_a;                                            // slots x lds_b item records
   float* o_s = reinterpret_cast<float*>(smem + a.lds_a + (size_t)a.lds_b * (a.K + 1));  // [slot][rows_wg] slot outputs
@@ -354,9 +358,12 @@ __global__ __launch_bounds__(1024) void moe_ffn_f_kernel(const MoeFfnArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ float scratch[16];
   constexpr int NW = 16;
-  constexpr int ESZ = FTraits<QT>::ESZ;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int bid = blockIdx.x, G = gridDim.x;
+  const int bid = blockIdx.x, G = a.grid;
+  if (bid >= G) {  // tail prefetch workgroups (MoeFfnArgs::pf_wgs)
+    tail_prefetch(a.pf_p, a.pf_n, tid, 1024);
+    return;
+  }
   float* actA = reinterpret_cast<float*>(smem);                                  // rmsnorm(x), dim floats
   float* actB = reinterpret_cast<float*>(smem + a.lds_a);                        // [slot][lds_b / 4] hidden vectors
   float* o_s = reinterpret_cast<float*>(smem + a.lds_a + (size_t)a.lds_b * (a.K + 1));  // [slot][rows_wg] slot outputs
@@ -598,8 +605,8 @@ int launch_moe_ffn(hipStream_t st, const MoeFfnArgs& a, hipEvent_t ev_start, hip
   const size_t lds = (size_t)a.lds_a + (size_t)a.lds_b * (a.K + 1) + a.lds_o;
   auto go = [&](auto k) {
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (ev_start && ev_stop) hipExtLaunchKernelGGL(k, dim3(a.grid), dim3(1024), (uint32_t)lds, st, ev_start, ev_stop, 0u, a);
-    else hipLaunchKernelGGL(k, dim3(a.grid), dim3(1024), lds, st, a);
+    if (ev_start && ev_stop) hipExtLaunchKernelGGL(k, dim3(a.grid + (a.pf_wgs > 0 ? a.pf_wgs : 0)), dim3(1024), (uint32_t)lds, st, ev_start, ev_stop, 0u, a);
+    else hipLaunchKernelGGL(k, dim3(a.grid + (a.pf_wgs > 0 ? a.pf_wgs : 0)), dim3(1024), lds, st, a);
   };
   if (a.quant == DSK_QUANT_Q2_K) go(moe_ffn_kernel<DSK_QUANT_Q2_K, MOE_UA, 4>);
   else if (a.quant == DSK_QUANT_F8E5M2) go(moe_ffn_f_kernel<DSK_QUANT_F8E5M2>);

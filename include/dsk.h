@@ -188,6 +188,10 @@ int dsk_model_destroy(dsk_model* m);
  *   "rider_fill"      4  workgroup fill divisor of the shared expert's rider (1..16)
  *   "mla_flash_min" 320  context length from which MLA attention runs on the matrix cores
  *   "mha_split_min" 1024 context length from which MHA attention splits a head's context over workgroups
+ *   "tail_prefetch"   8  workgroups behind the fused expert launch that read the next block's norm weights and first
+ *                        launch descriptor into the XCDs' L2 (0: off; results unaffected)
+ *   "moe_q8_handoff"  1  fused expert launch: hidden vectors handed over as Q8_K, quantised once by their producers
+ *   "fuse_moe_float"  1  fused expert launch for F8E5M2 / F16 / F32 weights too (0: two launches; bit-identical)
  *   "timeline"        0  in-kernel wall-clock stamps for dsk_model_get_timeline
  *   "moe_spin_limit"  0  polls before the fused expert launch's hand-off wait gives up (0: 2^20); < 0: fault
  *                        injection (a give-up is reported although the hand-off succeeded: exercises the fallback)
