@@ -213,8 +213,8 @@ struct MoeFfnArgs {
   // first-stage projections 7.12 -> 6.77 us, this launch unchanged.  (The same behind wo for the router launch and behind
   // the dense w2: no gain for the consumer, +0.7 us for the producer - its tail is short.)
   int pf_wgs;
-  const void* pf_p[3];
-  int pf_n[3];
+  const void* pf_p[6];
+  int pf_n[6];
   int lprA_log2, lprB_log2;  // lanes per row of the two halves (= the two-launch plans': bit-identical results)
   int UA, rows_wg, lds_a, lds_b, lds_o, grid;  // filled by moe_ffn_plan
   int spin_limit;        // polls before the hand-off wait gives up (0: 2^20); < 0: fault injection (workgroup 0 reports a give-up)
@@ -346,6 +346,11 @@ struct HeadAttnArgs {
   int8_t* tap_qs;
   float* tap_d;
   int tap_stride;
+  // prefetch workgroups behind the heads' (MoeFfnArgs::pf_wgs; here they run at once on CUs this launch leaves idle): the
+  // cold lines wo opens with
+  int pf_wgs;
+  const void* pf_p[6];
+  int pf_n[6];
 };
 #define MHA_SPLIT_MIN_KV 1024  // below this one workgroup per head is faster (default; DSK_MHA_SPLIT_MIN overrides)
 #define MHA_SPLIT_MAX 16
@@ -415,6 +420,9 @@ struct MlaHeadArgs {
   int8_t* tap_qs;
   float* tap_d;
   float* tap_o;
+  int pf_wgs;             // prefetch workgroups behind the heads' (HeadAttnArgs::pf_wgs)
+  const void* pf_p[6];
+  int pf_n[6];
 };
 int mla_head_plan(MlaHeadArgs& A);
 int launch_mla_head(hipStream_t st, const MlaHeadArgs& A, const StepParams* sp, int max_kv);

@@ -127,7 +127,7 @@ struct dsk_model {
   unsigned* moe_blk_ctr = nullptr; // per-block arrivals of the fused expert launch (hidden vectors quantised by their producers)
   bool fuse_moe_float = true;      // option "fuse_moe_float": the fused expert launch for F8E5M2 / F16 / F32 weights too
   bool moe_q8_handoff = true;      // option "moe_q8_handoff"
-  int tail_prefetch = 8;           // option "tail_prefetch": workgroups behind the fused expert launch that read the next block's cold lines (0: off)
+  int tail_prefetch = 8;           // option "tail_prefetch": cold-line prefetch workgroups per launch that has room for them (forward.cpp build_plans; 0: off)
   // DSK_TIMELINE=1 (debug): 8 wall-clock stamps per workgroup of the LAST launch of each kind in a token;
   // kind 0 first-stage projections, 1 per-head attention, 2 wo, 3 router + shared expert, 4 fused routed experts
   unsigned long long* moe_timeline = nullptr;  // base of [8 kinds][1024 workgroups][8]

@@ -431,14 +431,41 @@ int build_plans(dsk_model* m) {
   }
   (void)H;
   HIP_TRY(hipMalloc((void**)&m->plans_dev, m->plans.size() * sizeof(GemvLaunch)));
-  if (m->tail_prefetch > 0 && !m->sharded()) {  // the fused expert launch's tail reads what the NEXT block opens with (MoeFfnArgs::pf_wgs)
+  if (m->tail_prefetch > 0 && !m->sharded()) {
+    // Cold lines: every launch opens with lines nobody has touched since the previous token - its descriptor, its norm
+    // weights - and waits ~1-2 us for them from HBM.  Workgroups that cost nothing read them into every XCD's L2 ahead of
+    // time (one per XCD: workgroup b runs on XCD b % 8): behind the heads of the per-head attention launch, on the 128 CUs it
+    // leaves idle, what wo and the FFN's first launch open with; behind the fused expert launch, as its first workgroups
+    // leave, what the next block's first launch opens with.  Token 5.06-5.11 -> 4.94-4.96 ms on one box, MLA 5.53-5.55 -> 5.40-5.44
+    // (first-stage projections 7.0 -> 6.7 us, wo 11.75 -> 10.9, the gate's bias row; the attention launch itself +0.6 with its 8
+    // extra workgroups).  More lines behind the expert launch (the
+    // next block's latent norm weights) lengthen its tail by 0.5 us and lose.
+    auto f32v = [&](const DTensor& t, int n, const void** p, int* bytes) { if (t.bound()) { *p = t.qs; *bytes = n * 4; } };
     for (int l = 0; l < nl; ++l) {
+      if (!c.use_mla && m->lp_wo[l] >= 0 && m->head_attn[l].tkv.n > 0) {
+        HeadAttnArgs& A = m->head_attn[l];
+        const int nxt = m->L[l].is_moe ? m->lp_sh13[l] : m->lp_w13[l];
+        A.pf_wgs = m->tail_prefetch;
+        A.pf_p[0] = m->plans_dev + m->lp_wo[l]; A.pf_n[0] = (int)sizeof(GemvLaunch);
+        f32v(m->L[l].t[DSK_ROLE_FFN_NORM], c.dim, &A.pf_p[1], &A.pf_n[1]);
+        if (nxt >= 0) { A.pf_p[2] = m->plans_dev + nxt; A.pf_n[2] = (int)sizeof(GemvLaunch); }
+        if (m->L[l].is_moe) f32v(m->L[l].t[DSK_ROLE_MOEGATE_BIAS], c.n_routed_experts, &A.pf_p[3], &A.pf_n[3]);  // the gate workgroup's
+        // (the step parameters - rope table - as a further range: no gain)
+      }
+      if (c.use_mla && m->lp_wo[l] >= 0 && m->mla_head[l].a.n_heads > 0) {
+        MlaHeadArgs& A = m->mla_head[l];
+        const int nxt = m->L[l].is_moe ? m->lp_sh13[l] : m->lp_w13[l];
+        A.pf_wgs = m->tail_prefetch;
+        A.pf_p[0] = m->plans_dev + m->lp_wo[l]; A.pf_n[0] = (int)sizeof(GemvLaunch);
+        f32v(m->L[l].t[DSK_ROLE_FFN_NORM], c.dim, &A.pf_p[1], &A.pf_n[1]);
+        if (nxt >= 0) { A.pf_p[2] = m->plans_dev + nxt; A.pf_n[2] = (int)sizeof(GemvLaunch); }
+        if (m->L[l].is_moe) f32v(m->L[l].t[DSK_ROLE_MOEGATE_BIAS], c.n_routed_experts, &A.pf_p[3], &A.pf_n[3]);
+      }
       if (m->moe_ffn[l].grid <= 0) continue;
       MoeFfnArgs& a = m->moe_ffn[l];
       const int nplan = l + 1 < nl ? m->lp_qkv_a[l + 1] : m->lp_head;
       a.pf_wgs = m->tail_prefetch;
-      a.pf_p[0] = l + 1 < nl ? (const void*)m->L[l + 1].t[DSK_ROLE_ATTN_NORM].qs : (const void*)m->g[DSK_ROLE_FINAL_NORM].qs;
-      a.pf_n[0] = c.dim * 4;
+      f32v(l + 1 < nl ? m->L[l + 1].t[DSK_ROLE_ATTN_NORM] : m->g[DSK_ROLE_FINAL_NORM], c.dim, &a.pf_p[0], &a.pf_n[0]);
       if (nplan >= 0) { a.pf_p[1] = m->plans_dev + nplan; a.pf_n[1] = (int)sizeof(GemvLaunch); }
     }
   }

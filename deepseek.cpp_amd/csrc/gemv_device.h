@@ -752,11 +752,11 @@ DEV void rows_dot_kq_exact(const KQRsrc& B, int sub, int q, const int (&rowblk)[
   }
 }
 
-// tail prefetch workgroup (MoeFfnArgs::pf_wgs): plain cacheable 16-byte loads over up to three ranges, results discarded
-DEV void tail_prefetch(const void* const (&p)[3], const int (&n)[3], int tid, int nthreads) {
+// tail prefetch workgroup (MoeFfnArgs::pf_wgs): plain cacheable 16-byte loads over up to six ranges, results discarded
+DEV void tail_prefetch(const void* const (&p)[6], const int (&n)[6], int tid, int nthreads) {
   u32 acc = 0;
 #pragma unroll
-  for (int r = 0; r < 3; ++r) {
+  for (int r = 0; r < 6; ++r) {
     const uint8_t* b = static_cast<const uint8_t*>(p[r]);
     if (!b) continue;
     for (int off = tid * 16; off + 16 <= n[r]; off += nthreads * 16) {

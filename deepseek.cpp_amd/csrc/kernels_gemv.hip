@@ -333,6 +333,10 @@ __global__ __launch_bounds__(1024) void head_attn_kernel(const HeadAttnArgs A, c
   constexpr int NW = 16;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int S = A.n_split;  // workgroups per head (1: the whole context here)
+  if ((int)blockIdx.x >= A.a.n_heads * (S > 1 ? S : 1)) {  // prefetch workgroups (HeadAttnArgs::pf_wgs)
+    tail_prefetch(A.pf_p, A.pf_n, tid, 1024);
+    return;
+  }
   const int h = S > 1 ? (int)blockIdx.x / S : (int)blockIdx.x, split = S > 1 ? (int)blockIdx.x - h * S : 0;
   const AttnMhaArgs& a = A.a;
   unsigned long long* tl = A.timeline && blockIdx.x < DSK_TL_WGS ? A.timeline + (size_t)blockIdx.x * 8 : nullptr;  // (split contexts: H * n_split workgroups)
@@ -556,7 +560,7 @@ template <int QT>
 static int launch_head_attn_q(hipStream_t st, const HeadAttnArgs& A, const StepParams* sp, size_t lds) {
   auto k = head_attn_kernel<QT>;
   if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k, dim3(A.a.n_heads * (A.n_split > 1 ? A.n_split : 1)), dim3(1024), lds, st, A, sp);
+  hipLaunchKernelGGL(k, dim3(A.a.n_heads * (A.n_split > 1 ? A.n_split : 1) + (A.pf_wgs > 0 ? A.pf_wgs : 0)), dim3(1024), lds, st, A, sp);
   return DSK_OK;
 }
 int launch_head_attn(hipStream_t st, const HeadAttnArgs& A0, const StepParams* sp, int max_kv, int n_split) {
@@ -600,6 +604,10 @@ __global__ __launch_bounds__(1024) void mla_head_kernel(const MlaHeadArgs A, con
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int grp = lane >> 4, sl = lane & 15;
   const int h = blockIdx.x;
+  if (h >= A.a.n_heads) {  // prefetch workgroups (MlaHeadArgs::pf_wgs)
+    tail_prefetch(A.pf_p, A.pf_n, tid, 1024);
+    return;
+  }
   const AttnMlaArgs& a = A.a;
   const int lora = a.lora, rope = a.rope, kv_len = sp->kv_len;
   uint8_t* act = smem;
@@ -835,7 +843,7 @@ template <int QT>
 static int launch_mla_head_q(hipStream_t st, const MlaHeadArgs& A, const StepParams* sp, size_t lds) {
   auto k = mla_head_kernel<QT>;
   if (lds > 32 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k, dim3(A.a.n_heads), dim3(1024), lds, st, A, sp);
+  hipLaunchKernelGGL(k, dim3(A.a.n_heads + (A.pf_wgs > 0 ? A.pf_wgs : 0)), dim3(1024), lds, st, A, sp);
   return DSK_OK;
 }
 int launch_mla_head(hipStream_t st, const MlaHeadArgs& A, const StepParams* sp, int max_kv) {

@@ -188,8 +188,9 @@ int dsk_model_destroy(dsk_model* m);
  *   "rider_fill"      4  workgroup fill divisor of the shared expert's rider (1..16)
  *   "mla_flash_min" 320  context length from which MLA attention runs on the matrix cores
  *   "mha_split_min" 1024 context length from which MHA attention splits a head's context over workgroups
- *   "tail_prefetch"   8  workgroups behind the fused expert launch that read the next block's norm weights and first
- *                        launch descriptor into the XCDs' L2 (0: off; results unaffected)
+ *   "tail_prefetch"   8  cold-line prefetch: workgroups on CUs the per-head attention launch leaves idle, and behind the fused
+ *                        expert launch, read what the following launches open with (descriptors, norm weights, the gate's
+ *                        bias row) into the XCDs' L2 (0: off; results unaffected)
  *   "moe_q8_handoff"  1  fused expert launch: hidden vectors handed over as Q8_K, quantised once by their producers
  *   "fuse_moe_float"  1  fused expert launch for F8E5M2 / F16 / F32 weights too (0: two launches; bit-identical)
  *   "timeline"        0  in-kernel wall-clock stamps for dsk_model_get_timeline

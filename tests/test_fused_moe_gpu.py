@@ -185,3 +185,24 @@ def test_handoff_give_up_falls_back_to_the_two_launch_form(ctx):
     assert np.array_equal(out, B.run_block(moe_layer, x, 0))
     G.close()
     B.close()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("mla", [False, True], ids=["mha", "mla"])
+def test_cold_line_prefetch_changes_no_bits(ctx, mla):
+    """option "tail_prefetch" (default 8): extra workgroups of the per-head attention launch and of the fused expert launch
+    READ the lines the following launches open with; they write nothing, so logits with and without them are identical -
+    eager, graph, at full width (grid + 8 workgroups behind a launch whose own workgroups must all be resident)."""
+    import dsk
+    for c, T in ((synth.preset("tiny_v3", "q2_k", mla), True),
+                 (synth.preset("v3", "q2_k", mla, n_layers=3, first_k_dense_replace=1, n_routed_experts=32, max_seq_len=64), False)):
+        W = synth.synth_model(c, seed=29) if T else None
+        A = dsk.Model(ctx, c, W, synth_seed=None if T else 6)
+        B = dsk.Model(ctx, c, W, synth_seed=None if T else 6, options={"tail_prefetch": 0})
+        tok = 3
+        for pos in range(6):
+            la, lb = A.forward(tok, pos), B.forward(tok, pos)
+            assert np.array_equal(la, lb), pos
+            tok = int(np.argmax(la))
+        A.close()
+        B.close()
