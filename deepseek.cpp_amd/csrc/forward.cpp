@@ -450,6 +450,7 @@ int build_plans(dsk_model* m) {
         f32v(m->L[l].t[DSK_ROLE_FFN_NORM], c.dim, &A.pf_p[1], &A.pf_n[1]);
         if (nxt >= 0) { A.pf_p[2] = m->plans_dev + nxt; A.pf_n[2] = (int)sizeof(GemvLaunch); }
         if (m->L[l].is_moe) f32v(m->L[l].t[DSK_ROLE_MOEGATE_BIAS], c.n_routed_experts, &A.pf_p[3], &A.pf_n[3]);  // the gate workgroup's
+        else if (m->lp_w2[l] >= 0) { A.pf_p[3] = m->plans_dev + m->lp_w2[l]; A.pf_n[3] = (int)sizeof(GemvLaunch); }  // dense block: w2's descriptor
         // (the step parameters - rope table - as a further range: no gain)
       }
       if (c.use_mla && m->lp_wo[l] >= 0 && m->mla_head[l].a.n_heads > 0) {

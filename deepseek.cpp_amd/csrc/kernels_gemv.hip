@@ -334,6 +334,7 @@ __global__ __launch_bounds__(1024) void head_attn_kernel(const HeadAttnArgs A, c
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int S = A.n_split;  // workgroups per head (1: the whole context here)
   if ((int)blockIdx.x >= A.a.n_heads * (S > 1 ? S : 1)) {  // prefetch workgroups (HeadAttnArgs::pf_wgs)
+    // (one further workgroup per head reading the head's cached K / V rows into its XCD's L2: attention 16.96 -> 16.77 us, token unchanged)
     tail_prefetch(A.pf_p, A.pf_n, tid, 1024);
     return;
   }
