@@ -82,6 +82,9 @@ struct DTensor {
   float* scale = nullptr;   // F8 block scales
   bool scale_bound = false; // the ".scale" tensor was actually uploaded / synthesised (alloc_tensor only reserves it)
   size_t e_qs = 0, e_sc = 0, e_hm = 0, e_dm = 0, e_scale = 0;  // per-expert strides in bytes (scale: floats)
+  // Q2_K in the TILED layout (tile_device.h): qs = the tile records (rows padded to a multiple of 16 per matrix), e_qs = the
+  // bytes of one padded matrix, sc / dm unused
+  bool tiled = false;
   bool bound() const { return base != nullptr; }
 };
 
@@ -102,6 +105,7 @@ struct GemvTask {
   const int* expert_ids;                    // device: slot -> expert id (null: expert = slot)
   int slot, expert_base, local_experts;
   int rows, n;
+  int wt_tiled;            // host-side: the weights are tile records (tile_device.h)
   // activation vector
   int act_mode;            // ACT_*
   const int8_t* a_qs;      // ACT_Q8: ready Q8_K vector
@@ -141,6 +145,10 @@ struct GemvLaunch {
   // `bd_heads` equal (rows, n) matrices stacked along rows; head h reads activation a_f32 + h*n and
   // writes out + h*rows; bd_wgs workgroups per head
   int bd_heads, bd_wgs;
+  // Q2_K weights in the tiled layout (tile_device.h; kernels_tile.hip): qs / qs2 point at tile records, e_qs = bytes of one
+  // padded matrix of a stack, vrow_* count rows padded to 16 per task, part_unit is a multiple of 16; t_act = bytes of the
+  // staged activation vector in LDS, t_rcap = items a round's partials hold (behind it)
+  int tiled, t_act, t_rcap;
   // MoE combine folded into a TASKS launch (tasks = routed slots in k order, then the shared expert;
   // every task writes its own vector t[i].out): the LAST task to finish a row group (arrival counter
   // per group) runs  x[row] += w_k * out_k[row]  in k order, then + shared (src/infer.cpp:874-877,900-903)
@@ -170,6 +178,10 @@ struct GemvLaunch {
 extern thread_local hipEvent_t g_prof_start, g_prof_stop;
 int gemv_plan(GemvLaunch& h, int target_wgs);
 int gemv_launch(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& host);
+// the same for Q2_K weights in the tiled layout (kernels_tile.hip; gemv_plan / gemv_launch forward to them when h.tiled)
+int gemv_plan_tile(GemvLaunch& h, int target_wgs);
+int gemv_launch_tile(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& host);
+size_t tile_mat_bytes(size_t rows, size_t n);  // bytes of one (rows, n) Q2_K matrix in the tiled layout (rows padded to 16)
 
 // The routed experts of one MoE block in ONE launch (kernels_moe.hip): w1/w3 GLU units, per-slot hand-off, W2 units,
 // k-ordered combine.  Planes of the expert stacks + per-expert strides; the shared expert's W2 as a plain matrix.
@@ -274,6 +286,9 @@ int launch_moe_combine(hipStream_t st, float* x, const float* eout, const float*
 int launch_quantize_q8k(hipStream_t st, const float* x, int n, int8_t* qs, float* d, int16_t* bsums);
 int launch_norm_jobs(hipStream_t st, const NormJob* jobs, int n_jobs, const StepParams* sp);
 int launch_repack_q2k(hipStream_t st, const uint8_t* aos, size_t n_blocks, uint8_t* qs, uint8_t* sc, uint8_t* dm);
+int launch_repack_q2k_tiles(hipStream_t st, const uint8_t* aos, size_t gb0, size_t n_blocks, int rows, int nb, size_t e_bytes, uint8_t* tiles);
+int launch_planes_to_tiles_q2k(hipStream_t st, const uint8_t* qs, const uint8_t* sc, const uint8_t* dm, size_t gb0, size_t n_blocks, int rows, int nb,
+                               size_t e_bytes, uint8_t* tiles);
 int launch_repack_q3k(hipStream_t st, const uint8_t* aos, size_t n_blocks, uint8_t* qs, uint8_t* hm, uint8_t* sc, uint8_t* dm);
 int launch_embed(hipStream_t st, const DTensor& t, const StepParams* sp, int token_override, int b0, int b1, float* x);
 struct RouterArgs {       // F32 router GEMV (+ optional rmsnorm prologue) + moe_gate in the last workgroup

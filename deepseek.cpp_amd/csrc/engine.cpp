@@ -256,6 +256,10 @@ extern "C" int dsk_model_set_option(dsk_model* m, const char* key, int value) {
   else if (k == "fuse_moe_float") m->fuse_moe_float = value != 0;
   else if (k == "force_exchange") m->force_exchange = value != 0;
   else if (k == "graph_with_comm") m->graph_with_comm = value != 0;
+  else if (k == "q2k_tiles") {
+    if (m->any_bound) DSK_FAIL(DSK_ERR_STATE, "set_option: q2k_tiles must be set before the first tensor is bound");
+    m->q2k_tiles = value != 0;
+  }
   else DSK_FAIL(DSK_ERR_INVALID, "set_option: unknown option '%s'", key);
   return DSK_OK;
 }
@@ -315,7 +319,18 @@ const int ALL_LAYER_ROLES[] = {DSK_ROLE_ATTN_NORM, DSK_ROLE_Q_A_NORM, DSK_ROLE_K
 
 static bool is_routed_role(int role) { return role == DSK_ROLE_W1 || role == DSK_ROLE_W2 || role == DSK_ROLE_W3; }
 
-// allocate the device planes of a tensor; local = experts kept on this rank
+// Which Q2_K tensors live in the tiled layout (tile_device.h): the roles whose every consumer runs the matrix-pipe row
+// products.  Option "q2k_tiles" (before the first bind) switches the layout off for A/B comparisons.
+static bool role_tiled(const dsk_model* m, int role, int e, int quant) {
+  if (quant != DSK_QUANT_Q2_K || !m->q2k_tiles) return false;
+  switch (role) {
+    case DSK_ROLE_EMBED: case DSK_ROLE_OUTPUT: case DSK_ROLE_WQ: case DSK_ROLE_WQ_A: case DSK_ROLE_WKV_A: case DSK_ROLE_WO: return true;
+    case DSK_ROLE_W1: case DSK_ROLE_W2: case DSK_ROLE_W3: return e == 0;  // dense blocks
+    default: return false;
+  }
+}
+
+// allocate the device planes of a tensor (t.tiled set by the caller: Q2_K tile records instead); local = experts kept on this rank
 int alloc_tensor(int b0, int b1, DTensor& t, int quant, int e, int rows, int n, int local, int base) {
   t.quant = quant;
   t.n_experts = e;
@@ -326,7 +341,11 @@ int alloc_tensor(int b0, int b1, DTensor& t, int quant, int e, int rows, int n, 
   const size_t mats = e > 0 ? (size_t)local : 1;
   const size_t per = (size_t)rows * n;
   size_t o_qs = 0, o_sc = 0, o_hm = 0, o_dm = 0, o_scale = 0, total = 0;
-  if (quant == DSK_QUANT_Q2_K) {
+  if (quant != DSK_QUANT_Q2_K) t.tiled = false;
+  if (t.tiled) {  // tile records (tile_device.h): rows padded to 16 per matrix; padding rows stay zero (memset below)
+    t.e_qs = tile_mat_bytes(rows, n);
+    total = mats * t.e_qs;
+  } else if (quant == DSK_QUANT_Q2_K) {
     const size_t nblk = per / 256;
     t.e_qs = nblk * 64; t.e_sc = nblk * 16; t.e_dm = nblk * 4;
     o_qs = 0; o_sc = align_up(o_qs + mats * t.e_qs, 256); o_dm = align_up(o_sc + mats * t.e_sc, 256);
@@ -350,7 +369,9 @@ int alloc_tensor(int b0, int b1, DTensor& t, int quant, int e, int rows, int n, 
   HIP_TRY(hipMalloc((void**)&t.base, total));
   t.bytes = total;
   t.qs = t.base + o_qs;
-  if (quant == DSK_QUANT_Q2_K || quant == DSK_QUANT_Q3_K) {
+  if (t.tiled) {
+    if (rows & 15) HIP_TRY(hipMemset(t.base, 0, total));
+  } else if (quant == DSK_QUANT_Q2_K || quant == DSK_QUANT_Q3_K) {
     t.sc = t.base + o_sc;
     t.dm = t.base + o_dm;
     if (quant == DSK_QUANT_Q3_K) t.hm = t.base + o_hm;
@@ -379,7 +400,9 @@ int upload_tensor(dsk_ctx* ctx, DTensor& t, const HostSrc& src) {
   for (size_t b0 = 0; b0 < total_blocks; b0 += chunk_blocks) {
     const size_t nb = std::min(chunk_blocks, total_blocks - b0);
     DSK_TRY(stage_copy(ctx, src, off0 + b0 * bsz, stage, nb * bsz));
-    if (t.quant == DSK_QUANT_Q2_K)
+    if (t.tiled)
+      DSK_TRY(launch_repack_q2k_tiles(st, (const uint8_t*)stage, b0, nb, t.rows, t.n / 256, tile_mat_bytes(t.rows, t.n), t.qs));
+    else if (t.quant == DSK_QUANT_Q2_K)
       DSK_TRY(launch_repack_q2k(st, (const uint8_t*)stage, nb, t.qs + b0 * 64, t.sc + b0 * 16, t.dm + b0 * 4));
     else
       DSK_TRY(launch_repack_q3k(st, (const uint8_t*)stage, nb, t.qs + b0 * 64, t.hm + b0 * 32, t.sc + b0 * 12, t.dm + b0 * 2));
@@ -493,8 +516,10 @@ int bind_src(dsk_model* m, int role, int layer, int quant, const int32_t shape[4
   const size_t per_bytes = mat_bytes(quant, rs.rows, rs.n);
   if (bytes != per_bytes * mats) DSK_FAIL(DSK_ERR_INVALID, "bind: role %d layer %d has %zu bytes, expected %zu", r, layer, bytes, per_bytes * mats);
   if (t->bound()) DSK_FAIL(DSK_ERR_STATE, "bind: role %d layer %d bound twice", r, layer);
+  t->tiled = role_tiled(m, r, rs.e, quant);
   DSK_TRY(alloc_tensor(c.block_size[0], c.block_size[1], *t, quant, rs.e, rs.rows, rs.n, local, base));
   m->weight_bytes += (double)t->bytes;
+  m->any_bound = true;
   return upload_tensor(m->ctx, *t, src);
 }
 
@@ -522,6 +547,23 @@ int bind_planes(dsk_model* m, int role, int layer, int quant, const HostSrc plan
                          nblk * (quant == DSK_QUANT_Q2_K ? 4 : 2)};
   for (int i = 0; i < 4; ++i)
     if (bytes[i] != per[i] * mats) DSK_FAIL(DSK_ERR_INVALID, "bind: plane %d of role %d layer %d has %zu bytes, expected %zu", i, role, layer, bytes[i], per[i] * mats);
+  m->any_bound = true;
+  if (role_tiled(m, role, rs.e, quant)) {
+    // a tiled tensor from a planes-v1 checkpoint: the planes land in a temporary plane tensor and are re-laid-out on the device
+    DTensor tmp;
+    DSK_TRY(alloc_tensor(c.block_size[0], c.block_size[1], tmp, quant, rs.e, rs.rows, rs.n, local, base));
+    struct TmpTensor { DTensor t; ~TmpTensor() { if (t.base) hipFree(t.base); } } guard;
+    guard.t = tmp;
+    uint8_t* dstp[4] = {tmp.qs, tmp.sc, tmp.hm, tmp.dm};
+    for (int i = 0; i < 4 && lm; ++i)
+      if (per[i]) DSK_TRY(stage_copy(m->ctx, planes[i], (uint64_t)base * per[i], dstp[i], lm * per[i]));
+    t->tiled = true;
+    DSK_TRY(alloc_tensor(c.block_size[0], c.block_size[1], *t, quant, rs.e, rs.rows, rs.n, local, base));
+    m->weight_bytes += (double)t->bytes;
+    if (lm) DSK_TRY(launch_planes_to_tiles_q2k(m->ctx->stream, tmp.qs, tmp.sc, tmp.dm, 0, lm * nblk, rs.rows, rs.n / 256, tile_mat_bytes(rs.rows, rs.n), t->qs));
+    HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+    return DSK_OK;
+  }
   DSK_TRY(alloc_tensor(c.block_size[0], c.block_size[1], *t, quant, rs.e, rs.rows, rs.n, local, base));
   m->weight_bytes += (double)t->bytes;
   uint8_t* dst[4] = {t->qs, t->sc, t->hm, t->dm};
@@ -545,6 +587,8 @@ extern "C" int dsk_model_synthesize(dsk_model* m, uint64_t seed) {
     if (is_kq(rs.quant) && rs.n % 256) DSK_FAIL(DSK_ERR_INVALID, "synthesize: k-quant row length %d", rs.n);
     int base, local;
     shard_range(m, role, rs.e, &base, &local);
+    t->tiled = role_tiled(m, role, rs.e, rs.quant);
+    m->any_bound = true;
     DSK_TRY(alloc_tensor(c.block_size[0], c.block_size[1], *t, rs.quant, rs.e, rs.rows, rs.n, local, base));
     m->weight_bytes += (double)t->bytes;
     t->scale_bound = true;  // launch_fill_tensor writes the block scales of an F8 tensor too

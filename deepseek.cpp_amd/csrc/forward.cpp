@@ -90,6 +90,7 @@ static void task_weights(GemvTask& T, const DTensor& t) {
   T.qs = t.qs; T.sc = t.sc; T.hm = t.hm; T.dm = t.dm; T.scale = t.scale;
   T.rows = t.rows; T.n = t.n;
   T.local_experts = 1;
+  T.wt_tiled = t.tiled;
 }
 static void task_weights2(GemvTask& T, const DTensor& t3) {
   T.qs2 = t3.qs; T.sc2 = t3.sc; T.hm2 = t3.hm; T.dm2 = t3.dm; T.scale2 = t3.scale;
@@ -116,6 +117,9 @@ static void task_out_hb(const dsk_model* m, GemvTask& T, int layer, size_t off) 
 static void task_act_q8(GemvTask& T, const Q8Buf& q) { T.act_mode = ACT_Q8; T.a_qs = q.qs; T.a_d = q.d; T.a_bsums = q.bsums; }
 
 static int add_plan(dsk_model* m, GemvLaunch& h, int* idx_out) {
+  h.tiled = h.t[0].wt_tiled;  // every tensor of a launch has the same layout (engine.cpp role_tiled deals whole launches)
+  for (int i = 1; i < h.n_tasks; ++i)
+    if (h.t[i].wt_tiled != h.t[0].wt_tiled) DSK_FAIL(DSK_ERR_STATE, "launch plan: tasks with mixed weight layouts");
   h.b0 = std::max(1, m->c.block_size[0]);
   h.b1 = std::max(1, m->c.block_size[1]);
   h.act = m->c.act;

@@ -50,6 +50,12 @@ DEV float act_fn(float x, int act) {
 // ------------------------------------------------------------------------------------
 #define ITEM_LDS 80
 DEV size_t kq_lds_bytes(int n) { return (size_t)(n >> 6) * ITEM_LDS; }
+// staging layouts (template parameter LAY of the staging routines): item records with Q3_K / Q2_K meta, or the block records
+// of the tiled Q2_K path (tile_device.h: codes[256] linear | zeros[16] | (bsum hi[4], lo[4]) x 4 | d); a block is 320 bytes
+// in all three
+#define LAY_Q3 0
+#define LAY_Q2 1
+#define LAY_TILE 2
 
 // ------------------------------------------------------------------------------------
 // Q2_K: one item = (block b, quarter q): bytes qs[32*h + 16*lh .. +15].  Word k of the item, shifted by
@@ -150,8 +156,20 @@ DEV u32 wave_max_bits(u32 v) {
 
 // write one lane's share of a staged block: 4 consecutive int8 (elements 4*lane..+3), the sub-block
 // sum (lanes 4j) and the block scale (lanes 0..3, one per quarter record)
-template <bool Q2META>
+template <int LAY>
 DEV void q8k_store_lds(u32 packed, int quadsum, float d, int lane, uint8_t* blk) {
+  constexpr bool Q2META = LAY == LAY_Q2;
+  if (LAY == LAY_TILE) {
+    *reinterpret_cast<u32*>(blk + lane * 4) = packed;
+    if ((lane & 3) == 0) {
+      const int j = lane >> 2;
+      blk[272 + 8 * (j >> 2) + (j & 3)] = (uint8_t)(quadsum >> 8);
+      blk[276 + 8 * (j >> 2) + (j & 3)] = (uint8_t)(quadsum & 0xff);
+    }
+    if (lane < 4) *reinterpret_cast<u32*>(blk + 256 + lane * 4) = 0u;
+    if (lane == 0) *reinterpret_cast<float*>(blk + 304) = d;
+    return;
+  }
   const int h = lane >> 5, sidx = (lane >> 3) & 3, lh = (lane >> 2) & 1;
   uint8_t* rec = blk + (2 * h + lh) * ITEM_LDS;
   *reinterpret_cast<u32*>(rec + sidx * 16 + (lane & 3) * 4) = packed;
@@ -171,7 +189,7 @@ DEV void q8k_store_lds(u32 packed, int quadsum, float d, int lane, uint8_t* blk)
 }
 
 // rounding half of quantize_row_q8_K_ref given the block's signed max (src/quant.cpp:630-650)
-template <bool Q2META>
+template <int LAY>
 DEV void q8k_round_lds(const float (&v)[4], float vmax, int lane, uint8_t* blk) {
   int q[4] = {0, 0, 0, 0};
   float d = 0.f;
@@ -188,10 +206,10 @@ DEV void q8k_round_lds(const float (&v)[4], float vmax, int lane, uint8_t* blk) 
   int sum = q[0] + q[1] + q[2] + q[3];
   sum += (int)dpp_u32<DPP_XOR1>((u32)sum);
   sum += (int)dpp_u32<DPP_XOR2>((u32)sum);
-  q8k_store_lds<Q2META>(packed, sum, d, lane, blk);
+  q8k_store_lds<LAY>(packed, sum, d, lane, blk);
 }
 
-template <bool Q2META>
+template <int LAY>
 DEV void q8k_block_lds(const float (&v)[4], int lane, uint8_t* blk) {
   // max = signed value of the FIRST element with the largest |x| (src/quant.cpp:622-629)
   float amax_l = 0.f, vmax_l = 0.f;
@@ -205,7 +223,7 @@ DEV void q8k_block_lds(const float (&v)[4], int lane, uint8_t* blk) {
   const unsigned long long owners = __ballot(__builtin_bit_cast(u32, amax_l) == amax_bits);
   const int owner = __ffsll((long long)owners) - 1;
   const float vmax = u2f(__builtin_amdgcn_readlane(__builtin_bit_cast(u32, vmax_l), owner));
-  q8k_round_lds<Q2META>(v, vmax, lane, blk);
+  q8k_round_lds<LAY>(v, vmax, lane, blk);
 }
 
 // workgroup barrier for LDS traffic only: unlike __syncthreads() (a fence: s_waitcnt vmcnt(0) first) it leaves this wave's
@@ -295,10 +313,26 @@ struct ActSrc {
 DEV float pre_scale_of(const ActSrc& s) { return s.pre_scale; }
 DEV float pre_scale_of(const GemvTask&) { return 0.f; }
 
-template <bool Q2META, int NW, typename SRC>
+template <int LAY, int NW, typename SRC>
 DEV void stage_q8(const SRC& T, uint8_t* lds, int tid, float* scratch, unsigned long long* tl = nullptr) {
+  constexpr bool Q2META = LAY == LAY_Q2;
   const int n = T.n, nb = n >> 8;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  if (LAY == LAY_TILE && T.act_mode == ACT_Q8) {  // ready Q8_K vector into block records
+    for (int i = tid; i < (n >> 4); i += NW * 64) {
+      const int b = i >> 4, j = i & 15;
+      uint8_t* rec = lds + (size_t)b * 320;
+      *reinterpret_cast<u32x4*>(rec + j * 16) = reinterpret_cast<const u32x4*>(T.a_qs)[i];
+      const int bs = T.a_bsums[i];
+      rec[272 + 8 * (j >> 2) + (j & 3)] = (uint8_t)(bs >> 8);
+      rec[276 + 8 * (j >> 2) + (j & 3)] = (uint8_t)(bs & 0xff);
+    }
+    for (int b = tid; b < nb; b += NW * 64) {
+      *reinterpret_cast<u32x4*>(lds + (size_t)b * 320 + 256) = u32x4{0u, 0u, 0u, 0u};
+      *reinterpret_cast<float*>(lds + (size_t)b * 320 + 304) = T.a_d[b];
+    }
+    return;
+  }
   if (T.act_mode == ACT_Q8) {  // ready Q8_K vector: 16-byte runs (one sub-block each) go straight to their record
     for (int i = tid; i < (n >> 4); i += NW * 64) {
       const int b = i >> 4, j = i & 15, h = j >> 3, sidx = (j >> 1) & 3, lh = j & 1;
@@ -356,7 +390,7 @@ DEV void stage_q8(const SRC& T, uint8_t* lds, int tid, float* scratch, unsigned 
       const int b = wave + NW * k;
       if (b < nb) {
         float v[4] = {t[k].x * scale * wv[k].x, t[k].y * scale * wv[k].y, t[k].z * scale * wv[k].z, t[k].w * scale * wv[k].w};
-        q8k_block_lds<Q2META>(v, lane, lds + (size_t)b * 4 * ITEM_LDS);
+        q8k_block_lds<LAY>(v, lane, lds + (size_t)b * 4 * ITEM_LDS);
       }
     }
     return;
@@ -389,7 +423,7 @@ DEV void stage_q8(const SRC& T, uint8_t* lds, int tid, float* scratch, unsigned 
           v[2] = v[2] * scale * wv[k].z;
           v[3] = v[3] * scale * wv[k].w;
           }
-        q8k_block_lds<Q2META>(v, lane, lds + (size_t)b * 4 * ITEM_LDS);
+        q8k_block_lds<LAY>(v, lane, lds + (size_t)b * 4 * ITEM_LDS);
       }
     }
   }
@@ -415,8 +449,15 @@ DEV void stage_f32(const SRC& T, float* l_x, int tid, float* scratch) {
 }
 
 // parity tap: the staged item records of an n-vector back to the linear Q8_K form (int8 codes, block scales)
-template <bool Q2META>
+template <int LAY>
 __device__ __attribute__((noinline)) void dump_staged_q8(const uint8_t* lds, int n, int8_t* qs, float* d, int tid, int nthreads) {
+  constexpr bool Q2META = LAY == LAY_Q2;
+  if (LAY == LAY_TILE) {
+    for (int i = tid; i < (n >> 4); i += nthreads)
+      reinterpret_cast<u32x4*>(qs)[i] = *reinterpret_cast<const u32x4*>(lds + (size_t)(i >> 4) * 320 + (i & 15) * 16);
+    for (int b = tid; b < (n >> 8); b += nthreads) d[b] = *reinterpret_cast<const float*>(lds + (size_t)b * 320 + 304);
+    return;
+  }
   for (int i = tid; i < (n >> 4); i += nthreads) {  // 16-byte runs = sub-blocks
     const int b = i >> 4, j = i & 15, h = j >> 3, sidx = (j >> 1) & 3, lh = j & 1;
     const uint8_t* rec = lds + (size_t)(b * 4 + 2 * h + lh) * ITEM_LDS;

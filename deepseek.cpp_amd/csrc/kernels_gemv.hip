@@ -985,6 +985,7 @@ int launch_gemv_kvwrite(hipStream_t st, const GemvLaunch* dev, const GemvLaunch&
 }
 
 int gemv_launch(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& h) {
+  if (h.tiled) return gemv_launch_tile(st, dev, h);
   switch (h.quant) {
     case DSK_QUANT_F32: return launch_nw<DSK_QUANT_F32>(st, dev, h);
     case DSK_QUANT_F16: return launch_nw<DSK_QUANT_F16>(st, dev, h);
@@ -997,6 +998,7 @@ int gemv_launch(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& h) {
 
 // Decide lanes-per-row, rows-per-wave, grid and workgroup ranges.  `target_wgs` ~ a few per CU.
 int gemv_plan(GemvLaunch& h, int target_wgs) {
+  if (h.tiled) return gemv_plan_tile(h, target_wgs);
   const bool cg = h.comb_x != nullptr || h.comb_geometry != 0;  // fused-combine geometry
   if (h.n_tasks < 1 || h.n_tasks > GEMV_MAX_TASKS) DSK_FAIL(DSK_ERR_INVALID, "gemv: %d tasks", h.n_tasks);
   const bool kq = h.quant == DSK_QUANT_Q2_K || h.quant == DSK_QUANT_Q3_K;

@@ -486,6 +486,65 @@ int launch_repack_q2k(hipStream_t st, const uint8_t* aos, size_t n_blocks, uint8
   return DSK_OK;
 }
 
+// Q2_K into the TILED layout (tile_device.h): block gb0 + i of the reference's [matrix][row][block] order -> its place in the
+// tile records (16-row x 256-column tiles of 1344 bytes, strips of a matrix contiguous, rows padded to 16 per matrix)
+DEV size_t tile_block_base(size_t gb, int rows, int nb, size_t e_bytes, int* r16) {
+  const size_t per = (size_t)rows * nb;
+  const size_t mat = gb / per, rem = gb - mat * per;
+  const int r = (int)(rem / nb), b = (int)(rem - (size_t)r * nb);
+  *r16 = r & 15;
+  return mat * e_bytes + ((size_t)(r >> 4) * nb + b) * 1344;
+}
+__global__ void repack_q2k_tiles_kernel(const u32* __restrict__ aos, size_t gb0, size_t n_blocks, int rows, int nb, size_t e_bytes, uint8_t* tiles) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = gid / 21;
+  const int j = (int)(gid % 21);
+  if (i >= n_blocks) return;
+  const u32 w = aos[i * 21 + j];  // 84-byte blocks: scales[16] | qs[64] | d | dmin (src/quant.h:41-52)
+  int n;
+  uint8_t* T = tiles + tile_block_base(gb0 + i, rows, nb, e_bytes, &n);
+  if (j < 4) *reinterpret_cast<u32*>(T + 1024 + 4 * (n + 16 * j)) = w;                                 // scales[4j .. 4j + 3]
+  else if (j < 20) *reinterpret_cast<u32*>(T + 16 * (n + 16 * ((j - 4) >> 2)) + 4 * ((j - 4) & 3)) = w;  // qs bytes [4 (j - 4), + 4)
+  else *reinterpret_cast<u32*>(T + 1280 + 4 * n) = w;
+}
+int launch_repack_q2k_tiles(hipStream_t st, const uint8_t* aos, size_t gb0, size_t n_blocks, int rows, int nb, size_t e_bytes, uint8_t* tiles) {
+  const size_t total = n_blocks * 21;
+  hipLaunchKernelGGL(repack_q2k_tiles_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const u32*>(aos), gb0,
+                     n_blocks, rows, nb, e_bytes, tiles);
+  return DSK_OK;
+}
+// the same from the PLANE layout (a checkpoint repacked offline as planes-v1): qs[blk][64], sc[blk][16] in quarter order
+// sc'[4 (2h + lh) + s] = scales[8h + 2s + lh], dm[blk]
+__global__ void planes_to_tiles_q2k_kernel(const u32* __restrict__ qs, const uint8_t* __restrict__ sc, const u32* __restrict__ dm, size_t gb0,
+                                           size_t n_blocks, int rows, int nb, size_t e_bytes, uint8_t* tiles) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = gid / 21;
+  const int j = (int)(gid % 21);
+  if (i >= n_blocks) return;
+  int n;
+  uint8_t* T = tiles + tile_block_base(gb0 + i, rows, nb, e_bytes, &n);
+  if (j < 4) {
+    u32 w = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int jj = 4 * j + t, h = jj >> 3, s = (jj >> 1) & 3, lh = jj & 1;
+      w |= (u32)sc[i * 16 + (2 * h + lh) * 4 + s] << (8 * t);
+    }
+    *reinterpret_cast<u32*>(T + 1024 + 4 * (n + 16 * j)) = w;
+  } else if (j < 20) {
+    *reinterpret_cast<u32*>(T + 16 * (n + 16 * ((j - 4) >> 2)) + 4 * ((j - 4) & 3)) = qs[i * 16 + (j - 4)];
+  } else {
+    *reinterpret_cast<u32*>(T + 1280 + 4 * n) = dm[i];
+  }
+}
+int launch_planes_to_tiles_q2k(hipStream_t st, const uint8_t* qs, const uint8_t* sc, const uint8_t* dm, size_t gb0, size_t n_blocks, int rows, int nb,
+                               size_t e_bytes, uint8_t* tiles) {
+  const size_t total = n_blocks * 21;
+  hipLaunchKernelGGL(planes_to_tiles_q2k_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const u32*>(qs), sc,
+                     reinterpret_cast<const u32*>(dm), gb0, n_blocks, rows, nb, e_bytes, tiles);
+  return DSK_OK;
+}
+
 __global__ void repack_q3k_kernel(const unsigned short* __restrict__ aos, size_t n_blocks, unsigned short* qs,
                                   unsigned short* hm, unsigned short* sc, unsigned short* dm) {
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -533,6 +592,17 @@ __global__ void embed_kernel(DTensor t, const StepParams* __restrict__ sp, int t
       break;
     }
     case DSK_QUANT_Q2_K: {  // dequantize_row_q2_K, src/quant.cpp:217-247
+      if (t.tiled) {  // tile records (tile_device.h): 16-row x 256-column tiles of 1344 bytes
+        const uint8_t* T = t.qs + ((size_t)(token >> 4) * nb + (i >> 8)) * 1344;
+        const int n = token & 15, e = i & 255, h = e >> 7, s = (e >> 5) & 3, l = e & 31, jj = e >> 4;
+        const int byte = 32 * h + l;
+        const int q = (T[16 * (n + 16 * (byte >> 4)) + (byte & 15)] >> (2 * s)) & 3;
+        const int scb = T[1024 + 4 * (n + 16 * (jj >> 2)) + (jj & 3)];
+        const u32 dmw = *reinterpret_cast<const u32*>(T + 1280 + 4 * n);
+        const float dl = h2f(dmw & 0xffff) * (scb & 0xF), ml = h2f(dmw >> 16) * (scb >> 4);
+        y = dl * q - ml;
+        break;
+      }
       const size_t b = (size_t)token * nb + (i >> 8);
       const int e = i & 255, h = e >> 7, s = (e >> 5) & 3, l = e & 31, lh = l >> 4;
       const int q = (t.qs[b * 64 + 32 * h + l] >> (2 * s)) & 3;
@@ -1268,6 +1338,20 @@ __global__ void fill_dm_q2k_kernel(u32* dm, size_t n_blocks, uint64_t seed, floa
     dm[i] = (u32)f2h(d) | ((u32)f2h(1.5f * d) << 16);
   }
 }
+// tiled Q2_K (tile_device.h): the d | dmin words of every tile (16 words at byte 1280 of each 1344-byte record); rows past
+// `rows` of a matrix are padding: d = dmin = 0
+__global__ void fill_dm_tiles_kernel(uint8_t* tiles, size_t n_tiles, int rows, int nb, uint64_t seed, float wscale) {
+  const size_t strips_per_mat = (size_t)((rows + 15) >> 4);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_tiles * 16; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t tile = i >> 4;
+    const int n = (int)(i & 15);
+    const size_t strip = tile / nb;
+    const int row = (int)(strip % strips_per_mat) * 16 + n;
+    const uint64_t r = mix64(seed ^ (i * 0xA24BAED4963EE407ull));
+    const float d = (0.5f + u01(r)) * wscale / 13.9f;
+    *reinterpret_cast<u32*>(tiles + tile * 1344 + 1280 + 4 * n) = row < rows ? ((u32)f2h(d) | ((u32)f2h(1.5f * d) << 16)) : 0u;
+  }
+}
 // Q3_K: (sc-32)*q has std ~43 for uniform fields
 __global__ void fill_d_q3k_kernel(unsigned short* dm, size_t n_blocks, uint64_t seed, float wscale) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_blocks; i += (size_t)gridDim.x * blockDim.x) {
@@ -1320,6 +1404,12 @@ int launch_fill_tensor(hipStream_t st, const DTensor& t, uint64_t seed, float ws
       break;
     }
     case DSK_QUANT_Q2_K: {
+      if (t.tiled) {
+        const size_t n_tiles = mats * (size_t)((t.rows + 15) >> 4) * (t.n >> 8);
+        hipLaunchKernelGGL(fill_u32_kernel, dim3(fill_grid(n_tiles * 336)), dim3(256), 0, st, reinterpret_cast<u32*>(t.qs), n_tiles * 336, seed);
+        hipLaunchKernelGGL(fill_dm_tiles_kernel, dim3(fill_grid(n_tiles * 16)), dim3(256), 0, st, t.qs, n_tiles, t.rows, t.n >> 8, seed ^ 0xd3, wscale);
+        break;
+      }
       const size_t nblk = numel / 256;
       hipLaunchKernelGGL(fill_u32_kernel, dim3(fill_grid(nblk * 16)), dim3(256), 0, st, reinterpret_cast<u32*>(t.qs), nblk * 16, seed);
       hipLaunchKernelGGL(fill_u32_kernel, dim3(fill_grid(nblk * 4)), dim3(256), 0, st, reinterpret_cast<u32*>(t.sc), nblk * 4, seed ^ 0x51);

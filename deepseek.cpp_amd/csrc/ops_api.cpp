@@ -87,6 +87,7 @@ static int gemv_common(dsk_ctx* ctx, int quant, const void* w, size_t w_bytes, c
   TensorGuard tg;
   // upload only the selected expert's slice (the engine proper keeps whole stacks resident)
   DTensor& t = tg.t;
+  t.tiled = quant == DSK_QUANT_Q2_K;  // the layout the model's launches run (tile_device.h)
   DSK_TRY(alloc_tensor(b0, b1, t, quant, 0, d, n, 1, 0));
   const char* src = (const char*)w + (size_t)(n_experts > 0 ? expert : 0) * mat_bytes(quant, d, n);
   DSK_TRY(upload_tensor(ctx, t, src));
@@ -112,6 +113,7 @@ static int gemv_common(dsk_ctx* ctx, int quant, const void* w, size_t w_bytes, c
   GemvTask& T = h.t[0];
   T.qs = t.qs; T.sc = t.sc; T.hm = t.hm; T.dm = t.dm; T.scale = dsc;
   T.rows = d; T.n = n; T.local_experts = 1;
+  h.tiled = t.tiled;
   T.act_mode = ACT_F32; T.a_f32 = dx.as<float>();
   T.out = dout.as<float>(); T.epilogue = EPI_STORE;
   DSK_TRY(gemv_plan(h, 1024));
@@ -148,6 +150,7 @@ extern "C" int dsk_embed_row(dsk_ctx* ctx, int quant, const void* w, size_t w_by
   }
   hipStream_t st = ctx_stream(ctx);
   TensorGuard tg;
+  tg.t.tiled = quant == DSK_QUANT_Q2_K;
   DSK_TRY(alloc_tensor(b0, b1, tg.t, quant, 0, vocab, dim, 1, 0));
   DSK_TRY(upload_tensor(ctx, tg.t, w));
   if (quant == DSK_QUANT_F8E5M2)
@@ -367,6 +370,7 @@ extern "C" int dsk_bench_gemv(dsk_ctx* ctx, int quant, int rows, int n, int n_ta
   if (dsk_ab_env("DSK_BENCH_COPIES")) copies = std::max(1, atoi(dsk_ab_env("DSK_BENCH_COPIES")));  // 1: the Infinity Cache serves the weights
   std::vector<TensorGuard> W((size_t)copies * mats);
   for (size_t i = 0; i < W.size(); ++i) {
+    W[i].t.tiled = quant == DSK_QUANT_Q2_K && !dsk_ab_env("DSK_BENCH_PLANES");
     DSK_TRY(alloc_tensor(128, 128, W[i].t, quant, 0, rows, n, 1, 0));
     DSK_TRY(launch_fill_tensor(st, W[i].t, 1234 + i, 1.0f / sqrtf((float)n)));
   }
@@ -393,7 +397,9 @@ extern "C" int dsk_bench_gemv(dsk_ctx* ctx, int quant, int rows, int n, int n_ta
     GemvLaunch& h = H[c];
     memset(&h, 0, sizeof h);
     h.quant = quant; h.glu = kind == 1; h.act = DSK_ACT_SILU;
+    h.tiled = W[0].t.tiled;
     h.b0 = h.b1 = 128; h.force_lpr = force_lpr; h.force_R = force_R; h.force_U = force_U;
+    if (h.tiled) { h.force_NW = force_R; h.force_U = target_wgs > 8 ? target_wgs : 0; }  // tiled launches: R -> waves per workgroup, target_wgs -> workgroups
     if (dsk_ab_env("DSK_FORCE_NW")) h.force_NW = atoi(dsk_ab_env("DSK_FORCE_NW"));  // tuning knob of tools/kbench.py
     for (int i = 0; i < n_tasks; ++i) {
       GemvTask& T = h.t[h.n_tasks++];
@@ -455,6 +461,10 @@ extern "C" int dsk_bench_gemv(dsk_ctx* ctx, int quant, int rows, int n, int n_ta
     }
     fprintf(stderr, "timeline grid=%d (NW=%d R=%d U=%d lpr=%d) us since first entry [min avg max]: entry %.2f %.2f %.2f | staged %.2f %.2f %.2f | first group %.2f %.2f %.2f | exit %.2f %.2f %.2f\n",
             grid, H[0].NW, H[0].R, H[0].U, 1 << H[0].lpr_log2, mn[0], av[0] / cnt, mx[0], mn[1], av[1] / cnt, mx[1], mn[2], av[2] / cnt, mx[2], mn[3], av[3] / cnt, mx[3]);
+    if (H[0].tiled)
+      fprintf(stderr, "   tiled [min avg max]: descriptor %.2f %.2f %.2f | staged (wave 0) %.2f %.2f %.2f | round-1 items done (wave 0) %.2f %.2f %.2f | after its barrier %.2f %.2f %.2f | rows reduced %.2f %.2f %.2f\n",
+              mn[6], av[6] / cnt, mx[6], mn[7], av[7] / cnt, mx[7], mn[2], av[2] / cnt, mx[2], mn[4], av[4] / cnt, mx[4], mn[5], av[5] / cnt, mx[5]);
+    else
     fprintf(stderr, "   prologue avg: descriptor read %.2f | x loaded + sumsq %.2f | barrier + scale %.2f | quantised %.2f | all waves %.2f\n", av[6] / cnt, av[4] / cnt, av[5] / cnt, av[7] / cnt, av[1] / cnt);
   }
   return finish(ctx);
