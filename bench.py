@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (MLA path, kv_len sweep)")
     ap.add_argument("--dry-shard", default="", help="R/W: single-process dry run of expert shard R of W (no communicator)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="KEY=VALUE model option (include/dsk.h dsk_model_set_option), repeatable: A/B runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--profile-steps", type=int, default=4)
@@ -256,7 +257,8 @@ def main():
         c.first_k_dense_replace = min(c.first_k_dense_replace, a.layers)
     c.max_seq_len = max(a.ctx, a.steps + a.warmup + a.profile_steps + 2)
     t_build = time.time()
-    M = dsk.Model(ctx, c, None, synth_seed=0)
+    opts = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.opt}
+    M = dsk.Model(ctx, c, None, synth_seed=0, options=opts)
     t_build = time.time() - t_build
     if a.no_graph:
         M.set_graph(False)

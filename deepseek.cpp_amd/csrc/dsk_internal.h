@@ -229,6 +229,8 @@ struct MoeFfnArgs {
   int pf_n[6];
   int lprA_log2, lprB_log2;  // lanes per row of the two halves (= the two-launch plans': bit-identical results)
   int UA, rows_wg, lds_a, lds_b, lds_o, grid;  // filled by moe_ffn_plan
+  int tiled, lds_red;    // Q2_K weights in the tiled layout (kernels_moe_tile.hip: w*_qs = tile records, e13_qs / e2_qs = bytes of one
+                         // padded expert matrix); lds_red = bytes of the partials region
   int spin_limit;        // polls before the hand-off wait gives up (0: 2^20); < 0: fault injection (workgroup 0 reports a give-up)
   // float-weight models (F8E5M2 / F16 / F32; moe_ffn_f_kernel): block scales (F8 only, per-expert strides in floats), the
   // shared expert's w1 / w3 (computed in phase A too: these models have no rider in the router launch), the FFN norm (x is
@@ -248,6 +250,8 @@ struct MoeFfnArgs {
 };
 int moe_ffn_plan(MoeFfnArgs& a, int n_cus);
 int launch_moe_ffn(hipStream_t st, const MoeFfnArgs& a, hipEvent_t ev_start, hipEvent_t ev_stop);
+int moe_ffn_plan_tile(MoeFfnArgs& a, int n_cus);
+int launch_moe_ffn_tile(hipStream_t st, const MoeFfnArgs& a, hipEvent_t ev_start, hipEvent_t ev_stop);
 
 // per-token parameters living in device memory so that a captured graph can be replayed
 struct StepParams {

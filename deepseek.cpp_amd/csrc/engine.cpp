@@ -258,7 +258,8 @@ extern "C" int dsk_model_set_option(dsk_model* m, const char* key, int value) {
   else if (k == "graph_with_comm") m->graph_with_comm = value != 0;
   else if (k == "q2k_tiles") {
     if (m->any_bound) DSK_FAIL(DSK_ERR_STATE, "set_option: q2k_tiles must be set before the first tensor is bound");
-    m->q2k_tiles = value != 0;
+    if (value < 0 || value > 2) DSK_FAIL(DSK_ERR_INVALID, "set_option: q2k_tiles %d (0 none, 1 experts, 2 every converted role)", value);
+    m->q2k_tiles = value;
   }
   else DSK_FAIL(DSK_ERR_INVALID, "set_option: unknown option '%s'", key);
   return DSK_OK;
@@ -319,13 +320,24 @@ const int ALL_LAYER_ROLES[] = {DSK_ROLE_ATTN_NORM, DSK_ROLE_Q_A_NORM, DSK_ROLE_K
 
 static bool is_routed_role(int role) { return role == DSK_ROLE_W1 || role == DSK_ROLE_W2 || role == DSK_ROLE_W3; }
 
-// Which Q2_K tensors live in the tiled layout (tile_device.h): the roles whose every consumer runs the matrix-pipe row
-// products.  Option "q2k_tiles" (before the first bind) switches the layout off for A/B comparisons.
+// Which Q2_K tensors live in the tiled layout (tile_device.h), by option "q2k_tiles" (set before the first bind):
+//   0  none (the plane layout and the dot4 row products everywhere)
+//   1  (default) the routed experts' and the shared expert's matrices, when the fused expert launch can run them
+//      (kernels_moe_tile.hip: hidden vectors of <= 2048 values): same-box A/B on the full model, phase A of the fused launch
+//      16.6 -> 14.0 us, the launch 34.3 -> 34.1 us; the other converted roles are at parity or behind in the model (wo 10.9 -> 11.9 us:
+//      448 strips of 16 rows deal 2 : 1 over 256 CUs where 7168 rows deal evenly), so they stay on planes
+//   2  every converted role (experts, shared expert, dense FFN, first-stage projections, wo, embedding / classifier): tests, kbench
+static bool tile_experts_ok(const dsk_config& c) {
+  const int mi = c.moe_intermediate_size, sn = c.n_shared_experts * mi;
+  return c.n_routed_experts > 0 && c.dim % 256 == 0 && mi % 256 == 0 && mi / 256 <= 8 && sn % 256 == 0 && sn / 256 <= 8;
+}
 static bool role_tiled(const dsk_model* m, int role, int e, int quant) {
-  if (quant != DSK_QUANT_Q2_K || !m->q2k_tiles) return false;
+  if (quant != DSK_QUANT_Q2_K || m->q2k_tiles <= 0) return false;
+  const bool all = m->q2k_tiles >= 2;
   switch (role) {
-    case DSK_ROLE_EMBED: case DSK_ROLE_OUTPUT: case DSK_ROLE_WQ: case DSK_ROLE_WQ_A: case DSK_ROLE_WKV_A: case DSK_ROLE_WO: return true;
-    case DSK_ROLE_W1: case DSK_ROLE_W2: case DSK_ROLE_W3: return e == 0;  // dense blocks
+    case DSK_ROLE_EMBED: case DSK_ROLE_OUTPUT: case DSK_ROLE_WQ: case DSK_ROLE_WQ_A: case DSK_ROLE_WKV_A: case DSK_ROLE_WO: return all;
+    case DSK_ROLE_W1: case DSK_ROLE_W2: case DSK_ROLE_W3: return e == 0 ? all : (all || tile_experts_ok(m->c));
+    case DSK_ROLE_SHARED_W1: case DSK_ROLE_SHARED_W2: case DSK_ROLE_SHARED_W3: return all || tile_experts_ok(m->c);
     default: return false;
   }
 }

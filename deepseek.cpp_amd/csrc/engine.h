@@ -114,7 +114,7 @@ struct dsk_model {
   bool want_timeline = false;      // "timeline": in-kernel wall-clock stamps (dsk_model_get_timeline)
   int moe_spin_limit = 0;          // "moe_spin_limit": polls before the fused expert launch's hand-off gives up (0: default 2^20; < 0: fault injection - workgroup 0 reports a give-up)
   bool force_exchange = false;     // "force_exchange": run the expert-sharded code path (two-launch form, RCCL exchange, combine launch) at world == 1 too
-  bool q2k_tiles = true;           // "q2k_tiles": Q2_K tensors of the converted roles in the tiled layout (tile_device.h; engine.cpp role_tiled); set before the first bind
+  int q2k_tiles = 1;               // "q2k_tiles": which Q2_K tensors live in the tiled layout (tile_device.h): 0 none, 1 the experts, 2 every converted role (engine.cpp role_tiled); set before the first bind
   bool any_bound = false;
   bool graph_with_comm = false;    // "graph_with_comm": capture the sharded step into a hipGraph as well (default: eager)
   int exchange_calls = 0;          // RCCL collectives enqueued by this model (eager path) - diagnostics

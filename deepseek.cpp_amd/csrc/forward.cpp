@@ -327,6 +327,7 @@ int build_plans(dsk_model* m) {
         RouterArgs probe;
         memset(&probe, 0, sizeof probe);
         probe.ksplit = m->router_ksplit; probe.dim = c.dim; probe.norm_w = reinterpret_cast<const float*>(L.t[DSK_ROLE_FFN_NORM].qs);
+        hs.tiled = hs.t[0].wt_tiled;
         GemvLaunch trial = hs;
         trial.b0 = std::max(1, c.block_size[0]); trial.b1 = std::max(1, c.block_size[1]); trial.act = c.act;
         // (V2-Lite's 2048-wide rows plan U = 1 and stay out: with the rider forced in - 2 column steps - its router launch
@@ -412,6 +413,7 @@ int build_plans(dsk_model* m) {
         a.hq_qs = nullptr;
       }
       a.n_experts = c.n_routed_experts;
+      a.tiled = w1.tiled;
       a.err = m->err_host;
       a.spin_limit = m->moe_spin_limit;
       a.timeline = m->timeline_of(4);

@@ -25,6 +25,7 @@
 //   * all reductions are fixed-order shuffles: no atomics, bit-reproducible run to run.
 #include "dsk_internal.h"
 #include "gemv_device.h"
+#include "tile_gemv.h"
 
 #ifndef GEMV_EXACT
 #define GEMV_EXACT 2  // 0: only the generic chunk loop in gemv_body; 1: straight-line form for the 7168-wide GLU rows; 2: also for the
@@ -310,6 +311,26 @@ __global__ __launch_bounds__(1024) void router_shared_kernel(const RouterArgs a,
   __shared__ float nscratch[16];
   const float scale = rd::router_norm_scale(a, threadIdx.x, nscratch);
   gemv_body<QT, 1, U, true, 16>(Lp, a.x, a.norm_w, nullptr, a.dim, ACT_F32_NORM, a.eps, 0, 0, (int)blockIdx.x - n_router, scale);
+}
+
+// the same two launches for Q2_K weights in the tiled layout (tile_gemv.h)
+__global__ __launch_bounds__(1024) void gemv_kvwrite_tile_kernel(const GemvLaunch* __restrict__ Lp, const void* h_a0, const void* h_a1,
+                                                                const void* h_a2, int h_n, int h_mode, float h_eps, const MlaKvArgs kv,
+                                                                const StepParams* __restrict__ sp) {
+  if (blockIdx.x == gridDim.x - 1) {
+    rd::mla_kv_write_body(kv, sp, threadIdx.x, 1024);
+    return;
+  }
+  gemv_tile_body<false, 16>(Lp, h_a0, h_a1, h_a2, h_n, h_mode, h_eps, 0, 0, (int)blockIdx.x, 0.f);
+}
+__global__ __launch_bounds__(1024) void router_shared_tile_kernel(const RouterArgs a, int n_router, const GemvLaunch* __restrict__ Lp) {
+  if ((int)blockIdx.x < n_router) {
+    rd::router_body<2>(a, (int)blockIdx.x, n_router);
+    return;
+  }
+  __shared__ float nscratch[16];
+  const float scale = rd::router_norm_scale(a, threadIdx.x, nscratch);
+  gemv_tile_body<true, 16>(Lp, a.x, a.norm_w, nullptr, a.dim, ACT_F32_NORM, a.eps, 0, 0, (int)blockIdx.x - n_router, scale);
 }
 
 // ------------------------------------------------------------------------------------
@@ -930,6 +951,9 @@ static int launch_nw(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& h)
 
 // router + shared expert in one launch; h = the planned one-task GLU descriptor of the shared expert's w1/w3
 bool router_shared_supported(const RouterArgs& a, const GemvLaunch& h) {
+  if (h.tiled)
+    return a.ksplit >= 8 && a.norm_w && h.glu && h.n_tasks == 1 && h.n_groups == 1 && h.bd_heads == 0 && h.NW == 16 &&
+           h.t[0].act_mode == ACT_F32_NORM && h.t[0].n == a.dim && (a.dim >> 8) <= 32 && !h.comb_x;
   const bool q2 = h.quant == DSK_QUANT_Q2_K, q3 = h.quant == DSK_QUANT_Q3_K;
   return (q2 || q3) && a.ksplit >= 8 && a.norm_w && h.glu && h.n_tasks == 1 && h.n_groups == 1 && h.bd_heads == 0 && h.NW == 16 && h.R == 1 &&
          (h.U == 2 || (q2 && h.U == 4)) && h.t[0].act_mode == ACT_F32_NORM && h.t[0].n == a.dim && (a.dim >> 8) <= 32 && !h.comb_x;
@@ -939,6 +963,12 @@ int launch_router_shared(hipStream_t st, const RouterArgs& a, const GemvLaunch* 
   const int n_router = (a.n_routed + 1) / 2;
   dim3 grid(n_router + h.grid), block(1024);
   const size_t lds = h.lds_bytes;
+  if (h.tiled) {
+    auto k = router_shared_tile_kernel;
+    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, grid, block, lds, st, a, n_router, dev);
+    return DSK_OK;
+  }
 #define RS_LAUNCH(QT, U)                                                                                             \
   do {                                                                                                               \
     auto k = router_shared_kernel<QT, U>;                                                                            \
@@ -956,6 +986,7 @@ int launch_router_shared(hipStream_t st, const RouterArgs& a, const GemvLaunch* 
 }
 
 bool gemv_kvwrite_supported(const GemvLaunch& h) {
+  if (h.tiled) return !h.glu && h.n_groups == 1 && h.bd_heads == 0 && h.NW == 16 && !h.comb_x && !h.timeline;
   const bool kq = h.quant == DSK_QUANT_Q2_K || h.quant == DSK_QUANT_Q3_K;
   return kq && !h.glu && h.n_groups == 1 && h.bd_heads == 0 && h.NW == 16 && h.R == 1 && (h.U == 4 || h.U == 2) && !h.comb_x && !h.timeline;
 }
@@ -967,6 +998,12 @@ int launch_gemv_kvwrite(hipStream_t st, const GemvLaunch* dev, const GemvLaunch&
   if (T.act_mode == ACT_Q8) { a0 = T.a_qs; a1 = T.a_d; a2 = T.a_bsums; }
   dim3 grid(h.grid + 1), block(1024);
   const size_t lds = h.lds_bytes;
+  if (h.tiled) {
+    auto k = gemv_kvwrite_tile_kernel;
+    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, grid, block, lds, st, dev, a0, a1, a2, T.n, T.act_mode, T.eps, kv, sp);
+    return DSK_OK;
+  }
 #define KV_LAUNCH(QT, U)                                                                                             \
   do {                                                                                                               \
     auto k = gemv_kvwrite_kernel<QT, U>;                                                                             \

@@ -554,6 +554,7 @@ static int moe_ffn_plan_f(MoeFfnArgs& a, int n_cus) {
 }
 
 int moe_ffn_plan(MoeFfnArgs& a, int n_cus) {
+  if (a.tiled) return moe_ffn_plan_tile(a, n_cus);
   const bool q3 = a.quant == DSK_QUANT_Q3_K;
   if (a.quant == DSK_QUANT_F32 || a.quant == DSK_QUANT_F16 || a.quant == DSK_QUANT_F8E5M2) return moe_ffn_plan_f(a, n_cus);
   if (a.quant != DSK_QUANT_Q2_K && !q3) DSK_FAIL(DSK_ERR_UNSUPPORTED, "moe_ffn: bad quant %d", a.quant);
@@ -602,6 +603,7 @@ int moe_ffn_plan(MoeFfnArgs& a, int n_cus) {
 }
 
 int launch_moe_ffn(hipStream_t st, const MoeFfnArgs& a, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  if (a.tiled) return launch_moe_ffn_tile(st, a, ev_start, ev_stop);
   const size_t lds = (size_t)a.lds_a + (size_t)a.lds_b * (a.K + 1) + a.lds_o;
   auto go = [&](auto k) {
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

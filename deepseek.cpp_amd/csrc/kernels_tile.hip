@@ -4,11 +4,12 @@
 // planner and the launcher.  Same descriptor (GemvLaunch), activation groups, staging and epilogues as kernels_gemv.hip.
 #include "dsk_internal.h"
 #include "tile_gemv.h"
+#include <algorithm>
 
-template <bool GLU, int NW, int SEG>
+template <bool GLU, int NW>
 __global__ __launch_bounds__(NW * 64) void gemv_tile_kernel(const GemvLaunch* __restrict__ Lp, const void* h_a0, const void* h_a1,
                                                               const void* h_a2, int h_n, int h_mode, float h_eps, int h_gwgs, int h_gstride) {
-  gemv_tile_body<GLU, NW, SEG>(Lp, h_a0, h_a1, h_a2, h_n, h_mode, h_eps, h_gwgs, h_gstride, (int)blockIdx.x, 0.f);
+  gemv_tile_body<GLU, NW>(Lp, h_a0, h_a1, h_a2, h_n, h_mode, h_eps, h_gwgs, h_gstride, (int)blockIdx.x, 0.f);
 }
 
 size_t tile_mat_bytes(size_t rows, size_t n) { return ((rows + 15) / 16) * (n / 256) * TILE_B; }
@@ -27,8 +28,6 @@ int gemv_plan_tile(GemvLaunch& h, int target_wgs) {
     GemvTask& T = h.t[i];
     if (T.rows <= 0 || T.n <= 0) DSK_FAIL(DSK_ERR_INVALID, "gemv: empty shape %d x %d", T.rows, T.n);
     if (T.n % QK_K) DSK_FAIL(DSK_ERR_INVALID, "k-quant gemv: n=%d is not a multiple of 256 (quantizer.cpp:8)", T.n);
-    if (h.glu && tile_seg(T.n >> 8) != tile_seg(h.t[0].n >> 8)) DSK_FAIL(DSK_ERR_INVALID, "gemv: tasks of one launch must share the item size");
-    if (tile_seg(T.n >> 8) != tile_seg(h.t[0].n >> 8)) DSK_FAIL(DSK_ERR_UNSUPPORTED, "tiled gemv: rows of %d and %d blocks in one launch", T.n >> 8, h.t[0].n >> 8);
     if (cg && T.rows != h.t[0].rows) DSK_FAIL(DSK_ERR_INVALID, "gemv combine: tasks must share the row count");
     const int nb = T.n >> 8, strips = (T.rows + 15) >> 4;
     nb_max = nb > nb_max ? nb : nb_max;
@@ -56,7 +55,8 @@ int gemv_plan_tile(GemvLaunch& h, int target_wgs) {
   // partials of a round: big rounds balance the waves (items are dealt as contiguous ranges) and cost one barrier pair each
   h.t_rcap = h.NW == 16 ? 256 : (h.NW == 8 ? 128 : 48);
   {
-    const int ips = tile_ips(nb_max) * (h.glu ? 2 : 1);
+    int ips = 0;  // a round holds at least one strip (pair) of any task
+    for (int i = 0; i < h.n_tasks; ++i) ips = std::max(ips, tile_ips(h.t[i].n >> 8) * (h.glu ? 2 : 1));
     if (h.t_rcap < ips) h.t_rcap = ips;
   }
   h.lds_bytes = (size_t)h.t_act + (size_t)h.t_rcap * 256;
@@ -117,7 +117,7 @@ int gemv_plan_tile(GemvLaunch& h, int target_wgs) {
 // ------------------------------------------------------------------------------------
 // launcher
 // ------------------------------------------------------------------------------------
-template <bool GLU, int NW, int SEG>
+template <bool GLU, int NW>
 static void launch_tile_one(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& h) {
   dim3 grid(h.grid), block(NW * 64);
   // activation hint (gemv_device.h ActSrc): only when every workgroup stages the same vector, or equally spaced ones
@@ -140,28 +140,21 @@ static void launch_tile_one(hipStream_t st, const GemvLaunch* dev, const GemvLau
     }
     if (ok) { a0 = T0.a_f32; hn = T0.n; hm = ACT_F32; gw = w0; gs = (int)sd; }
   }
-  auto k = gemv_tile_kernel<GLU, NW, SEG>;
+  auto k = gemv_tile_kernel<GLU, NW>;
   if (h.lds_bytes > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds_bytes);
   if (g_prof_start && g_prof_stop) hipExtLaunchKernelGGL(k, grid, block, (uint32_t)h.lds_bytes, st, g_prof_start, g_prof_stop, 0u, dev, a0, a1, a2, hn, hm, he, gw, gs);
   else hipLaunchKernelGGL(k, grid, block, h.lds_bytes, st, dev, a0, a1, a2, hn, hm, he, gw, gs);
 }
 
 int gemv_launch_tile(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& h) {
-  const int seg = tile_seg(h.t[0].n >> 8);
-#define TL_GO(GLU, NW)                                                   \
-  do {                                                                   \
-    if (seg == 1) launch_tile_one<GLU, NW, 1>(st, dev, h);               \
-    else launch_tile_one<GLU, NW, 4>(st, dev, h);                        \
-  } while (0)
   if (h.glu) {
-    if (h.NW == 16) TL_GO(true, 16);
-    else if (h.NW == 8) TL_GO(true, 8);
-    else TL_GO(true, 4);
+    if (h.NW == 16) launch_tile_one<true, 16>(st, dev, h);
+    else if (h.NW == 8) launch_tile_one<true, 8>(st, dev, h);
+    else launch_tile_one<true, 4>(st, dev, h);
   } else {
-    if (h.NW == 16) TL_GO(false, 16);
-    else if (h.NW == 8) TL_GO(false, 8);
-    else TL_GO(false, 4);
+    if (h.NW == 16) launch_tile_one<false, 16>(st, dev, h);
+    else if (h.NW == 8) launch_tile_one<false, 8>(st, dev, h);
+    else launch_tile_one<false, 4>(st, dev, h);
   }
-#undef TL_GO
   return DSK_OK;
 }

@@ -104,67 +104,6 @@ DEV void tstep_mac(const TStep& S, const uint8_t* rec, const TLane& L, float& ac
 }
 DEV float titem_value(float accd, float accm, const TLane& L) { return fmaf(accd, L.lanefac, -accm); }
 
-#ifndef TILE_PIPELINE
-#define TILE_PIPELINE 0
-#endif
-// One HALF of a work unit: up to 4 consecutive blocks of one strip (for rows of more than 8 blocks: exactly one item).
-struct THalf {
-  rsrc_t W;            // the strip's matrix
-  int soff;            // byte offset of the half's first tile
-  const uint8_t* rec;  // LDS record of its first block
-  float* red;          // where its first partial goes ([item][64] floats)
-  int cnt;             // blocks (0: empty half)
-  int sp;              // strip (pair) index for the arrival counters
-};
-
-// half hh of a round: strip hh / hps, blocks [4 kk, 4 kk + 4) of it (hps = halves per strip, rcp = ceil(2^32 / hps))
-template <int SEG, typename F>
-DEV THalf thalf_make(int hh, int H, int hps, unsigned rcp, int ips, int nb, int n_pairs, float* red, F&& strip_of) {
-  THalf D;
-  D.cnt = 0; D.sp = 0; D.soff = 0; D.rec = nullptr; D.red = red;
-  if (hh < H) {
-    const int s = (int)__umulhi((unsigned)hh, rcp), kk = hh - s * hps, b0 = 4 * kk;
-    int soff0;
-    const uint8_t *act, *wp;
-    strip_of(s, wp, soff0, act);
-    D.W = make_rsrc(wp);
-    D.soff = soff0 + b0 * TILE_B;
-    D.rec = act + (size_t)b0 * TREC;
-    D.red = red + ((size_t)s * ips + (SEG == 1 ? b0 : kk)) * 64;
-    D.cnt = nb - b0 < 4 ? nb - b0 : 4;
-    D.sp = s < n_pairs ? s : s - n_pairs;
-  } else {
-    int soff0;
-    const uint8_t *act, *wp;
-    strip_of(0, wp, soff0, act);  // a valid descriptor for the (skipped) loads' operand
-    D.W = make_rsrc(wp);
-  }
-  return D;
-}
-// FULL: the half has its four blocks (known to the caller: straight-line code, which is what lets hipcc interleave the LDS
-// reads, matrix instructions and scale arithmetic of neighbouring steps; with a branch per step every step pays its LDS
-// and matrix-pipe latencies alone)
-template <int SEG, bool FULL>
-DEV void thalf_load(TStep (&S)[4], const THalf& D, const TLane& L) {
-#pragma unroll
-  for (int u = 0; u < 4; ++u)
-    if (FULL || u < D.cnt) tstep_load(S[u], D.W, L, D.soff + u * TILE_B);
-}
-// multiplies the half and leaves its partial(s) in LDS: one per block for rows of <= 8 blocks, one per half otherwise
-template <int SEG, bool FULL>
-DEV void thalf_mac(const TStep (&S)[4], const THalf& D, const TLane& L, int lane) {
-  float accd = 0.f, accm = 0.f;
-#pragma unroll
-  for (int u = 0; u < 4; ++u)
-    if (FULL || u < D.cnt) {
-      tstep_mac(S[u], D.rec + u * TREC, L, accd, accm);
-      if (SEG == 1 || (FULL ? u == 3 : u == D.cnt - 1)) {
-        D.red[(SEG == 1 ? u * 64 : 0) + lane] = titem_value(accd, accm, L);
-        accd = accm = 0.f;
-      }
-    }
-}
-
 #ifndef TILE_G
 #define TILE_G 8  // column steps requested together
 #endif
@@ -250,108 +189,3 @@ DEV float tile_strip_value(const float* red_strip, int ips, int lane) {
   return a + __shfl_xor(a, 32);
 }
 
-// One ROUND of a workgroup: NS strips x hps halves.  The waves pull units of two consecutive halves (8 column steps) from an
-// LDS counter until the round is gone - the waves of a CU run at very different speeds, a static deal leaves the fast ones
-// idle -; the next unit is fetched and its loads are ISSUED before the arrival bookkeeping of the unit just multiplied, so
-// dequeue, arrival and the finisher's reduction run under memory latency.  cnt[] (zeroed; one word per strip, or per w1 / w3
-// pair of strips: pair index = s % n_pairs) counts delivered items; the wave that delivers the LAST item of a strip (pair)
-// runs finish(sp): every partial of it is visible in LDS.  No workgroup barrier.
-template <int SEG, typename F, typename H>
-DEV void tile_round(int NS, int ips, int nb, int n_pairs, int target, unsigned* next, unsigned* cnt, float* red, const TLane& L, int lane,
-                    F&& strip_of, H&& finish) {
-  const int hps = SEG == 1 ? (nb + 3) >> 2 : ips;
-  const int Hn = NS * hps, n_units = (Hn + 1) >> 1;
-  const unsigned rcp = (unsigned)(0xFFFFFFFFull / (unsigned)hps) + 1u;  // ceil(2^32 / hps) for hps >= 2; hps == 1: see below
-  auto fetch = [&]() {
-    unsigned u = 0;
-    if (lane == 0) u = __hip_atomic_fetch_add(next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    return (int)__builtin_amdgcn_readfirstlane(u);
-  };
-  auto make = [&](int hh) {
-    if (hps == 1) {  // (2^32 does not fit the multiplier: strip = half)
-      THalf D = thalf_make<SEG>(0, 0, 1, 0u, ips, nb, n_pairs, red, strip_of);
-      if (hh < Hn) {
-        int soff0;
-        const uint8_t *act, *wp;
-        strip_of(hh, wp, soff0, act);
-        D.W = make_rsrc(wp);
-        D.soff = soff0; D.rec = act; D.red = red + (size_t)hh * ips * 64; D.cnt = nb < 4 ? nb : 4; D.sp = hh < n_pairs ? hh : hh - n_pairs;
-      }
-      return D;
-    }
-    return thalf_make<SEG>(hh, Hn, hps, rcp, ips, nb, n_pairs, red, strip_of);
-  };
-  auto arrive = [&](int sp, int n) {  // -> sp if this wave delivered the strip's last item, else -1
-    unsigned old = 0;
-    // LDS only: this wave's partials are in LDS before the count (the LDS serves a wave's operations in order; the wait
-    // makes that explicit), and the completing wave reads everybody's after its own count returned.  NOT a release /
-    // acquire pair of the memory model: that would wait for vmcnt(0) - the next unit's loads, just issued.
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (lane == 0) old = __hip_atomic_fetch_add(cnt + sp, (unsigned)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    old = __builtin_amdgcn_readfirstlane(old);
-    asm volatile("" ::: "memory");
-    return (int)old + n == target ? sp : -1;
-  };
-#if TILE_PIPELINE
-  int u = fetch();
-  if (u >= n_units) return;
-  THalf D0 = make(2 * u), D1 = make(2 * u + 1);
-  TStep S0[4], S1[4];
-  auto load2 = [&]() {
-    if (D0.cnt == 4 && D1.cnt == 4) { thalf_load<SEG, true>(S0, D0, L); thalf_load<SEG, true>(S1, D1, L); }
-    else { thalf_load<SEG, false>(S0, D0, L); thalf_load<SEG, false>(S1, D1, L); }
-  };
-  load2();
-  for (;;) {
-    if (D0.cnt == 4 && D1.cnt == 4) { thalf_mac<SEG, true>(S0, D0, L, lane); thalf_mac<SEG, true>(S1, D1, L, lane); }
-    else { thalf_mac<SEG, false>(S0, D0, L, lane); thalf_mac<SEG, false>(S1, D1, L, lane); }
-    const int n0 = SEG == 1 ? D0.cnt : 1, n1 = D1.cnt == 0 ? 0 : (SEG == 1 ? D1.cnt : 1);
-    const int sp0 = D0.sp, sp1 = D1.sp;
-    const int u2 = fetch();
-    const bool more = u2 < n_units;
-    if (more) {
-      D0 = make(2 * u2);
-      D1 = make(2 * u2 + 1);
-      load2();
-    }
-    int f0, f1 = -1;
-    if (n1 > 0 && sp1 == sp0) f0 = arrive(sp0, n0 + n1);
-    else {
-      f0 = arrive(sp0, n0);
-      if (n1 > 0) f1 = arrive(sp1, n1);
-    }
-#pragma unroll 1
-    for (int q = 0; q < 2; ++q) {  // (one copy of the finisher's code)
-      const int f = q ? f1 : f0;
-      if (f >= 0) finish(f);
-    }
-    if (!more) break;
-  }
-#else
-  for (;;) {
-    const int u = fetch();
-    if (u >= n_units) break;
-    const THalf D0 = make(2 * u), D1 = make(2 * u + 1);
-    TStep S0[4], S1[4];
-    if (D0.cnt == 4 && D1.cnt == 4) {  // straight-line: requests, then the multiplies as the data arrives
-      thalf_load<SEG, true>(S0, D0, L); thalf_load<SEG, true>(S1, D1, L);
-      thalf_mac<SEG, true>(S0, D0, L, lane); thalf_mac<SEG, true>(S1, D1, L, lane);
-    } else {
-      thalf_load<SEG, false>(S0, D0, L); thalf_load<SEG, false>(S1, D1, L);
-      thalf_mac<SEG, false>(S0, D0, L, lane); thalf_mac<SEG, false>(S1, D1, L, lane);
-    }
-    const int n0 = SEG == 1 ? D0.cnt : 1, n1 = D1.cnt == 0 ? 0 : (SEG == 1 ? D1.cnt : 1);
-    int f0, f1 = -1;
-    if (n1 > 0 && D1.sp == D0.sp) f0 = arrive(D0.sp, n0 + n1);
-    else {
-      f0 = arrive(D0.sp, n0);
-      if (n1 > 0) f1 = arrive(D1.sp, n1);
-    }
-#pragma unroll 1
-    for (int q = 0; q < 2; ++q) {  // (one copy of the finisher's code)
-      const int f = q ? f1 : f0;
-      if (f >= 0) finish(f);
-    }
-  }
-#endif
-}

@@ -4,26 +4,19 @@
 //
 // A workgroup owns whole 16-row strips of its activation group's (padded) row space.  It works in ROUNDS of as many strips as
 // the partials' LDS region holds (one round for every DeepSeek shape): the round's items (strip x 4-block item, or strip x
-// block for rows of <= 8 blocks) are pulled by the waves from an LDS counter, 8 column steps at a time - the waves of a CU run
-// at very different speeds (in-kernel stamps: a static deal left the fastest wave of a workgroup idle for a third of the
-// launch) -, every item leaves its partial in LDS, and the wave that delivers the LAST item of a strip adds the strip's partials
-// in the fixed order of tile_device.h and runs the epilogue for its 16 rows: no workgroup barrier after the staging prologue.
-// GLU launches treat w1 and w3 as two strips of the same rows, completed together.
+// block for rows of <= 8 blocks) are dealt to the waves as contiguous ranges - a wave streams one contiguous byte range of
+// tiles -, every item leaves its partial in LDS, and after a barrier one WAVE per strip adds the strip's partials in the fixed
+// order of tile_device.h and runs the epilogue for its 16 rows.  GLU launches treat w1 and w3 as two strips of the same rows.
 #pragma once
 #include "tile_device.h"
 #define TILE_MAX_ROUND_STRIPS 256
-#ifndef TILE_DYNAMIC
-#define TILE_DYNAMIC 0
-#endif
 
-template <bool GLU, int NW, int SEG>
+template <bool GLU, int NW>
 DEV void gemv_tile_body(const GemvLaunch* __restrict__ Lp, const void* h_a0, const void* h_a1, const void* h_a2, int h_n, int h_mode,
                         float h_eps, int h_gwgs, int h_gstride, const int bid, const float h_pre_scale) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ float scratch[16];
   __shared__ bool comb_last;
-  __shared__ unsigned t_next;
-  __shared__ unsigned t_cnt[TILE_MAX_ROUND_STRIPS];
   const GemvLaunch& L = *Lp;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const unsigned long long t_entry = wall_clock64();
@@ -115,7 +108,7 @@ DEV void gemv_tile_body(const GemvLaunch* __restrict__ Lp, const void* h_a0, con
   const bool comb = !GLU && L.comb_x != nullptr;
   float* red = reinterpret_cast<float*>(smem + t_act);
   const TLane TL = tlane_init(lane);
-  bool first = true, first_round = true;
+  bool first = true;
   int comb_rows = 0;       // combine: this workgroup's rows [r_lo, r_lo + comb_rows) of its ONE task
   float* comb_out = nullptr;
 
@@ -146,54 +139,27 @@ DEV void gemv_tile_body(const GemvLaunch* __restrict__ Lp, const void* h_a0, con
     }
     const uint8_t* const W1 = T.qs + (size_t)le * T.e_qs;
     const uint8_t* const W3 = GLU ? T.qs2 + (size_t)le * T.e_qs : T.qs;
-    const int nb = T.n >> 8, ips = SEG == 1 ? nb : (nb + 3) >> 2;
+    const int nb = T.n >> 8, ips = tile_ips(nb);
     int cap = L.t_rcap / (ips * (GLU ? 2 : 1));  // strips (of each matrix) per round
     if (cap < 1) cap = 1;
     if (cap > TILE_MAX_ROUND_STRIPS) cap = TILE_MAX_ROUND_STRIPS;
     for (int tb = lo >> 4; tb < (hi >> 4); tb += cap) {
       const int nt = (hi >> 4) - tb < cap ? (hi >> 4) - tb : cap;
-#if TILE_DYNAMIC
-      if (!first_round) __syncthreads();  // the previous round's waves are done with the counters and the partials
-      if (tid < nt) t_cnt[tid] = 0u;
-      if (tid == 0) t_next = 0u;
-      __syncthreads();
-      first_round = false;
-      tile_round<SEG>(nt * (GLU ? 2 : 1), ips, nb, nt, ips * (GLU ? 2 : 1), &t_next, t_cnt, red, TL, lane,
-          [&](int s, const uint8_t*& W, int& soff0, const uint8_t*& act) {
-            const bool m3 = GLU && s >= nt;
-            W = m3 ? W3 : W1;
-            soff0 = (tb + (m3 ? s - nt : s)) * nb * TILE_B;
-            act = smem;
-          },
-          [&](int sp) {  // this wave delivered the last item of strip (pair) sp: its rows' values and the epilogue
-            const float v = tile_strip_value(red + (size_t)sp * ips * 64, ips, lane);
-            const float v3 = GLU ? tile_strip_value(red + (size_t)(nt + sp) * ips * 64, ips, lane) : 0.f;
-            const int row = (tb + sp) * 16 + lane;
-            if (lane < 16 && row < T.rows) {
-              float* o = T.out + row;
-              if (GLU) *o = act_fn(v, L.act) * v3;                                                  // src/infer.cpp:859-872
-              else if (comb) __hip_atomic_store(o, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through: the finisher sits on another CU
-              else if (T.epilogue == EPI_ADD) *o += v;                                              // residual add, src/infer.cpp:832-834, 928-930
-              else *o = v;
-            }
-          });
-#else
       // static deal: the round's items as contiguous ranges (a wave streams one contiguous byte range of tiles), a barrier,
       // then one wave per strip adds its partials (the association of tile_device.h) and runs the epilogue.
-      // (Measured and rejected, TILE_DYNAMIC: the waves pulling 8-step units from an LDS counter, the wave that delivers a
+      // (Measured and rejected: the waves pulling 8-step units from an LDS counter, the wave that delivers a
       // strip's last item reducing it, no barrier - with and without the next unit's loads issued ahead of the bookkeeping:
       // classifier 53.7 -> 65 us, experts' w1/w3 21.9 -> 23.5, first-stage projections 5.4 -> 7.5.)
-      (void)first_round; (void)t_next; (void)t_cnt;
       const int NS = nt * (GLU ? 2 : 1), I = NS * ips;
       const int i0 = (int)((long long)I * wave / NW), i1 = (int)((long long)I * (wave + 1) / NW);
-      tile_items<SEG>(i0, i1, ips, nb, red, TL, lane,
-          [&](int s, rsrc_t& W, int& soff0, const uint8_t*& act) {
-            const bool m3 = GLU && s >= nt;
-            W = make_rsrc(m3 ? W3 : W1);
-            soff0 = (tb + (m3 ? s - nt : s)) * nb * TILE_B;
-            act = smem;
-          },
-          [](int, int) {});
+      auto strip_of = [&](int s, rsrc_t& W, int& soff0, const uint8_t*& act) {
+        const bool m3 = GLU && s >= nt;
+        W = make_rsrc(m3 ? W3 : W1);
+        soff0 = (tb + (m3 ? s - nt : s)) * nb * TILE_B;
+        act = smem;
+      };
+      if (nb > 8) tile_items<4>(i0, i1, ips, nb, red, TL, lane, strip_of, [](int, int) {});  // (item size: tile_device.h)
+      else tile_items<1>(i0, i1, ips, nb, red, TL, lane, strip_of, [](int, int) {});
       __syncthreads();
       for (int sp = wave; sp < nt; sp += NW) {
         const float v = tile_strip_value(red + (size_t)sp * ips * 64, ips, lane);
@@ -208,7 +174,6 @@ DEV void gemv_tile_body(const GemvLaunch* __restrict__ Lp, const void* h_a0, con
         }
       }
       if (tb + cap < (hi >> 4)) __syncthreads();  // another round follows: its partials reuse the region
-#endif
       if (tl && tid == 0 && first) { tl[2] = wall_clock64(); first = false; }
     }
   }

@@ -7,9 +7,13 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "deepseek.cpp_am
 import dsk
 from tools import synth
 
-ap = argparse.ArgumentParser(); ap.add_argument("--layers", type=int, default=8); a = ap.parse_args()
+ap = argparse.ArgumentParser(); ap.add_argument("--layers", type=int, default=8)
+ap.add_argument("--opt", action="append", default=[], help="KEY=VALUE model option, repeatable (e.g. q2k_tiles=0)")
+a = ap.parse_args()
 c = synth.preset("v3", "q2_k", False, n_layers=a.layers, max_seq_len=64)
-ctx = dsk.Ctx(0); M = dsk.Model(ctx, c, None, synth_seed=0, options={"timeline": 1})
+ctx = dsk.Ctx(0); opts = {"timeline": 1}
+opts.update({kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.opt})
+M = dsk.Model(ctx, c, None, synth_seed=0, options=opts)
 for pos in range(6):
     M.forward(17 + pos, pos)
 n = 256
