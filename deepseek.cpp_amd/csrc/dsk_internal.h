@@ -20,6 +20,7 @@ static inline const char* dsk_ab_env(const char*) { return nullptr; }
 
 // ---- error plumbing (never abort across the boundary; include/dsk.h conventions) ----
 void dsk_set_error(int code, const char* fmt, ...);
+void dsk_clear_error();  // a recoverable planning failure (a fused form that does not apply) must not leave its message behind
 #define DSK_FAIL(code, ...)            \
   do {                                 \
     dsk_set_error((code), __VA_ARGS__); \
@@ -352,6 +353,8 @@ struct HeadAttnArgs {
   int quant, b0, b1;
   int lq_log2, lkv_log2; // lanes per row of the two projections
   int lds_q, lds_kv;     // bytes of the two staged activation vectors
+  int tiled;             // Q2_K projections stored as tile records (tile_device.h): the head's strips on the matrix pipe
+  int red_off, red_bytes; // tiled: the partials [step][64] live behind the scores (red_off floats behind lds_q + lds_kv)
   AttnMhaArgs a;
   // long contexts: n_split workgroups per head, each over a contiguous share of the cached positions (both
   // redo the head's projections: the other CUs would idle anyway); partial (O, m, l) per (head, split) go to

@@ -33,6 +33,7 @@ void dsk_set_error(int code, const char* fmt, ...) {
   vsnprintf(g_err + n, sizeof g_err - n, fmt, ap);
   va_end(ap);
 }
+void dsk_clear_error() { g_err[0] = 0; }
 extern "C" const char* dsk_last_error(void) { return g_err; }
 extern "C" int dsk_abi_version(void) { return DSK_ABI_VERSION; }
 
@@ -165,6 +166,10 @@ extern "C" int dsk_comm_init(dsk_ctx* c, const void* uid128, int rank, int world
   // (world == 1 WITH a uid: a one-rank communicator - the exchange of a model created with the option
   //  "force_exchange" then really calls RCCL on the engine stream: tests/test_comm_gpu.py)
   HIP_TRY(hipSetDevice(c->device));
+  if (c->comm) {  // a second call replaces the communicator
+    ncclCommDestroy(c->comm);
+    c->comm = nullptr;
+  }
   ncclUniqueId id;
   memcpy(&id, uid128, 128);
   ncclResult_t r = ncclCommInitRank(&c->comm, world, id, rank);
@@ -272,6 +277,12 @@ extern "C" int dsk_model_get_info(dsk_model* m, const char* key, int* value) {
   else if (k == "fused_moe_layers") { int n = 0; for (auto& a : m->moe_ffn) n += a.grid > 0; *value = n; }
   else if (k == "graph_captured") { int n = 0; for (auto g : m->graph) n += g != nullptr; *value = n; }
   else if (k == "exchange_calls") *value = m->exchange_calls;
+  else if (k == "tiled_tensors") {  // weight tensors stored as tile records (option "q2k_tiles")
+    int n = 0;
+    for (auto& t : m->g) n += t.tiled;
+    for (auto& L : m->L) for (auto& t : L.t) n += t.tiled;
+    *value = n;
+  }
   else DSK_FAIL(DSK_ERR_INVALID, "get_info: unknown key '%s'", key);
   return DSK_OK;
 }
@@ -327,6 +338,9 @@ static bool is_routed_role(int role) { return role == DSK_ROLE_W1 || role == DSK
 //      16.6 -> 14.0 us, the launch 34.3 -> 34.1 us; the other converted roles are at parity or behind in the model (wo 10.9 -> 11.9 us:
 //      448 strips of 16 rows deal 2 : 1 over 256 CUs where 7168 rows deal evenly), so they stay on planes
 //   2  every converted role (experts, shared expert, dense FFN, first-stage projections, wo, embedding / classifier): tests, kbench
+#ifndef TILE_LEVEL_HEAD
+#define TILE_LEVEL_HEAD 2  // the q2k_tiles level from which wq_b / wkv_b are tiled
+#endif
 static bool tile_experts_ok(const dsk_config& c) {
   const int mi = c.moe_intermediate_size, sn = c.n_shared_experts * mi;
   return c.n_routed_experts > 0 && c.dim % 256 == 0 && mi % 256 == 0 && mi / 256 <= 8 && sn % 256 == 0 && sn / 256 <= 8;
@@ -338,6 +352,13 @@ static bool role_tiled(const dsk_model* m, int role, int e, int quant) {
     case DSK_ROLE_EMBED: case DSK_ROLE_OUTPUT: case DSK_ROLE_WQ: case DSK_ROLE_WQ_A: case DSK_ROLE_WKV_A: case DSK_ROLE_WO: return all;
     case DSK_ROLE_W1: case DSK_ROLE_W2: case DSK_ROLE_W3: return e == 0 ? all : (all || tile_experts_ok(m->c));
     case DSK_ROLE_SHARED_W1: case DSK_ROLE_SHARED_W2: case DSK_ROLE_SHARED_W3: return all || tile_experts_ok(m->c);
+    case DSK_ROLE_WQ_B: case DSK_ROLE_WKV_B: {  // the per-head attention launch's projections (kernels_gemv.hip head_attn_kernel)
+      const dsk_config& c = m->c;
+      const int hd = c.qk_nope_head_dim + c.qk_rope_head_dim, nv = c.qk_nope_head_dim + c.v_head_dim;
+      const bool ok = !c.use_mla && c.q_lora_rank > 0 && c.q_lora_rank % 256 == 0 && c.kv_lora_rank % 256 == 0 && c.q_lora_rank / 256 <= 8 &&
+                      c.kv_lora_rank / 256 <= 8 && hd % 16 == 0 && nv % 16 == 0;
+      return ok && m->q2k_tiles >= TILE_LEVEL_HEAD;
+    }
     default: return false;
   }
 }

@@ -201,6 +201,7 @@ int build_plans(dsk_model* m) {
         const GemvLaunch& P = m->plans[m->lp_qkv_b[l]];
         if (A.has_q) { A.tq = P.t[0]; A.tkv = P.t[1]; }
         else A.tkv = P.t[0];
+        A.tiled = P.tiled;
         AttnMhaArgs& a = A.a;
         a.q = m->q; a.kv_b = m->kv_b; a.kv_a = m->kv_a; a.key_cache = L.key_cache; a.value_cache = L.value_cache; a.out = m->att_out;
         a.n_heads = H; a.head_dim = m->head_dim; a.nope = c.qk_nope_head_dim; a.rope = c.qk_rope_head_dim; a.v_dim = c.v_head_dim;
@@ -420,7 +421,8 @@ int build_plans(dsk_model* m) {
       a.lprA_log2 = m->plans[m->lp_w13[l]].lpr_log2;
       a.lprB_log2 = m->plans[m->lp_w2[l]].lpr_log2;
       a.algo_bytes = m->plans[m->lp_w13[l]].algo_bytes + m->plans[m->lp_w2[l]].algo_bytes;
-      if (moe_ffn_plan(a, m->ctx->n_cus) == DSK_OK) m->moe_ffn[l] = a;  // otherwise: the two-launch form
+      if (moe_ffn_plan(a, m->ctx->n_cus) == DSK_OK) m->moe_ffn[l] = a;
+      else dsk_clear_error();  // "not fusable" is not an error: the two-launch form runs (dsk_model_get_info "fused_moe_layers" tells)
     }
   }
   {  // classifier on rmsnorm(x, final_norm) (src/infer.cpp:1292-1316)
@@ -723,12 +725,20 @@ static int run_token(dsk_model* m, int token, int pos, int mode, bool retried = 
   HIP_TRY(hipSetDevice(m->ctx->device));
   hipStream_t st = m->ctx->stream;
   DSK_TRY(fill_step_params(m, token, pos));
+  // The re-run of a token after a hand-off give-up (below) must be idempotent.  Everything a token writes is a pure function of
+  // (token, pos, earlier cache rows) and is rewritten with the same values - except the attention-sink rotation: from pos >= W on
+  // every layer's cache-write kernel rotates the two sink keys IN PLACE by one position (src/infer.cpp:1011-1024, 1103-1110),
+  // and the first pass has already done that in every layer (the give-up does not stop the stream).  The sink loops take their
+  // bound from StepParams::kv_sink and nothing else on the device reads it (kv_pos / kv_len are computed here), so the re-run
+  // passes 0: the sink keys are rotated exactly once per token.
+  if (retried) m->sp_host->kv_sink = 0;
   // LDS for attention scores is sized once (graph-replay safe): kv_len never exceeds the ring W nor the allocation
   const int max_kv = std::min(m->c.max_seq_len, std::max(1, m->c.rs_original_max_position_embeddings));
   // A sharded model (real communicator) is enqueued eagerly: measured on MI355X an eager stream of these
   // launches is as fast as the graph replay (the host stays ~10 launches ahead), and it keeps RCCL's
   // lazily initialised collectives out of stream capture.
-  const bool graphable = m->use_graph && !m->trace && !m->profiling && (!m->ctx->comm || m->graph_with_comm);
+  // (a communicator that no collective of this model uses - a generic launcher passing a uid at world 1 - costs nothing)
+  const bool graphable = m->use_graph && !m->trace && !m->profiling && (!m->ctx->comm || !m->sharded() || m->graph_with_comm);
   // the long-context MLA regime enqueues one more launch per block: its own captured graph
   const bool long_mla = m->fl_part_o && m->sp_host->kv_len >= m->mla_flash_min_kv;
   // ... and so does the long-context MHA regime (split contexts: a different grid)
@@ -760,7 +770,8 @@ static int run_token(dsk_model* m, int token, int pos, int mode, bool retried = 
   if (handoff_gave_up(m)) {
     // The fused expert launch needs every workgroup resident at once; on a CU-masked or shared GPU its bounded spin gives
     // up.  The model then switches to the two-launch form (no in-launch waiting) for the rest of its life and THIS token is
-    // run again: its side effects so far (the KV row of `pos`, the activations) are rewritten with the same values.
+    // run again: its side effects so far (the KV row of `pos`, the activations) are rewritten with the same values; the sink
+    // rotation, the one in-place update of a token, is skipped in the re-run (above).
     if (retried) DSK_FAIL(DSK_ERR_HIP, "forward: an in-kernel hand-off timed out");
     return run_token(m, token, pos, mode, true);
   }
@@ -1009,7 +1020,13 @@ extern "C" int dsk_model_run_block(dsk_model* m, int layer, const float* x_in, i
   if (e != hipSuccess) DSK_FAIL(DSK_ERR_HIP, "run_block: %s", hipGetErrorString(e));
   DSK_TRY(r2);
   HIP_TRY(hipGetLastError());
-  if (handoff_gave_up(m)) DSK_FAIL(DSK_ERR_HIP, "run_block: an in-kernel hand-off timed out (the model now uses the two-launch form: call again)");
+  if (handoff_gave_up(m)) {
+    // (from pos >= W on the block has rotated its two cached sink keys in place: calling again would rotate them twice)
+    if (m->sp_host->kv_sink > 0)
+      DSK_FAIL(DSK_ERR_HIP, "run_block: an in-kernel hand-off timed out at pos >= %d: the block's sink keys were rotated; restore its cache rows "
+                            "(dsk_model_set_cache_rows) before calling again (the model now uses the two-launch form)", m->c.rs_original_max_position_embeddings);
+    DSK_FAIL(DSK_ERR_HIP, "run_block: an in-kernel hand-off timed out (the model now uses the two-launch form: call again)");
+  }
   HIP_TRY(hipMemcpy(x_out, m->x, (size_t)c.dim * 4, hipMemcpyDeviceToHost));
   m->stage_kv_len = m->sp_host->kv_len;
   m->stage_last_layer = layer;

@@ -372,8 +372,13 @@ __global__ __launch_bounds__(1024) void head_attn_kernel(const HeadAttnArgs A, c
 #ifndef DSK_NO_TAPS
     if constexpr (KQ) {
       if (A.tap_qs && blockIdx.x == 0) {  // parity tap
-        if (A.has_q) dump_staged_q8<QT == DSK_QUANT_Q2_K>(act_q, A.tq.n, A.tap_qs, A.tap_d, tid, 1024);
-        dump_staged_q8<QT == DSK_QUANT_Q2_K>(act_kv, A.tkv.n, A.tap_qs + A.tap_stride, A.tap_d + (A.tap_stride >> 8), tid, 1024);
+        if (QT == DSK_QUANT_Q2_K && A.tiled) {
+          if (A.has_q) dump_staged_q8<LAY_TILE>(act_q, A.tq.n, A.tap_qs, A.tap_d, tid, 1024);
+          dump_staged_q8<LAY_TILE>(act_kv, A.tkv.n, A.tap_qs + A.tap_stride, A.tap_d + (A.tap_stride >> 8), tid, 1024);
+        } else {
+          if (A.has_q) dump_staged_q8<QT == DSK_QUANT_Q2_K>(act_q, A.tq.n, A.tap_qs, A.tap_d, tid, 1024);
+          dump_staged_q8<QT == DSK_QUANT_Q2_K>(act_kv, A.tkv.n, A.tap_qs + A.tap_stride, A.tap_d + (A.tap_stride >> 8), tid, 1024);
+        }
       }
     }
 #endif
@@ -404,7 +409,9 @@ __global__ __launch_bounds__(1024) void head_attn_kernel(const HeadAttnArgs A, c
     if (Z.mine) {
       const float scale = 1.0f / sqrtf(total / (float)T.n + T.eps);
       float v[4] = {t.x * scale * wv.x, t.y * scale * wv.y, t.z * scale * wv.z, t.w * scale * wv.w};
-      q8k_block_lds<QT == DSK_QUANT_Q2_K>(v, lane, (Z.is_q ? act_q : act_kv) + (size_t)Z.b * 4 * ITEM_LDS);
+      uint8_t* dst = (Z.is_q ? act_q : act_kv) + (size_t)Z.b * 4 * ITEM_LDS;  // (a block is 320 bytes in every staging layout)
+      if (QT == DSK_QUANT_Q2_K && A.tiled) q8k_block_lds<LAY_TILE>(v, lane, dst);
+      else q8k_block_lds<QT == DSK_QUANT_Q2_K>(v, lane, dst);
     }
     lds_barrier();
   };
@@ -431,8 +438,74 @@ __global__ __launch_bounds__(1024) void head_attn_kernel(const HeadAttnArgs A, c
     }
   };
   bool exact = false;
-#if HEAD_EXACT
   if constexpr (QT == DSK_QUANT_Q2_K) {
+    // Tiled weights (tile_device.h): head h's strips of both projections - head_dim / 16 of wq_b, (nope + v) / 16 of wkv_b, rows of
+    // <= 8 blocks: one item per block - as ONE list of steps (strip, block), dealt to the 16 waves as contiguous ranges; a wave
+    // requests ALL its steps at once (<= 8), multiplies them as they arrive (matrix pipe: ~42 VALU per step where the dot4 form
+    // spent 4.3 us of arithmetic per head on 4 SIMDs), a barrier, then one wave per strip adds the partials (the association
+    // of tile_device.h) into q_s / kvb_s.
+    if (A.tiled) {
+      exact = true;
+      latent_finish(latent_request());
+      tap_staged();
+      if (tl && tid == 0) tl[1] = wall_clock64();
+      const TLane TL = tlane_init(lane);
+      float* red = reinterpret_cast<float*>(smem + A.lds_q + A.lds_kv) + A.red_off;
+      const int nbq_ = A.tq.n >> 8, nbk_ = A.tkv.n >> 8;
+      const int sq = a.head_dim >> 4, sk = (a.nope + a.v_dim) >> 4;  // strips per head
+      const int JQ = sq * nbq_, J = JQ + sk * nbk_;
+      const int j0 = (int)((long long)J * wave / NW), j1 = (int)((long long)J * (wave + 1) / NW);
+      const rsrc_t Wq = make_rsrc(A.tq.qs), Wk = make_rsrc(A.tkv.qs);
+      constexpr int HS = 7;  // steps a wave holds at once (DeepSeek-V3: 104 steps per head, 6 or 7 per wave)
+      TStep S[HS];
+      const uint8_t* recv[HS];
+      auto locate = [&](int j, bool& isq, int& soff, const uint8_t*& rec) {
+        isq = j < JQ;
+        if (isq) {
+          const int st = j / nbq_, b = j - st * nbq_;
+          soff = ((h * sq + st) * nbq_ + b) * TILE_B;
+          rec = act_q + (size_t)b * TREC;
+        } else {
+          const int jj = j - JQ, st = jj / nbk_, b = jj - st * nbk_;
+          soff = ((h * sk + st) * nbk_ + b) * TILE_B;
+          rec = act_kv + (size_t)b * TREC;
+        }
+      };
+      for (int jb = j0; jb < j1; jb += HS) {
+        const int cnt = j1 - jb < HS ? j1 - jb : HS;
+        if (cnt == 7) {
+#pragma unroll
+          for (int u = 0; u < 7; ++u) { bool isq; int soff; locate(jb + u, isq, soff, recv[u]); tstep_load(S[u], isq ? Wq : Wk, TL, soff); }
+#pragma unroll
+          for (int u = 0; u < 7; ++u) { float ad_ = 0.f, am_ = 0.f; tstep_mac(S[u], recv[u], TL, ad_, am_); red[(size_t)(jb + u) * 64 + lane] = titem_value(ad_, am_, TL); }
+        } else if (cnt == 6) {
+#pragma unroll
+          for (int u = 0; u < 6; ++u) { bool isq; int soff; locate(jb + u, isq, soff, recv[u]); tstep_load(S[u], isq ? Wq : Wk, TL, soff); }
+#pragma unroll
+          for (int u = 0; u < 6; ++u) { float ad_ = 0.f, am_ = 0.f; tstep_mac(S[u], recv[u], TL, ad_, am_); red[(size_t)(jb + u) * 64 + lane] = titem_value(ad_, am_, TL); }
+        } else {
+#pragma unroll
+          for (int u = 0; u < HS; ++u)
+            if (u < cnt) { bool isq; int soff; locate(jb + u, isq, soff, recv[u]); tstep_load(S[u], isq ? Wq : Wk, TL, soff); }
+#pragma unroll
+          for (int u = 0; u < HS; ++u)
+            if (u < cnt) { float ad_ = 0.f, am_ = 0.f; tstep_mac(S[u], recv[u], TL, ad_, am_); red[(size_t)(jb + u) * 64 + lane] = titem_value(ad_, am_, TL); }
+        }
+      }
+      __syncthreads();
+      for (int st = wave; st < sq + sk; st += NW) {
+        const bool isq = st < sq;
+        const float v = isq ? tile_strip_value(red + (size_t)st * nbq_ * 64, nbq_, lane)
+                            : tile_strip_value(red + (size_t)(JQ + (st - sq) * nbk_) * 64, nbk_, lane);
+        if (lane < 16) {
+          if (isq) q_s[st * 16 + lane] = v;
+          else kvb_s[(st - sq) * 16 + lane] = v;
+        }
+      }
+    }
+  }
+#if HEAD_EXACT
+  if constexpr (QT == DSK_QUANT_Q2_K) if (!exact) {
     // DeepSeek-V3 shapes (192 q rows of 1536, 256 kv rows of 512, 8 lanes per row: 3 and 1 column steps, all known at
     // compile time): every wave requests ALL its rows of both projections at once - q rows w*8.., kv rows w*8.. and
     // 128 + w*8.., and for waves 0-7 q rows 128 + w*8.. - and multiplies them as they arrive, instead of four dependent
@@ -574,6 +647,13 @@ int head_attn_plan(HeadAttnArgs& A) {
   auto lds = [&](int n) { return (int)(((kq ? (size_t)(n / 64) * ITEM_LDS : (size_t)n * 4) + 15) & ~(size_t)15); };
   A.lds_q = A.has_q ? lds(A.tq.n) : 0;
   A.lds_kv = lds(A.tkv.n);
+  if (A.tiled) {
+    const int nbq = A.tq.n >> 8, nbk = A.tkv.n >> 8;
+    if (A.quant != DSK_QUANT_Q2_K || !A.has_q || nbq > 8 || nbk > 8 || nbq + nbk > 16 || A.a.head_dim % 16 || (A.a.nope + A.a.v_dim) % 16 ||
+        A.tq.act_mode != ACT_F32_NORM || A.tkv.act_mode != ACT_F32_NORM)
+      DSK_FAIL(DSK_ERR_UNSUPPORTED, "head_attn: tiled projections need Q2_K, a q latent, rows of <= 8 blocks and heads of whole 16-row strips");
+    A.red_bytes = ((A.a.head_dim >> 4) * nbq + ((A.a.nope + A.a.v_dim) >> 4) * nbk) * 256;
+  }
   if (A.b0 < 1) A.b0 = 1;
   if (A.b1 < 1) A.b1 = 1;
   return DSK_OK;
@@ -588,7 +668,11 @@ static int launch_head_attn_q(hipStream_t st, const HeadAttnArgs& A, const StepP
 int launch_head_attn(hipStream_t st, const HeadAttnArgs& A0, const StepParams* sp, int max_kv, int n_split) {
   HeadAttnArgs A = A0;
   A.n_split = (n_split > 1 && A0.split_part && A0.split_counter) ? (n_split > MHA_SPLIT_MAX ? MHA_SPLIT_MAX : n_split) : 1;
-  const size_t lds = (size_t)A.lds_q + A.lds_kv + (size_t)max_kv * 4;
+  size_t lds = (size_t)A.lds_q + A.lds_kv + (size_t)max_kv * 4;
+  if (A.tiled) {
+    A.red_off = (max_kv + 15) & ~15;
+    lds = (size_t)A.lds_q + A.lds_kv + (size_t)A.red_off * 4 + A.red_bytes;
+  }
   if (lds > 120 * 1024) DSK_FAIL(DSK_ERR_UNSUPPORTED, "attn: kv_len %d does not fit LDS", max_kv);
   switch (A.quant) {
     case DSK_QUANT_F32: return launch_head_attn_q<DSK_QUANT_F32>(st, A, sp, lds);

@@ -191,6 +191,8 @@ __global__ __launch_bounds__(1024) void moe_ffn_kernel(const MoeFfnArgs a) {
     auto wait_slots = [&]() {
       if (wave == 0) {
         unsigned spins = 0;
+        // (an earlier launch of this token already gave up: the host will re-run the token - do not spin the limit out again in every layer)
+        if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) spins = (unsigned)a.spin_limit > 64u ? (unsigned)a.spin_limit - 64u : 0u;
         for (;;) {
           const bool ok = lane >= K || __hip_atomic_load(a.slot_ctr + lane * MOE_CTR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= slot_target;
           if (__all(ok)) break;
@@ -467,6 +469,8 @@ __global__ __launch_bounds__(1024) void moe_ffn_f_kernel(const MoeFfnArgs a) {
     // hand-off: lane k of wave 0 watches slot k's counter (the shared expert's is slot K); bounded like the K-quant kernel's
     if (wave == 0) {
       unsigned spins = 0;
+      // (an earlier launch of this token already gave up: the host will re-run the token - do not spin the limit out again in every layer)
+      if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) spins = (unsigned)a.spin_limit > 64u ? (unsigned)a.spin_limit - 64u : 0u;
       for (;;) {
         const unsigned want = lane < K ? (unsigned)a.mi : (unsigned)a.shared_n;
         const bool ok = lane >= slots || __hip_atomic_load(a.slot_ctr + lane * MOE_CTR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
@@ -566,6 +570,8 @@ int moe_ffn_plan(MoeFfnArgs& a, int n_cus) {
   const int RGA = 16 * (64 / lprA), RGB = 16 * (64 / lprB) * 2;
   (void)RGB;
   a.UA = (a.mi + RGA - 1) / RGA;
+  // the Q8_K hand-over counts the units of a 256-block: a unit must divide the block, and the block counters must exist
+  if (a.hq_qs && (RGA > 256 || 256 % RGA != 0 || (long)a.K * (a.mi / 256) > MOE_BLK_CTRS)) a.hq_qs = nullptr;
   // one descriptor spans the W2 stack: a lane's byte offset (expert, row, block) must fit its 32-bit offset field
   if ((double)a.n_experts * a.dim * (a.mi / 256) * 64.0 >= 2147483648.0) DSK_FAIL(DSK_ERR_UNSUPPORTED, "moe_ffn: the W2 stack exceeds the 31-bit offset of a buffer load");
   // every workgroup must be resident at once (phase B spins on the slot counters): one 16-wave workgroup per CU

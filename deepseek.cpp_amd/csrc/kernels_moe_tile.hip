@@ -197,6 +197,8 @@ __global__ __launch_bounds__(1024) void moe_ffn_tile_kernel(const MoeFfnArgs a) 
     const unsigned slot_target = a.hq_qs ? (unsigned)(a.mi >> 8) : (unsigned)a.UA;
     if (wave == 0) {
       unsigned spins = 0;
+      // (an earlier launch of this token already gave up: the host will re-run the token - do not spin the limit out again in every layer)
+      if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) spins = (unsigned)a.spin_limit > 64u ? (unsigned)a.spin_limit - 64u : 0u;
       for (;;) {
         const bool ok = lane >= K || __hip_atomic_load(a.slot_ctr + lane * MOE_CTR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= slot_target;
         if (__all(ok)) break;

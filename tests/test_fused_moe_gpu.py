@@ -187,6 +187,43 @@ def test_handoff_give_up_falls_back_to_the_two_launch_form(ctx):
     B.close()
 
 
+@pytest.mark.parametrize("mla", [False, True], ids=["mha", "mla"])
+def test_handoff_give_up_past_the_ring_rotates_the_sink_keys_once(ctx, mla):
+    """from pos >= W (rs_original_max_position_embeddings) every layer's cache-write kernel rotates the two
+    attention-sink keys IN PLACE by one position (src/infer.cpp:1011-1024, 1103-1110).  The token that is re-run after a
+    hand-off give-up must not rotate them a second time: a give-up injected at a position past the ring must leave this token's
+    logits AND every later token's bit-identical to a model that never fused."""
+    import dsk
+    W = 8
+    c = synth.preset("tiny_v3", "q2_k", mla, n_shared_experts=0, rs_original_max_position_embeddings=W, max_seq_len=32)
+    T = synth.synth_model(c, seed=19)
+    B = dsk.Model(ctx, c, T, options={"fuse_moe": 0})
+    G = dsk.Model(ctx, c, T, options={"moe_spin_limit": -1})  # gives up at its FIRST token, which sits past the ring
+    assert G.info("fused_moe_layers") > 0
+    rng = np.random.default_rng(11)
+    H, hd = c.n_heads, c.qk_nope_head_dim + c.qk_rope_head_dim
+
+    def f16(a):
+        return np.asarray(a, np.float32).astype(np.float16).view(np.uint16)
+
+    for l in range(c.n_layers):  # the same random ring (sink rows included) in both models
+        if mla:
+            rows = {"nope_cache": f16(rng.standard_normal((W, c.kv_lora_rank))), "rope_cache": f16(rng.standard_normal((W, c.qk_rope_head_dim)))}
+        else:
+            rows = {"k_cache": f16(0.5 * rng.standard_normal((W, H * hd))), "v_cache": f16(0.5 * rng.standard_normal((W, H * c.v_head_dim)))}
+        for name, r in rows.items():
+            B.set_cache_rows(l, name, 0, r)
+            G.set_cache_rows(l, name, 0, r)
+    tok = 7
+    for pos in range(W + 1, W + 6):
+        lb, lg = B.forward(tok, pos), G.forward(tok, pos)
+        assert np.array_equal(lg, lb), pos
+        assert G.info("handoff_fallbacks") == 1 and G.info("fused_moe_layers") == 0
+        tok = int(np.argmax(lb))
+    B.close()
+    G.close()
+
+
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("mla", [False, True], ids=["mha", "mla"])
 def test_cold_line_prefetch_changes_no_bits(ctx, mla):

@@ -79,13 +79,18 @@ def _v3_full_width(mla, seed, quant="q2_k"):
 
 
 @pytest.mark.timeout(1500)
-@pytest.mark.parametrize("mla,quant", [(False, "q2_k"), (True, "q2_k"), (False, "q3_k")], ids=["mha", "mla", "mha-q3_k"])
-def test_v3_full_width_256_experts_teacher_forced(ctx, oracle, mla, quant):
+@pytest.mark.parametrize("mla,quant,tiles", [(False, "q2_k", None), (True, "q2_k", None), (False, "q3_k", None), (False, "q2_k", 2), (False, "q2_k", 0)],
+                         ids=["mha", "mla", "mha-q3_k", "mha-all-tiles", "mha-no-tiles"])
+def test_v3_full_width_256_experts_teacher_forced(ctx, oracle, mla, quant, tiles):
     """BASELINE.json configs[3] at full width: 256 routed experts, 8 groups / 4 kept, top-8; 1 dense + 1 MoE block.  Q3_K at
-    the same width runs the other instantiation of every K-quant kernel (moe_ffn_kernel<Q3_K, 2, 2>, the generic row loops)."""
+    the same width runs the other instantiation of every K-quant kernel (moe_ffn_kernel<Q3_K, 2, 2>, the generic row loops).
+    `tiles`: option q2k_tiles - default (the experts' matrices as tile records, matrix-pipe row products), 2 (every converted role:
+    first-stage projections, the per-head attention launch's projections, wo, dense FFN, classifier), 0 (planes + dot4 everywhere)."""
     import dsk
     c, T = _v3_full_width(mla, seed=31, quant=quant)
-    M, O = dsk.Model(ctx, c, T), oracle.model(c, T)
+    M, O = dsk.Model(ctx, c, T, options=None if tiles is None else {"q2k_tiles": tiles}), oracle.model(c, T)
+    if quant == "q2_k":
+        assert (M.info("tiled_tensors") > 0) == (tiles != 0)
     aud = teacher.BlockAuditor(oracle, c, T)
     emb = T["model.embed.weight"]
     flips, worst, free, routes = 0, 0.0, [], []
