@@ -35,7 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "deepseek.cpp_amd"))
 
-PMC_FILE = "r03_pmc.json"
+PMC_FILE = "r04_pmc.json"
 
 
 def csrc_sha() -> str:
@@ -226,6 +226,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, the way the driver does (one process per
+        # GPU, RCCL over xGMI), and pass their exit code on - never print a 1-GPU line for N > 1
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     import torch  # plumbing only: rendezvous, barrier, max-reduce; loaded first so one HIP runtime is shared
     import torch.distributed as dist
     import dsk
@@ -233,16 +244,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    launched = "WORLD_SIZE" in os.environ  # under torch.distributed.run (also with one rank): the rank plumbing runs
+    if launched:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     def barrier():
-        if world > 1:
+        if launched:
             dist.barrier()
 
     ctx = dsk.Ctx(local_rank)
-    if world > 1:
+    if launched:
         uid = [ctx.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(uid[0], rank, world)
@@ -277,12 +291,24 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if launched:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / a.steps * 1e3
     tok_s = a.steps / dt
+    # SURVEY 8d defines the rate over >= 128 decode steps: whatever --steps was, the line also carries that figure (positions
+    # continue behind the timed region; the MHA cache grows 5 MB per position, so it sits ~2 % under a 20-step figure)
+    tok_s_128 = None
+    if world == 1 and not a.no_extras and not a.dry_shard:
+        p128 = pos
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(128):
+            M.forward_nocopy(int(tokens[p128 % len(tokens)]), p128)
+            p128 += 1
+        torch.cuda.synchronize()
+        tok_s_128 = dict(tok_s=round(128 / (time.perf_counter() - t1), 3), steps=128, positions=[pos, p128 - 1])
     mid_pos = a.warmup + a.steps // 2
     algo_bytes = M.active_bytes(mid_pos)
     M_device_gb = M.device_bytes() / 1e9
@@ -358,6 +384,11 @@ def main():
         except Exception as e:
             extras["kv_sweep"] = {"error": repr(e)[:160]}
     measured_bw = None
+    M_info = [None, None, None, None]
+    try:
+        M_info = [M.info("fused_moe_layers"), M.info("handoff_fallbacks"), M.info("tiled_tensors"), M.info("exchange_calls")]
+    except Exception:  # noqa: BLE001
+        pass
     if rank == 0:
         try:
             M.close()
@@ -433,12 +464,16 @@ def main():
             "frac_of_measured": ({"kernel": round(roof["achieved"] / measured_bw, 4), "token": round(roof["token_gbps"] / measured_bw, 4)}
                                  if roof and measured_bw else None),
             "cpu_baseline": cpu,
+            "tok_s_128": tok_s_128,
+            # which code ran: fused expert launches in the model, times a hand-off give-up retired them (0 on an unshared GPU),
+            # weight tensors stored as matrix-pipe tiles (option q2k_tiles)
+            "engine": {"fused_moe_layers": M_info[0], "handoff_fallbacks": M_info[1], "tiled_tensors": M_info[2], "exchange_calls": M_info[3]},
             "csrc_sha": csrc_sha(),
         }
         out.update(extras)
         print(json.dumps(out), flush=True)
     barrier()
-    if world > 1:
+    if launched:
         dist.destroy_process_group()
 
 

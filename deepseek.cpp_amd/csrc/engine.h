@@ -116,7 +116,7 @@ struct dsk_model {
   bool force_exchange = false;     // "force_exchange": run the expert-sharded code path (two-launch form, RCCL exchange, combine launch) at world == 1 too
   int q2k_tiles = 1;               // "q2k_tiles": which Q2_K tensors live in the tiled layout (tile_device.h): 0 none, 1 the experts, 2 every converted role (engine.cpp role_tiled); set before the first bind
   bool any_bound = false;
-  bool graph_with_comm = false;    // "graph_with_comm": capture the sharded step into a hipGraph as well (default: eager)
+  bool graph_with_comm = true;     // "graph_with_comm": the sharded step (RCCL exchange included) is captured into a hipGraph too, after the first eager token of a mode (0: enqueued eagerly)
   int exchange_calls = 0;          // RCCL collectives enqueued by this model (eager path) - diagnostics
   int handoff_fallbacks = 0;       // times a hand-off give-up switched this model to the two-launch form (dsk_model_get_info)
   bool sharded() const { return ctx->world > 1 || force_exchange; }

@@ -439,7 +439,7 @@ int build_plans(dsk_model* m) {
   }
   (void)H;
   HIP_TRY(hipMalloc((void**)&m->plans_dev, m->plans.size() * sizeof(GemvLaunch)));
-  if (m->tail_prefetch > 0 && !m->sharded()) {
+  if (m->tail_prefetch > 0) {  // (expert-sharded ranks too: the attention launches are replicated; the fused expert launch is not planned there)
     // Cold lines: every launch opens with lines nobody has touched since the previous token - its descriptor, its norm
     // weights - and waits ~1-2 us for them from HBM.  Workgroups that cost nothing read them into every XCD's L2 ahead of
     // time (one per XCD: workgroup b runs on XCD b % 8): behind the heads of the per-head attention launch, on the 128 CUs it
@@ -734,9 +734,9 @@ static int run_token(dsk_model* m, int token, int pos, int mode, bool retried = 
   if (retried) m->sp_host->kv_sink = 0;
   // LDS for attention scores is sized once (graph-replay safe): kv_len never exceeds the ring W nor the allocation
   const int max_kv = std::min(m->c.max_seq_len, std::max(1, m->c.rs_original_max_position_embeddings));
-  // A sharded model (real communicator) is enqueued eagerly: measured on MI355X an eager stream of these
-  // launches is as fast as the graph replay (the host stays ~10 launches ahead), and it keeps RCCL's
-  // lazily initialised collectives out of stream capture.
+  // A sharded model (real communicator) is captured like the one-GPU step (option "graph_with_comm", default on): the first
+  // token of a mode runs eagerly - RCCL initialises its collectives lazily, outside any capture - and the second is captured
+  // with the exchange inside (validated on a 1-rank communicator: tests/test_comm_gpu.py; never run on more than one GPU).
   // (a communicator that no collective of this model uses - a generic launcher passing a uid at world 1 - costs nothing)
   const bool graphable = m->use_graph && !m->trace && !m->profiling && (!m->ctx->comm || !m->sharded() || m->graph_with_comm);
   // the long-context MLA regime enqueues one more launch per block: its own captured graph

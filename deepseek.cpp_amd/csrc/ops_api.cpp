@@ -300,8 +300,8 @@ extern "C" int dsk_attn_mla(dsk_ctx* ctx, const float* q_c, const float* q_rope,
 
 extern "C" int dsk_measure_read_bw(dsk_ctx* ctx, size_t bytes, int iters, double* gbps_out) {
   DSK_TRY(begin(ctx));
-  if (!gbps_out || bytes < (1u << 20) || iters <= 0) DSK_FAIL(DSK_ERR_INVALID, "measure_read_bw: bad argument");
-  bytes = bytes / 4096 * 4096;
+  if (!gbps_out || bytes < (1u << 25) || iters <= 0) DSK_FAIL(DSK_ERR_INVALID, "measure_read_bw: bad argument (at least 32 MiB)");
+  bytes = bytes / (4096u * 8192u) * (4096u * 8192u);  // 4096 waves x whole 8 KiB steps: every byte counted is read
   hipStream_t st = ctx_stream(ctx);
   DevBuf buf, sink;
   DSK_TRY(buf.alloc(bytes));

@@ -198,7 +198,8 @@ int dsk_model_destroy(dsk_model* m);
  *                        injection (a give-up is reported although the hand-off succeeded: exercises the fallback)
  *   "force_exchange"  0  run the expert-sharded code path (two-launch experts, RCCL all-reduce when the context has a
  *                        communicator, separate combine launch) at world == 1 too
- *   "graph_with_comm" 0  capture the sharded step into a hipGraph as well (default: enqueued eagerly) */
+ *   "graph_with_comm" 1  the sharded step - RCCL exchange included - is captured into a hipGraph after the first (eager) token of a
+ *                        mode, like the one-GPU step (0: enqueued eagerly; capture validated on a 1-rank communicator only) */
 int dsk_model_set_option(dsk_model* m, const char* key, int value);
 /* Read-only counters: "handoff_fallbacks" (times a hand-off give-up moved the model to the two-launch form; the token
  * that hit it was re-run transparently), "fused_moe_layers", "graph_captured", "exchange_calls" (RCCL collectives this

@@ -34,7 +34,7 @@ def test_forced_exchange_runs_rccl_on_the_engine_stream_and_keeps_the_bits(ctx, 
     n_moe = c.n_layers - c.first_k_dense_replace
     A = dsk.Model(ctx, c, T, synth_seed=seed)
     cc = _comm_ctx()
-    B = dsk.Model(cc, c, T, synth_seed=seed, options={"force_exchange": 1})
+    B = dsk.Model(cc, c, T, synth_seed=seed, options={"force_exchange": 1, "graph_with_comm": 0})
     assert B.info("fused_moe_layers") == 0
     toks = [5, 9, 700, 3, 44]
     for pos, t in enumerate(toks):
@@ -45,7 +45,7 @@ def test_forced_exchange_runs_rccl_on_the_engine_stream_and_keeps_the_bits(ctx, 
     assert B.info("graph_captured") == 0
     B.close()
     # the same step captured into a hipGraph (RCCL is initialised by the first, eager, token)
-    G = dsk.Model(cc, c, T, synth_seed=seed, options={"force_exchange": 1, "graph_with_comm": 1})
+    G = dsk.Model(cc, c, T, synth_seed=seed, options={"force_exchange": 1})  # graph_with_comm is the default
     try:
         for pos, t in enumerate(toks):
             lg = G.forward(t % c.vocab_size, pos)
@@ -61,3 +61,28 @@ def test_forced_exchange_runs_rccl_on_the_engine_stream_and_keeps_the_bits(ctx, 
     G.close()
     A.close()
     cc.close()
+
+
+def test_bench_under_torchrun_runs_the_rank_plumbing(tmp_path):
+    """the path a driver would launch - `python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` -
+    reads RANK / LOCAL_RANK / WORLD_SIZE, initialises torch.distributed over RCCL, broadcasts the ncclUniqueId, builds the engine's
+    communicator and (option force_exchange) runs the expert-sharded step with its RCCL exchange on a 4-block model; and
+    `bench.py --gpus 2` WITHOUT a launcher must start its ranks itself or fail - never print a 1-GPU line."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", "29731",
+           os.path.join(root, "bench.py"), "--gpus", "1", "--layers", "4", "--steps", "6", "--warmup", "3", "--ctx", "64", "--no-cpu-baseline", "--no-extras",
+           "--opt", "force_exchange=1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, stdin=subprocess.DEVNULL)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, r.stderr[-2000:]
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    assert d["engine"]["exchange_calls"] > 0, d["engine"]
+    # --gpus 2 on a one-GPU box without a launcher: the self-spawned ranks cannot both get a GPU -> non-zero exit, no JSON line
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--layers", "2", "--steps", "2", "--warmup", "1", "--ctx", "64",
+                         "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=600, env=env, stdin=subprocess.DEVNULL)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert r2.returncode != 0 and not any(l.startswith('{"metric"') for l in r2.stdout.splitlines())
