@@ -191,6 +191,7 @@ size_t tile_mat_bytes(size_t rows, size_t n);  // bytes of one (rows, n) Q2_K ma
                           // line: 35.6 us per launch, apart: 35.2)
 #endif
 #define MOE_CTR_WORDS (16 * MOE_CTR_STRIDE + 16)
+#define MOE_GAVE_UP_WORD (16 * MOE_CTR_STRIDE + 8)  // device-side copy of "a hand-off gave up during this token" (cleared with the counters)
 #define MOE_BLK_CTRS 1024  // per-block arrival counters of the fused expert launch (K x mi / 256 <= 1024)
 struct MoeFfnArgs {
   int quant;

@@ -191,13 +191,18 @@ __global__ __launch_bounds__(1024) void moe_ffn_kernel(const MoeFfnArgs a) {
     auto wait_slots = [&]() {
       if (wave == 0) {
         unsigned spins = 0;
-        // (an earlier launch of this token already gave up: the host will re-run the token - do not spin the limit out again in every layer)
-        if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) spins = (unsigned)a.spin_limit > 64u ? (unsigned)a.spin_limit - 64u : 0u;
+        // (an earlier launch of this token already gave up - a DEVICE word next to the counters says so; the host-visible word lives
+      // in pinned host memory and must not be read here: 256 reads over PCIe cost the launch 15 us - : the host will re-run the token,
+      // do not spin the limit out again in every layer)
+        if (__hip_atomic_load(a.slot_ctr + MOE_GAVE_UP_WORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) spins = (unsigned)a.spin_limit > 64u ? (unsigned)a.spin_limit - 64u : 0u;
         for (;;) {
           const bool ok = lane >= K || __hip_atomic_load(a.slot_ctr + lane * MOE_CTR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= slot_target;
           if (__all(ok)) break;
           __builtin_amdgcn_s_sleep(1);  // (8 or 32, or ONE counter for all slots: no difference in the time to pass)
-          if (++spins > (unsigned)a.spin_limit) { if (lane == 0) *a.err = 1u; break; }
+          if (++spins > (unsigned)a.spin_limit) {
+          if (lane == 0) { *a.err = 1u; __hip_atomic_store(a.slot_ctr + MOE_GAVE_UP_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+          break;
+        }
         }
         if (a.spin_limit < 0 && bid == 0 && lane == 0) *a.err = 1u;  // fault injection (option "moe_spin_limit" < 0): tests/test_fused_moe_gpu.py
       }
@@ -469,14 +474,19 @@ __global__ __launch_bounds__(1024) void moe_ffn_f_kernel(const MoeFfnArgs a) {
     // hand-off: lane k of wave 0 watches slot k's counter (the shared expert's is slot K); bounded like the K-quant kernel's
     if (wave == 0) {
       unsigned spins = 0;
-      // (an earlier launch of this token already gave up: the host will re-run the token - do not spin the limit out again in every layer)
-      if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) spins = (unsigned)a.spin_limit > 64u ? (unsigned)a.spin_limit - 64u : 0u;
+      // (an earlier launch of this token already gave up - a DEVICE word next to the counters says so; the host-visible word lives
+      // in pinned host memory and must not be read here: 256 reads over PCIe cost the launch 15 us - : the host will re-run the token,
+      // do not spin the limit out again in every layer)
+      if (__hip_atomic_load(a.slot_ctr + MOE_GAVE_UP_WORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) spins = (unsigned)a.spin_limit > 64u ? (unsigned)a.spin_limit - 64u : 0u;
       for (;;) {
         const unsigned want = lane < K ? (unsigned)a.mi : (unsigned)a.shared_n;
         const bool ok = lane >= slots || __hip_atomic_load(a.slot_ctr + lane * MOE_CTR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
         if (__all(ok)) break;
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (unsigned)a.spin_limit) { if (lane == 0) *a.err = 1u; break; }
+        if (++spins > (unsigned)a.spin_limit) {
+          if (lane == 0) { *a.err = 1u; __hip_atomic_store(a.slot_ctr + MOE_GAVE_UP_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+          break;
+        }
       }
       if (a.spin_limit < 0 && bid == 0 && lane == 0) *a.err = 1u;  // fault injection
     }

@@ -21,6 +21,10 @@
                       // 9 steps per wave (two tiles x 9 slots x 8 blocks = 144 per workgroup), and a ninth step requested behind the
                       // hand-off paid a whole memory round trip there; nine steps in registers spill (128 VGPRs at 16 waves)
 #define MOE_PARK_B 1536  // bytes of a parked step: 16 + 4 + 4 per lane
+// (Measured and rejected: the parked steps requested at kernel ENTRY as LDS-DMA (global_load_lds_dwordx4 / _dword straight into the
+// park layout, no register in between), so that 2 of a wave's 9-10 W2 steps stream before phase A instead of behind it.  A CU's
+// loads return in order: the staging of x (an L2 hit, 1.2 us) then waits behind the 43 KB of HBM reads - staged x 1.2 -> 3.0 us,
+// phase A done 15.3 -> 17.6, exit 31.9 -> 33.0, the launch 34.0 -> 35.2 us.)
 
 template <int DUMMY>
 __global__ __launch_bounds__(1024) void moe_ffn_tile_kernel(const MoeFfnArgs a) {
@@ -197,13 +201,18 @@ __global__ __launch_bounds__(1024) void moe_ffn_tile_kernel(const MoeFfnArgs a) 
     const unsigned slot_target = a.hq_qs ? (unsigned)(a.mi >> 8) : (unsigned)a.UA;
     if (wave == 0) {
       unsigned spins = 0;
-      // (an earlier launch of this token already gave up: the host will re-run the token - do not spin the limit out again in every layer)
-      if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) spins = (unsigned)a.spin_limit > 64u ? (unsigned)a.spin_limit - 64u : 0u;
+      // (an earlier launch of this token already gave up - a DEVICE word next to the counters says so; the host-visible word lives
+      // in pinned host memory and must not be read here: 256 reads over PCIe cost the launch 15 us - : the host will re-run the token,
+      // do not spin the limit out again in every layer)
+      if (__hip_atomic_load(a.slot_ctr + MOE_GAVE_UP_WORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) spins = (unsigned)a.spin_limit > 64u ? (unsigned)a.spin_limit - 64u : 0u;
       for (;;) {
         const bool ok = lane >= K || __hip_atomic_load(a.slot_ctr + lane * MOE_CTR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= slot_target;
         if (__all(ok)) break;
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (unsigned)a.spin_limit) { if (lane == 0) *a.err = 1u; break; }
+        if (++spins > (unsigned)a.spin_limit) {
+          if (lane == 0) { *a.err = 1u; __hip_atomic_store(a.slot_ctr + MOE_GAVE_UP_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+          break;
+        }
       }
       if (a.spin_limit < 0 && bid == 0 && lane == 0) *a.err = 1u;  // fault injection (option "moe_spin_limit" < 0)
     }

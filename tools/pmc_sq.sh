@@ -12,8 +12,8 @@ OUT=$ROOT/gpurun_out/pmc_sq
 rm -rf $OUT; mkdir -p $OUT
 ARGS="--layers 8 --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-extras ${PMC_BENCH_ARGS}"
 cd /tmp
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_LDS --kernel-trace -d $OUT/p1 -- python $ROOT/bench.py $ARGS > $OUT/p1.log 2>&1
-rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES --kernel-trace -d $OUT/p2 -- python $ROOT/bench.py $ARGS > $OUT/p2.log 2>&1
+timeout 180 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_LDS --kernel-trace -d $OUT/p1 -- python $ROOT/bench.py $ARGS < /dev/null > $OUT/p1.log 2>&1
+timeout 180 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES --kernel-trace -d $OUT/p2 -- python $ROOT/bench.py $ARGS < /dev/null > $OUT/p2.log 2>&1
 cd $ROOT
 python3 - "$OUT" > gpurun_out/${R}_pmc_sq.txt <<'PY'
 import collections, glob, re, sqlite3, sys
@@ -45,4 +45,4 @@ for name in sorted(agg, key=lambda n: -sum(agg[n].get("SQ_WAVE_CYCLES", [0]))):
         if "SQ_INSTS_VMEM_RD" in c: print(f"   VALU instructions per VMEM read instruction   {c['SQ_INSTS_VALU'] / max(1.0, c['SQ_INSTS_VMEM_RD']):.1f}")
 PY
 rm -rf $OUT/p1 $OUT/p2
-cat gpurun_out/${R}_pmc_sq.txt | head -150
+head -150 gpurun_out/${R}_pmc_sq.txt

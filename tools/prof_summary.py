@@ -19,7 +19,7 @@ import sqlite3
 
 # bench.py kernel class -> substring of the kernel symbol that implements it in the V3 Q2_K bench
 CLASS_KERNEL = {
-    "moe_ffn": "moe_ffn_kernel",  # routed experts w1/w3 + W2 + the shared expert's W2 + combine: one launch (round 2)
+    "moe_ffn": "moe_ffn_",  # routed experts w1/w3 + W2 + the shared expert's W2 + combine: one launch (moe_ffn_kernel; round 4: moe_ffn_tile_kernel)
     # (two-launch form, DSK_NO_FUSE_MOE=1): one kernel, two populations of dispatches (8 routed experts / dense w1/w3)
     "gemv_experts_w13": ("gemv_kernel<3, 1, 4, true, 16>", "lo"),
     "gemv_dense_w13": ("gemv_kernel<3, 1, 4, true, 16>", "hi"),
@@ -27,7 +27,7 @@ CLASS_KERNEL = {
     "gemv_wo": "gemv_kernel<3, 1, 4, false, 16>",
     # wq_a || wkv_a (5 MB): 64 lanes per row, 2 column steps (gemv_kernel<3, 1, 8, false, 16> = dense w2 and lm_head)
     "gemv_qkv_a": "gemv_kernel<3, 1, 2, false, 16>",
-    "router_gate": "router_shared_kernel",  # router + the shared expert's w1/w3 (router_gate_kernel when not fused)
+    "router_gate": "router_shared_",  # router + the shared expert's w1/w3 (router_shared_kernel / router_shared_tile_kernel; router_gate_kernel when not fused)
     "attn_mha": "head_attn_kernel",
     "attn_mla": "mla_head_kernel",
 }
