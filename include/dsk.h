@@ -199,11 +199,16 @@ int dsk_model_destroy(dsk_model* m);
  *   "force_exchange"  0  run the expert-sharded code path (two-launch experts, RCCL all-reduce when the context has a
  *                        communicator, separate combine launch) at world == 1 too
  *   "graph_with_comm" 1  the sharded step - RCCL exchange included - is captured into a hipGraph after the first (eager) token of a
- *                        mode, like the one-GPU step (0: enqueued eagerly; capture validated on a 1-rank communicator only) */
+ *                        mode, like the one-GPU step (0: enqueued eagerly; capture validated on a 1-rank communicator only)
+ *   "q2k_tiles"       1  HBM layout of Q2_K matrices, fixed BEFORE the first tensor is bound (DSK_ERR_STATE afterwards):
+ *                        0 planes for the dot4 kernels; 1 the routed and shared experts' matrices as 16-row x 256-column tile
+ *                        records (1344 B) whose sub-block dots run on v_mfma_i32_16x16x64_i8; 2 every role that has a tiled
+ *                        kernel.  Same integer arithmetic at every level (src/quant.cpp:666-783), a different f32 association of
+ *                        the block sums; the caller's bytes are reference-format blocks at every level */
 int dsk_model_set_option(dsk_model* m, const char* key, int value);
 /* Read-only counters: "handoff_fallbacks" (times a hand-off give-up moved the model to the two-launch form; the token
  * that hit it was re-run transparently), "fused_moe_layers", "graph_captured", "exchange_calls" (RCCL collectives this
- * model has enqueued eagerly). */
+ * model has enqueued eagerly), "tiled_tensors" (weight tensors held as tile records, option "q2k_tiles"). */
 int dsk_model_get_info(dsk_model* m, const char* key, int* value);
 /* models created on the context and not yet destroyed (a context destroyed while models are alive is freed by the last
  * dsk_model_destroy) */
