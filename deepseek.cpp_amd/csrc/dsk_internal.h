@@ -289,6 +289,8 @@ struct NormJob {         // one workgroup of norm_q8_kernel
 // ---- launchers (kernels_misc.hip) --------------------------------------------------
 // x[i] += sum_k w[k] * eout[k][i] (k order), then + eout[n_slots][i] if add_shared (src/infer.cpp:874-877, 900-903)
 int launch_moe_combine(hipStream_t st, float* x, const float* eout, const float* weights, int n_slots, int add_shared, int n);
+int launch_moe_combine_gathered(hipStream_t st, float* x, const float* gathered, const float* eout, const int* experts,
+                                const float* weights, int n_slots, int add_shared, int n, int per);
 int launch_quantize_q8k(hipStream_t st, const float* x, int n, int8_t* qs, float* d, int16_t* bsums);
 int launch_norm_jobs(hipStream_t st, const NormJob* jobs, int n_jobs, const StepParams* sp);
 int launch_repack_q2k(hipStream_t st, const uint8_t* aos, size_t n_blocks, uint8_t* qs, uint8_t* sc, uint8_t* dm);

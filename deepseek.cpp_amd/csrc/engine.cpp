@@ -261,6 +261,7 @@ extern "C" int dsk_model_set_option(dsk_model* m, const char* key, int value) {
   else if (k == "fuse_moe_float") m->fuse_moe_float = value != 0;
   else if (k == "force_exchange") m->force_exchange = value != 0;
   else if (k == "graph_with_comm") m->graph_with_comm = value != 0;
+  else if (k == "exchange_allgather") m->exchange_allgather = value != 0;
   else if (k == "q2k_tiles") {
     if (m->any_bound) DSK_FAIL(DSK_ERR_STATE, "set_option: q2k_tiles must be set before the first tensor is bound");
     if (value < 0 || value > 2) DSK_FAIL(DSK_ERR_INVALID, "set_option: q2k_tiles %d (0 none, 1 experts, 2 every converted role)", value);
@@ -469,6 +470,14 @@ extern "C" int dsk_expert_shard(int n_experts, int world, int rank, int* base, i
   const int per = cdiv(n_experts, world);
   *base = std::min(n_experts, rank * per);
   *count = std::max(0, std::min(per, n_experts - *base));
+  return DSK_OK;
+}
+
+// the rank that owns expert `expert` under dsk_expert_shard's partition - what the gathered combine evaluates on the device
+// (kernels_misc.hip moe_combine_gathered_kernel: e / ceil(E / world))
+extern "C" int dsk_expert_owner(int n_experts, int world, int expert, int* rank) {
+  if (n_experts < 1 || world < 1 || expert < 0 || expert >= n_experts || !rank) DSK_FAIL(DSK_ERR_INVALID, "expert_owner: bad argument");
+  *rank = expert / cdiv(n_experts, world);
   return DSK_OK;
 }
 
@@ -750,6 +759,8 @@ extern "C" int dsk_model_finalize(dsk_model* m) {
   DSK_TRY(alloc_f(m, &m->att_out, (size_t)H * std::max(c.v_head_dim, c.use_mla ? c.kv_lora_rank : 0)));
   DSK_TRY(alloc_f(m, &m->hb, hb_n));
   DSK_TRY(alloc_f(m, &m->eout, (size_t)slots * c.dim));
+  if (m->exchange_allgather && m->sharded())  // the all-gather form of the exchange: every rank's routed slot rows side by side
+    DSK_TRY(alloc_f(m, &m->egather, (size_t)std::max(1, m->ctx->world) * std::max(1, c.n_active_routed) * c.dim));
   DSK_TRY(alloc_f(m, &m->q_c, (size_t)H * std::max(1, c.kv_lora_rank)));
   DSK_TRY(alloc_f(m, &m->q_rope, (size_t)H * std::max(1, c.qk_rope_head_dim)));
   DSK_TRY(alloc_f(m, &m->vb_out, (size_t)H * c.v_head_dim));
@@ -854,6 +865,7 @@ extern "C" int dsk_model_destroy(dsk_model* m) {
   free_plans(m);
   for (void* p : {(void*)m->tap_qs, (void*)m->tap_d, (void*)m->tap_latent, (void*)m->stage_x_mid})
     if (p) hipFree(p);
+  if (m->egather) hipFree(m->egather);
   if (m->moe_ctr) hipFree(m->moe_ctr);
   if (m->moe_blk_ctr) hipFree(m->moe_blk_ctr);
   if (m->moe_timeline) hipFree(m->moe_timeline);

@@ -117,6 +117,9 @@ struct dsk_model {
   int q2k_tiles = 1;               // "q2k_tiles": which Q2_K tensors live in the tiled layout (tile_device.h): 0 none, 1 the experts, 2 every converted role (engine.cpp role_tiled); set before the first bind
   bool any_bound = false;
   bool graph_with_comm = true;     // "graph_with_comm": the sharded step (RCCL exchange included) is captured into a hipGraph too, after the first eager token of a mode (0: enqueued eagerly)
+  bool exchange_allgather = false;  // "exchange_allgather": the sharded exchange as ONE all-gather of the ranks' slot rows (each slot is read from
+                                    // its owner's copy) instead of a sum all-reduce
+  float* egather = nullptr;         // [world][n_active_routed][dim], allocated at finalize when that option is set
   int exchange_calls = 0;          // RCCL collectives enqueued by this model (eager path) - diagnostics
   int handoff_fallbacks = 0;       // times a hand-off give-up switched this model to the two-launch form (dsk_model_get_info)
   bool sharded() const { return ctx->world > 1 || force_exchange; }

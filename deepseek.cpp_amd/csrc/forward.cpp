@@ -651,6 +651,19 @@ static int ffn(dsk_model* m, int l) {
   DSK_TRY(run_plan(m, "gemv_experts_w2", m->lp_w2[l]));
   if (exchange || (m->sharded() && m->class_filter)) {
     // every routed slot is non-zero on exactly one rank: a sum all-reduce is exact and order-independent
+    if (m->ctx->comm && exchange && m->egather) {
+      // all-gather form (option "exchange_allgather"): ONE collective phase instead of the all-reduce's reduce-scatter + all-gather,
+      // (world - 1) x K x dim floats received per rank instead of ~2 x K x dim.  Each rank contributes its K slot rows as they are
+      // (a captured graph cannot size a message by the routing); the combine reads slot k from the copy of the rank that OWNS
+      // expert k and never looks at the others.  Which form is faster is a question for an 8-GPU box.
+      ncclResult_t rr = ncclAllGather(m->eout, m->egather, (size_t)K * c.dim, ncclFloat, m->ctx->comm, st);
+      if (rr != ncclSuccess) DSK_FAIL(DSK_ERR_COMM, "ncclAllGather: %s", ncclGetErrorString(rr));
+      m->exchange_calls++;
+      PROFILED("moe_combine", (double)c.dim * (K + 3) * 4,
+               launch_moe_combine_gathered(st, m->x, m->egather, m->eout, m->route_e + (size_t)l * K, m->route_w + (size_t)l * K, K,
+                                           c.n_shared_experts > 0, c.dim, cdiv(E, std::max(1, m->ctx->world))));
+      return DSK_OK;
+    }
     if (m->ctx->comm && exchange) {  // (comm is null only in a single-rank dry run of a shard, dsk_comm_init with uid = NULL)
       ncclResult_t rr = ncclAllReduce(m->eout, m->eout, (size_t)K * c.dim, ncclFloat, ncclSum, m->ctx->comm, st);
       if (rr != ncclSuccess) DSK_FAIL(DSK_ERR_COMM, "ncclAllReduce: %s", ncclGetErrorString(rr));

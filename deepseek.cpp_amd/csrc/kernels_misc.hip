@@ -115,6 +115,30 @@ int launch_moe_combine(hipStream_t st, float* x, const float* eout, const float*
   return DSK_OK;
 }
 
+// ... after the ALL-GATHER form of the exchange (option "exchange_allgather"): gathered[r] holds rank r's n_slots slot rows, of
+// which only the rows of the experts r owns mean anything; slot k is read from the rank that owns expert experts[k]
+// (dsk_expert_owner: e / per, per = ceil(E / world)), the shared expert's row from this rank's own buffer.  Same k-ordered
+// multiply-adds on the same values as moe_combine_kernel after the sum all-reduce.
+__global__ __launch_bounds__(256) void moe_combine_gathered_kernel(float* __restrict__ x, const float* __restrict__ gathered,
+                                                                   const float* __restrict__ eout, const int* __restrict__ experts,
+                                                                   const float* __restrict__ w, int n_slots, int add_shared, int n, int per) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float xv = x[i];
+  for (int k = 0; k < n_slots; ++k) {
+    const int owner = experts[k] / per;
+    xv = fmaf(gathered[((size_t)owner * n_slots + k) * n + i], w[k], xv);
+  }
+  if (add_shared) xv += eout[(size_t)n_slots * n + i];
+  x[i] = xv;
+}
+int launch_moe_combine_gathered(hipStream_t st, float* x, const float* gathered, const float* eout, const int* experts,
+                                const float* weights, int n_slots, int add_shared, int n, int per) {
+  hipLaunchKernelGGL(moe_combine_gathered_kernel, dim3((n + 255) / 256), dim3(256), 0, st, x, gathered, eout, experts, weights,
+                     n_slots, add_shared, n, per);
+  return DSK_OK;
+}
+
 // argmax with Sampler::sample_argmax's tie rule: the lowest index among equal maxima (src/sampler.cpp:28-39;
 // -FLT_MAX start value: a vector of NaNs / -inf yields index 0 like the reference)
 __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ x, int n, int* __restrict__ out) {

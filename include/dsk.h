@@ -155,6 +155,8 @@ int dsk_comm_init(dsk_ctx* ctx, const void* uid128, int rank, int world);
 /* Which experts of an E-expert routed stack rank `rank` of `world` owns: [*base, *base + *count).
    Host arithmetic only (no GPU needed). */
 int dsk_expert_shard(int n_experts, int world, int rank, int* base, int* count);
+/* ... and the rank that owns one expert under that partition (what the all-gather form of the exchange evaluates per slot). */
+int dsk_expert_owner(int n_experts, int world, int expert, int* rank);
 /* Tensor-parallel partitions (DESIGN.md 4.4 - host arithmetic of the design, no engine mode yet):
    output rows [*row0, *row0 + *count) of a `rows`-row GEMV for rank `rank` of `world`, in multiples of `unit` rows
    (rows % unit == 0); heads likewise.  Rows are independent dot products: the all-gather of the ranges equals the one-GPU
@@ -200,6 +202,9 @@ int dsk_model_destroy(dsk_model* m);
  *                        communicator, separate combine launch) at world == 1 too
  *   "graph_with_comm" 1  the sharded step - RCCL exchange included - is captured into a hipGraph after the first (eager) token of a
  *                        mode, like the one-GPU step (0: enqueued eagerly; capture validated on a 1-rank communicator only)
+ *   "exchange_allgather" 0  the sharded exchange as ONE ncclAllGather of every rank's K slot rows, each slot then read from the
+ *                        copy of the rank that owns its expert (dsk_expert_owner), instead of a sum ncclAllReduce; bit-identical;
+ *                        no multi-GPU measurement exists for either form
  *   "q2k_tiles"       1  HBM layout of Q2_K matrices, fixed BEFORE the first tensor is bound (DSK_ERR_STATE afterwards):
  *                        0 planes for the dot4 kernels; 1 the routed and shared experts' matrices as 16-row x 256-column tile
  *                        records (1344 B) whose sub-block dots run on v_mfma_i32_16x16x64_i8; 2 every role that has a tiled

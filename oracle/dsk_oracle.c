@@ -447,6 +447,56 @@ int orc_gemv_q8(int quant, const void* w, int d, int n, const int8_t* qs, const 
   return 0;
 }
 
+/* The Q2_K x Q8_K GEMV with the f32 ASSOCIATION of the device's tiled kernels (csrc/tile_device.h), on a given Q8_K vector.
+ * Same integers as ggml_vec_dot_q2_K_q8_K (src/quant.cpp:666-783: the sub-block sums times their 4-bit scales, the 4-bit
+ * mins times the sub-block sums of the codes); what differs from vec_dot_q2k above - the AVX2 lane order - is only how the
+ * block terms are added in f32.  The device splits the 16 sub-blocks of a block into four groups g (sub-blocks 4g .. 4g+3),
+ * keeps per group
+ *     accd = fma(dx*d, float(F_g * isum_g), accd),  accm = fma(dx*dmin, float(summs_g), accm)      [F_g = 4 (g even), 16 (g odd)]
+ * over the blocks of an ITEM (4 consecutive blocks when the row has more than 8, one block otherwise), closes an item with
+ *     P = fma(accd, 1 / F_g, -accm),
+ * adds the items' P per group in order (from 0) and the four groups as (S0 + S1) + (S2 + S3).
+ * Test infrastructure: lets the parity tests demand BIT equality from the tiled kernels (tests/test_tiles_gpu.py) while the
+ * distance between the two associations is bounded on the CPU (tests/test_oracle_pin.py). */
+int orc_gemv_q2k_tiles(const void* w, int d, int n, const int8_t* qs, const float* yd, float* out) {
+  if (n % QK_K) return fail("k-quant gemv: n % 256 != 0");
+  const int nb = n / QK_K, seg = nb > 8 ? 4 : 1;
+  for (int r = 0; r < d; ++r) {
+    const uint8_t* row = (const uint8_t*)w + (size_t)r * nb * Q2K_BYTES;
+    float S[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int b0 = 0; b0 < nb; b0 += seg) {
+      float accd[4] = {0.f, 0.f, 0.f, 0.f}, accm[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int b = b0; b < b0 + seg && b < nb; ++b) {
+        const uint8_t* blk = row + (size_t)b * Q2K_BYTES;
+        const uint8_t* sc = blk;
+        const uint8_t* q2 = blk + 16;
+        const int8_t* a = qs + (size_t)b * QK_K;
+        const float dd = yd[b] * orc_half_to_float(rd16(blk + 80));
+        const float dmn = yd[b] * orc_half_to_float(rd16(blk + 82));
+        for (int g = 0; g < 4; ++g) {
+          int isum = 0, summs = 0;
+          for (int i = 0; i < 4; ++i) {
+            const int j = 4 * g + i, h = j >> 3, s = (j & 7) >> 1, lh = j & 1;  /* layout of dequantize_row_q2_K, src/quant.cpp:217-247 */
+            int dot = 0, bsum = 0;
+            for (int t = 0; t < 16; ++t) {
+              dot += ((q2[32 * h + 16 * lh + t] >> (2 * s)) & 3) * a[16 * j + t];
+              bsum += a[16 * j + t];
+            }
+            isum += (sc[j] & 0xF) * dot;
+            summs += (sc[j] >> 4) * bsum;
+          }
+          const int F = (g & 1) ? 16 : 4;
+          accd[g] = fmaf(dd, (float)(F * isum), accd[g]);
+          accm[g] = fmaf(dmn, (float)summs, accm[g]);
+        }
+      }
+      for (int g = 0; g < 4; ++g) S[g] += fmaf(accd[g], (g & 1) ? 0.0625f : 0.25f, -accm[g]);
+    }
+    out[r] = (S[0] + S[1]) + (S[2] + S[3]);
+  }
+  return 0;
+}
+
 int orc_gemv(int quant, const void* w, const float* scale, const int32_t* block_size, int d,
              int n, const float* x, float* out) {
   switch (quant) {

@@ -37,6 +37,8 @@ int orc_gemv(int quant, const void* w, const float* scale, const int32_t* block_
              int d, int n, const float* x, float* out);
 /* K-quant GEMV on a given Q8_K vector (codes + block scales), for teacher-forced parity at a staging point */
 int orc_gemv_q8(int quant, const void* w, int d, int n, const int8_t* qs, const float* yd, float* out);
+/* Q2_K GEMV on a given Q8_K vector with the f32 association of the device's tiled kernels (csrc/tile_device.h) */
+int orc_gemv_q2k_tiles(const void* w, int d, int n, const int8_t* qs, const float* yd, float* out);
 int orc_gemv_expert(int quant, const void* w, const float* scale, const int32_t* block_size,
                     int expert, int d, int n, const float* x, float* out);
 int orc_embed_row(int quant, const void* w, const float* scale, const int32_t* block_size,

@@ -143,6 +143,18 @@ class Oracle(_Lib):
             raise RuntimeError(self.err())
         return out
 
+    def gemv_q2k_tiles(self, w, d, n, qs, yd):
+        """Q2_K GEMV on a GIVEN Q8_K vector with the f32 association of the device's tiled kernels (orc_gemv_q2k_tiles)."""
+        qs = np.ascontiguousarray(qs, np.int8)
+        yd = np.ascontiguousarray(yd, np.float32)
+        assert qs.size == n and yd.size == n // 256
+        out = np.zeros(d, np.float32)
+        f = self.lib.orc_gemv_q2k_tiles
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, c_i8, c_f, c_f]
+        if f(vp(w), d, n, fp(qs, c_i8), fp(yd), fp(out)):
+            raise RuntimeError(self.err())
+        return out
+
     def gemv_expert(self, quant, w, expert, d, n, x, scale=None, block_size=(0, 0)):
         x = np.ascontiguousarray(x, np.float32)
         out = np.zeros(d, np.float32)

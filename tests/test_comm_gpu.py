@@ -22,8 +22,11 @@ def _comm_ctx():
     return c
 
 
+@pytest.mark.parametrize("gather", [0, 1], ids=["allreduce", "allgather"])
 @pytest.mark.parametrize("width", ["tiny", "v3"])
-def test_forced_exchange_runs_rccl_on_the_engine_stream_and_keeps_the_bits(ctx, width):
+def test_forced_exchange_runs_rccl_on_the_engine_stream_and_keeps_the_bits(ctx, width, gather):
+    """gather = 1: option "exchange_allgather" - ncclAllGather of the ranks' slot rows, the combine reads every slot from its
+    owner's copy (one rank here: owner 0); same bits, eager and captured"""
     import dsk
     if width == "tiny":
         c = synth.preset("tiny_v3", "q2_k", False)
@@ -34,7 +37,7 @@ def test_forced_exchange_runs_rccl_on_the_engine_stream_and_keeps_the_bits(ctx, 
     n_moe = c.n_layers - c.first_k_dense_replace
     A = dsk.Model(ctx, c, T, synth_seed=seed)
     cc = _comm_ctx()
-    B = dsk.Model(cc, c, T, synth_seed=seed, options={"force_exchange": 1, "graph_with_comm": 0})
+    B = dsk.Model(cc, c, T, synth_seed=seed, options={"force_exchange": 1, "graph_with_comm": 0, "exchange_allgather": gather})
     assert B.info("fused_moe_layers") == 0
     toks = [5, 9, 700, 3, 44]
     for pos, t in enumerate(toks):
@@ -45,14 +48,14 @@ def test_forced_exchange_runs_rccl_on_the_engine_stream_and_keeps_the_bits(ctx, 
     assert B.info("graph_captured") == 0
     B.close()
     # the same step captured into a hipGraph (RCCL is initialised by the first, eager, token)
-    G = dsk.Model(cc, c, T, synth_seed=seed, options={"force_exchange": 1})  # graph_with_comm is the default
+    G = dsk.Model(cc, c, T, synth_seed=seed, options={"force_exchange": 1, "exchange_allgather": gather})  # graph_with_comm is the default
     try:
         for pos, t in enumerate(toks):
             lg = G.forward(t % c.vocab_size, pos)
             assert np.array_equal(lg, A.forward(t % c.vocab_size, pos)), pos
         captured = G.info("graph_captured")
     except dsk.DskError as e:  # recorded, not hidden: DESIGN.md 4.4 states which it is
-        pytest.xfail(f"ncclAllReduce inside hipStreamBeginCapture failed on this ROCm / RCCL: {e}")
+        pytest.xfail(f"the collective inside hipStreamBeginCapture failed on this ROCm / RCCL: {e}")
     assert captured >= 1
     # replays are bit-stable
     ref = G.forward(7, len(toks)).copy()

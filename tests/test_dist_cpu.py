@@ -29,6 +29,15 @@ def shard(n_experts, world, rank):
     return base.value, count.value
 
 
+def owner(n_experts, world, expert):
+    import dsk
+    r = C.c_int()
+    f = dsk.lib().dsk_expert_owner
+    f.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    dsk.check(f(n_experts, world, expert, C.byref(r)))
+    return r.value
+
+
 @pytest.mark.parametrize("E", [1, 6, 8, 64, 160, 256])
 @pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
 def test_expert_shards_partition_the_stack(E, world):
@@ -41,9 +50,10 @@ def test_expert_shards_partition_the_stack(E, world):
     # ownership as the kernels evaluate it (csrc/kernels_gemv.hip resolve(): le = e - base, 0 <= le < count)
     per = -(-E // world)
     for e in range(E):
-        owner = e // per
-        base, count = shard(E, world, owner)
+        o = e // per
+        base, count = shard(E, world, o)
         assert base <= e < base + count
+        assert owner(E, world, e) == o  # the rank the all-gather form of the exchange reads slot outputs from
 
 
 def test_expert_shard_rejects_bad_arguments():
@@ -147,14 +157,25 @@ def _worker(rank, world, port, seed, q):
             if base <= experts[k] < base + count:
                 eout[k] = _slot(orc, w1[:, :, :], w2, w3, xb, experts[k])
                 mine += 1
-        t = torch.from_numpy(eout)
+        t = torch.from_numpy(eout.copy())
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         out = _combine(x, t.numpy(), weights)
+        # the all-gather form (option "exchange_allgather", csrc/forward.cpp ffn): every rank contributes its K slot rows as they
+        # are - rows of experts it does not own hold junk here, NaN, to prove nobody reads them - and slot k is taken from the
+        # copy of the rank that owns expert k (dsk_expert_owner, what moe_combine_gathered_kernel evaluates)
+        mine_rows = np.full((K, DIM), np.nan, np.float32)
+        for k in range(K):
+            if base <= experts[k] < base + count:
+                mine_rows[k] = eout[k]
+        parts = [torch.zeros(K, DIM) for _ in range(world)]
+        dist.all_gather(parts, torch.from_numpy(mine_rows))
+        picked = np.stack([parts[owner(E, world, int(experts[k]))].numpy()[k] for k in range(K)])
+        out_g = _combine(x, picked, weights)
         # the timing protocol of bench.py: barrier, then the MAX over ranks of a per-rank duration
         dist.barrier()
         dt = torch.tensor([float(rank + 1)], dtype=torch.float64)
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-        q.put((rank, mine, out.tobytes(), float(dt.item())))
+        q.put((rank, mine, out.tobytes(), float(dt.item()), out_g.tobytes()))
     finally:
         dist.destroy_process_group()
 
@@ -184,9 +205,10 @@ def test_two_rank_expert_sharded_layer_is_bit_identical_to_one_rank(oracle):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert [r[1] for r in res] == [2, 1]  # slots computed per rank: experts 1, 3 on rank 0; 6 on rank 1
-    for rank, _, blob, tmax in res:
+    for rank, _, blob, tmax, blob_g in res:
         out = np.frombuffer(blob, np.float32)
         assert np.array_equal(out, ref), f"rank {rank}: sharded result differs from the single-rank result"
+        assert np.array_equal(np.frombuffer(blob_g, np.float32), ref), f"rank {rank}: all-gather form differs"
         assert tmax == 2.0  # every rank sees the slowest rank's time
 
 

@@ -138,6 +138,28 @@ def test_live_gemv_and_q8_bitexact(oracle, ref):
         assert np.array_equal(oracle.gemv(2, w8, d, n, x, s8, (128, 128)), ref.gemv(2, w8, d, n, x, s8, (128, 128)))
 
 
+@pytest.mark.parametrize("rows,n", [(16, 256), (37, 512), (64, 2048), (130, 2304), (48, 7168), (16, 11008)])
+def test_tiled_association_stays_within_float_rounding_of_the_reference_order(oracle, rows, n):
+    """orc_gemv_q2k_tiles restates the f32 association of the device's tiled Q2_K kernels (csrc/tile_device.h) on the integers
+    of ggml_vec_dot_q2_K_q8_K (src/quant.cpp:666-783).  Against orc_gemv_q8 - pinned bit for bit to the reference above - the
+    two may differ by float rounding only: a wrong sub-block, scale or field would show at 1e-3 and up.  Rows of one block, of
+    <= 8 blocks (one item per block) and of more (four-block items, a ragged last item at 43 blocks)."""
+    rng = np.random.default_rng(rows * 131 + n)
+    w = synth.encode_q2k((rng.standard_normal((rows, n)) / np.sqrt(n)).astype(np.float32))
+    x = (rng.standard_normal(n) * rng.uniform(0.05, 20)).astype(np.float32)
+    qs, d, _ = oracle.q8k_quantize(x)
+    want = oracle.gemv_q8(3, w, rows, n, qs, d)
+    got = oracle.gemv_q2k_tiles(w, rows, n, qs, d)
+    assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
+    # exact where f32 cannot round: one block per row, integer-valued scales (d = 1, dmin = 1, dx = 1)
+    if n == 256:
+        w1 = w.copy().reshape(rows, 84)
+        w1[:, 80:84] = np.frombuffer(np.array([1.0, 1.0], np.float16).tobytes(), np.uint8)
+        q1 = rng.integers(-127, 128, 256).astype(np.int8)
+        one = np.ones(1, np.float32)
+        assert np.array_equal(oracle.gemv_q2k_tiles(w1, rows, n, q1, one), oracle.gemv_q8(3, w1, rows, n, q1, one))
+
+
 def test_live_router_gate_exact(oracle, ref):
     rng = np.random.default_rng(4)
     for _ in range(20):

@@ -73,6 +73,22 @@ def test_tiled_gemv_matches_oracle(ctx, oracle, rows, n):
     assert np.abs(got - want).max() <= 2e-5 * max(1e-6, np.abs(want).max())
 
 
+@pytest.mark.parametrize("rows,n", [(16, 256), (37, 512), (64, 2048), (130, 2304), (48, 7168), (16, 11008)])
+def test_tiled_gemv_is_bit_exact_against_the_restated_association(ctx, oracle, rows, n):
+    """the same launches against orc_gemv_q2k_tiles - the oracle's restatement of tile_device.h's f32 association on the
+    integers of ggml_vec_dot_q2_K_q8_K - fed with the Q8_K codes the DEVICE makes of x: every bit must agree (the integer
+    sub-block sums on the matrix pipe are exact, the float steps are the same fused multiply-adds in the same order)"""
+    rng = np.random.default_rng(rows * 977 + n)
+    w = synth.encode_q2k((rng.standard_normal((rows, n)) / np.sqrt(n)).astype(np.float32))
+    x = (rng.standard_normal(n) * rng.uniform(0.05, 20)).astype(np.float32)
+    qs, d, _ = ctx.q8k_quantize(x)
+    oq, od, _ = oracle.q8k_quantize(x)
+    assert np.array_equal(qs, oq) and np.array_equal(d, od)  # quantize_row_q8_K_ref (src/quant.cpp:616-653), bit for bit
+    got = ctx.gemv(3, w, rows, n, x)
+    want = oracle.gemv_q2k_tiles(w, rows, n, qs, d)
+    assert np.array_equal(got, want), (np.abs(got - want).max(), np.abs(want).max())
+
+
 def test_full_width_block_tiled_fused_equals_two_launch(ctx):
     """one dense + one MoE block at DeepSeek-V3 width (256 experts, top-8, 7168 / 2048): the tiled fused expert launch
     (kernels_moe_tile.hip: 8 steps in registers + parked steps, Q8_K hand-over) against the tiled two-launch form, bit for bit"""
