@@ -338,6 +338,9 @@ extern "C" int dsk_plan_gemv(int quant, int rows, int n, int n_tasks, int kind, 
   if (!out || rows < 1 || n < 1 || n_tasks < 1 || n_tasks > GEMV_MAX_TASKS) DSK_FAIL(DSK_ERR_INVALID, "plan_gemv: bad argument");
   GemvLaunch h;
   memset(&h, 0, sizeof h);
+  const bool tiled = (kind & 0x100) != 0;  // kind | 0x100: the weights in the tiled Q2_K layout (tile_device.h; kernels_tile.hip plans it)
+  kind &= 0xff;
+  h.tiled = tiled;
   h.quant = quant; h.glu = kind == 1; h.act = DSK_ACT_SILU; h.b0 = h.b1 = 128;
   static float dummy_x[4], dummy_res[4];
   static unsigned dummy_cnt[4];
@@ -346,14 +349,14 @@ extern "C" int dsk_plan_gemv(int quant, int rows, int n, int n_tasks, int kind, 
     GemvTask& T = h.t[h.n_tasks++];
     T.qs = T.sc = T.hm = T.dm = reinterpret_cast<const uint8_t*>(dummy_q);  // never dereferenced: planning reads shapes only
     if (kind == 1) T.qs2 = T.sc2 = T.hm2 = T.dm2 = T.qs;
-    T.rows = rows; T.n = n; T.local_experts = 1; T.act_mode = act_mode;
+    T.rows = rows; T.n = n; T.local_experts = 1; T.act_mode = act_mode; T.wt_tiled = tiled;
     T.a_qs = dummy_q; T.a_f32 = dummy_x + (kind >= 2 ? i : 0); T.norm_w = dummy_x; T.eps = 1e-6f;
   }
   if (kind >= 2) { h.comb_x = dummy_res; h.comb_counter = dummy_cnt; }
   DSK_TRY(gemv_plan(h, target_wgs > 0 ? target_wgs : 1024));
   const int lpr = 1 << h.lpr_log2;
   out[0] = lpr; out[1] = h.R; out[2] = h.U; out[3] = h.NW; out[4] = h.grid; out[5] = (int)h.lds_bytes; out[6] = h.n_groups;
-  out[7] = h.NW * (64 / lpr) * h.R;
+  out[7] = tiled ? h.t_rcap : h.NW * (64 / lpr) * h.R;  // tiled: item partials a round of strips may hold in LDS
   return DSK_OK;
 }
 

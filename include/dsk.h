@@ -370,8 +370,9 @@ int dsk_time_kernel_class(dsk_model* m, const char* name, int pos, int reps, dou
 /* Diagnostics, host only (no GPU needed): the geometry the launch planner picks for n_tasks equal (rows x n) matrices of
  * one activation group; kind 0 plain, 1 GLU pair (w1 / w3), 2 / 3 tasks with the fused MoE combine; act_mode 0 ready
  * Q8_K, 1 f32, 2 f32 + rmsnorm.  out[8] = lanes per row, rows per lane group (R), column steps in flight (U), waves per
- * workgroup, grid, LDS bytes, activation groups, rows per workgroup step.  tests/test_host_logic.py pins the choices for
- * the DeepSeek-V3 shapes. */
+ * workgroup, grid, LDS bytes, activation groups, rows per workgroup step.  kind | 0x100: the same launch on Q2_K weights in the
+ * tiled layout (option "q2k_tiles"): out[0..2] are placeholders, out[7] = item partials a round of strips holds in LDS.
+ * tests/test_host_logic.py pins the choices for the DeepSeek-V3 shapes. */
 int dsk_plan_gemv(int quant, int rows, int n, int n_tasks, int kind, int act_mode, int target_wgs, int* out);
 
 /* Diagnostics: time the GEMV kernel on device-resident synthetic weights (rotated through > 512 MB

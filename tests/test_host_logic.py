@@ -79,6 +79,34 @@ def test_reference_loads_what_the_writer_wrote(ref, oracle):
     M.close()
 
 
+def test_tile_planner_choices_for_the_deepseek_v3_shapes():
+    """gemv_plan_tile (kernels_tile.hip) - the launches on Q2_K weights in the tiled layout (option "q2k_tiles", tile_device.h) -
+    is host logic too: one 16-wave workgroup per CU for every launch that fills the chip, a round of 256 item partials (7168-wide
+    rows: 7 four-block items per strip), LDS = the staged vector's 320-byte block records + the round's partials."""
+    import dsk
+    Q2, T = 3, 0x100
+    rec = lambda n: n // 256 * 320
+    # the routed experts' w1 / w3 (the default level tiles exactly these), the classifier, the dense and shared pairs
+    for rows, nt, kind, act in ((2048, 9, 1, 0), (129280, 1, 0, 2), (18432, 1, 1, 2)):
+        p = dsk.plan_gemv(Q2, rows, 7168, nt, kind | T, act)
+        assert (p["waves"], p["grid"], p["groups"], p["rows_per_step"]) == (16, 256, 1, 256), (rows, p)
+        assert p["lds_bytes"] == rec(7168) + 256 * 256, p
+    # the two-launch experts' W2 with the fused combine: 8-wave workgroups, every task its own group with equal shares
+    p = dsk.plan_gemv(Q2, 7168, 2048, 9, 3 | T, 1)
+    assert (p["waves"], p["groups"], p["rows_per_step"]) == (8, 9, 128) and p["grid"] % 9 == 0 and p["grid"] >= 256, p
+    assert p["lds_bytes"] == rec(2048) + 128 * 256, p
+    # a launch with fewer strips than CUs gets one workgroup per strip (rows padded to 16): 1536 rows -> 96, 37 rows -> 3
+    assert dsk.plan_gemv(Q2, 1536, 7168, 1, T)["grid"] == 96
+    assert dsk.plan_gemv(Q2, 37, 512, 1, T, 1)["grid"] == 3
+    # wo: 64 blocks per row -> 16 four-block items per strip, the vector's records dominate the LDS
+    p = dsk.plan_gemv(Q2, 7168, 16384, 1, T, 0)
+    assert (p["waves"], p["grid"]) == (16, 256) and p["lds_bytes"] == rec(16384) + 256 * 256, p
+    with pytest.raises(dsk.DskError):
+        dsk.plan_gemv(Q2, 64, 300, 1, T)      # not a multiple of 256 columns (quantizer.cpp:8)
+    with pytest.raises(dsk.DskError):
+        dsk.plan_gemv(4, 64, 512, 1, T)       # the tiled layout exists for Q2_K only
+
+
 def test_launch_planner_choices_for_the_deepseek_v3_shapes():
     """gemv_plan (kernels_gemv.hip) is host logic: pin what it picks for the shapes of the headline model, so that a change
     of the rules shows up here and not as a silent slowdown (the measurements behind each choice: DESIGN.md 4.1 / 7)."""
