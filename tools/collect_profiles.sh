@@ -25,5 +25,9 @@ $T python tools/timeline.py < /dev/null 2>&1 | grep -v amdgpu.ids > gpurun_out/$
 $T python tools/moe_timeline.py < /dev/null 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_timeline_moe.txt
 $T python tools/moe_timeline.py --opt q2k_tiles=0 < /dev/null 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_timeline_moe_planes.txt
 timeout 400 bash tools/pmc_sq.sh ${R}_final < /dev/null > /dev/null 2>&1
+# DeepSeek-V2-Lite (BASELINE configs C3) in both Q2_K layouts; the Q8_K hand-over of the fused expert launch against f32 hidden vectors
+$T python bench.py --model v2lite --steps 32 --warmup 4 --no-cpu-baseline --no-extras < /dev/null 2>&1 | grep '^{' | tail -1 > gpurun_out/${R}_bench_v2lite.json
+$T python bench.py --model v2lite --steps 32 --warmup 4 --no-cpu-baseline --no-extras --opt q2k_tiles=0 < /dev/null 2>&1 | grep '^{' | tail -1 > gpurun_out/${R}_bench_v2lite_planes.json
+( timeout 120 python tools/moe_ab.py < /dev/null; timeout 120 python tools/moe_ab.py --opt moe_q8_handoff=0 < /dev/null; timeout 120 python tools/moe_ab.py --opt q2k_tiles=0 < /dev/null ) 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_ab_options.txt
 rm -rf gpurun_out/trace_mha gpurun_out/trace_mla gpurun_out/pmc gpurun_out/pmc_sq
 ls gpurun_out | grep "^${R}_" | head -40

@@ -38,7 +38,8 @@ for _ in range(4):
     pos += 1
 us = {n: round(v[1] * 1e3 / max(1, v[0]), 2) for n, v in acc.items()}
 keep = ["moe_ffn", "router_gate", "gemv_wo", "attn_mha", "attn_mla", "gemv_qkv_a", "gemv_qkv_b", "gemv_lm_head"]
-print(f"{os.path.basename(os.environ.get('DSK_LIB', 'libdsk_hip.so')):28s} {ms:7.4f} ms/token  {1e3 / ms:7.2f} tok/s  "
+label = os.path.basename(os.environ.get('DSK_LIB', 'libdsk_hip.so')) + (' ' + ' '.join(a.opt) if a.opt else '')
+print(f"{label:36s} {ms:7.4f} ms/token  {1e3 / ms:7.2f} tok/s  "
       + "  ".join(f"{n} {us[n]}" for n in keep if n in us)
       + f"  fused {M.info('fused_moe_layers')} fallbacks {M.info('handoff_fallbacks')}  logits {h.hexdigest()[:12]}", flush=True)
 M.close()
