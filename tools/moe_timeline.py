@@ -27,6 +27,16 @@ print("stamp                 min      median   max   (us after the first workgro
 for i, nm in enumerate(names):
     v = t[:, i] - t0
     print(f"{nm:18s} {v.min():8.2f} {np.median(v):8.2f} {v.max():8.2f}")
+if buf[:, 7].any():  # diagnostics builds (-DMOE_TL7=1: end of the workgroup's hand-over duty, bit 0 = it quantised a block; 2: polls passed)
+    raw = buf[:, 7]
+    v = (raw & ~np.uint64(1)).astype(np.float64) / 100.0 - t0
+    last = (raw & np.uint64(1)).astype(bool)
+    print(f"{'stamp 7':18s} {v.min():8.2f} {np.median(v):8.2f} {v.max():8.2f}")
+    if last.any() and not last.all():
+        print(f"{'  bit 0 set':18s} {v[last].min():8.2f} {np.median(v[last]):8.2f} {v[last].max():8.2f}   ({int(last.sum())} workgroups)")
+        print(f"{'  bit 0 clear':18s} {v[~last].min():8.2f} {np.median(v[~last]):8.2f} {v[~last].max():8.2f}")
+        dd = v - (t[:, 2] - t0)
+        print(f"{'  stamp 7 - phase A done':18s} bit 0 set: median {np.median(dd[last]):.2f} max {dd[last].max():.2f}; clear: median {np.median(dd[~last]):.2f} max {dd[~last].max():.2f}")
 d = np.diff(t[:, :7], axis=1)
 print("segment medians (us):", {names[i + 1]: round(float(np.median(d[:, i])), 2) for i in range(6)})
 
