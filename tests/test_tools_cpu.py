@@ -114,3 +114,18 @@ def test_random_block_checkpoints_are_valid_for_the_oracle():
         lg = O.forward(5, 0)
         assert np.all(np.isfinite(lg)) and 0.05 < float(lg.std()) < 20.0, (quant, float(lg.std()))
         O.close()
+
+
+def test_kept_experiment_patches_still_apply():
+    """tools/patches/*.patch are measured-and-rejected kernel variants kept for reproduction (EXPERIMENTS.md): each must still
+    apply to the sources it was cut from, or the A/B tables under profiles/ cannot be re-made"""
+    import glob
+    import shutil
+    import pytest
+    if not shutil.which("git"):
+        pytest.skip("git not available")
+    patches = sorted(glob.glob(os.path.join(ROOT, "tools", "patches", "*.patch")))
+    assert patches
+    for p in patches:
+        r = subprocess.run(["git", "apply", "--check", p], cwd=ROOT, capture_output=True, text=True)
+        assert r.returncode == 0, (os.path.basename(p), r.stderr[:300])
