@@ -160,6 +160,39 @@ def test_tiled_association_stays_within_float_rounding_of_the_reference_order(or
         assert np.array_equal(oracle.gemv_q2k_tiles(w1, rows, n, q1, one), oracle.gemv_q8(3, w1, rows, n, q1, one))
 
 
+def test_scaled_int8_expansion_of_q2k_reproduces_the_reference_block_sums(oracle):
+    """a 2-bit code times its sub-block's 4-bit scale fits an int8 (<= 45), and a packed 32-bit multiply of four masked
+    codes by one scale does not carry between bytes - so Q2_K weights expand to scaled int8 in registers and a PLAIN int8 dot over the
+    256 columns gives the isum of ggml_vec_dot_q2_K_q8_K (src/quant.cpp:666-783) exactly.  Checked here on the packed arithmetic
+    itself, against the oracle's vec_dot on blocks with d = dmin = 1 and a unit activation scale (f32 cannot round those)."""
+    rng = np.random.default_rng(77)
+    rows, n = 8, 1024
+    w = synth.encode_q2k((rng.standard_normal((rows, n)) / np.sqrt(n)).astype(np.float32)).reshape(rows, n // 256, 84).copy()
+    w[:, :, 80:84] = np.frombuffer(np.array([1.0, 1.0], np.float16).tobytes(), np.uint8)
+    a = rng.integers(-127, 128, n).astype(np.int8)
+    want = oracle.gemv_q8(3, np.ascontiguousarray(w.reshape(rows, -1)), rows, n, a, np.ones(n // 256, np.float32))
+    got = np.zeros(rows, np.float64)
+    for r in range(rows):
+        for b in range(n // 256):
+            blk = w[r, b]
+            sc, qs = blk[:16].astype(np.uint32), blk[16:80].copy().view("<u4")  # 16 dwords of packed codes
+            act = a[b * 256:(b + 1) * 256].astype(np.int64)
+            isum = 0
+            for dw in range(16):          # dword dw holds bytes 4 dw .. 4 dw + 3 of the 64: byte t of half h = 32 h + l
+                h, l0 = (4 * dw) // 32, (4 * dw) % 32
+                for s_ in range(4):       # field s_ of byte (h, l) is element 128 h + 32 s_ + l, sub-block 8 h + 2 s_ + l // 16
+                    j = 8 * h + 2 * s_ + l0 // 16
+                    packed = ((int(qs[dw]) >> (2 * s_)) & 0x03030303) * int(sc[j] & 0xF)   # ONE 32-bit multiply for four weights
+                    assert packed < 1 << 32
+                    by = [(packed >> (8 * t)) & 0xFF for t in range(4)]
+                    assert max(by) <= 45                                                   # fits an int8, no carry between bytes
+                    e0 = 128 * h + 32 * s_ + l0
+                    isum += sum(by[t] * int(act[e0 + t]) for t in range(4))
+            summs = sum(int(sc[j] >> 4) * int(act[16 * j:16 * j + 16].sum()) for j in range(16))
+            got[r] += isum - summs
+    assert np.array_equal(got.astype(np.float32), want)
+
+
 def test_live_router_gate_exact(oracle, ref):
     rng = np.random.default_rng(4)
     for _ in range(20):
