@@ -462,6 +462,44 @@ int launch_argmax(hipStream_t st, const float* x, int n, int* out);  // first ma
 size_t sample_scratch_bytes();
 int launch_sample(hipStream_t st, const float* logits, int n, const StepParams* sp, float temperature, float top_p, float coin, float* scratch, int* out);
 
+// ---- batched prompt ingestion (kernels_hydrate.hip, hydrate.cpp) ------------------------------
+// One i8-MFMA GEMM: out[v][row] (+)= W[row] . A[v / a_div] for the entries v of every task's list.  W / W3: Q2_K tile records
+// (tile_device.h) of a plain matrix (n_experts 0) or an expert stack (task e = expert e, e_bytes apart); A: Q8_K rows in the
+// linear struct-of-arrays form (codes [a_rows][n], scales [a_rows][n / 256], sub-block sums [a_rows][n / 16]).
+struct HydGemmArgs {
+  const uint8_t* W;
+  const uint8_t* W3;      // non-null: GLU pair, out = act(W . a) * (W3 . a)
+  size_t e_bytes;
+  int n_experts;
+  int rows, n;
+  const int8_t* a_qs;
+  const float* a_d;
+  const int16_t* a_bsums;
+  int a_rows, a_div;
+  const int* list;        // per task: entries (null: 0 .. m - 1); count (null: m for the one task)
+  const int* count;
+  int list_stride, m;
+  float* out;
+  int out_stride;
+  int epilogue, act;      // EPI_STORE / EPI_ADD (ignored for GLU pairs); DSK_ACT_*
+};
+int launch_hyd_gemm(hipStream_t st, const HydGemmArgs& A, int nq);
+int launch_hyd_norm_q8(hipStream_t st, int NW, const float* X, int P, int n, const float* norm_w, float eps, int8_t* qs, float* d, int16_t* bsums);
+struct HydLatentArgs {
+  const float *q_a, *kv_a, *q_norm, *kv_norm;
+  int q_stride, kv_stride, nq, nkv;
+  float eps;
+  int8_t *qq_qs, *kq_qs;
+  float *qq_d, *kq_d;
+  int16_t *qq_bsums, *kq_bsums;
+};
+int launch_hyd_latent_q8(hipStream_t st, const HydLatentArgs& A, int P);
+int launch_hyd_kv_write(hipStream_t st, const AttnMhaArgs& a, const StepParams* sps, int P, const float* kv_b, int kvb_stride, const float* kv_a, int kva_stride);
+int launch_hyd_attn(hipStream_t st, const AttnMhaArgs& a, const StepParams* sps, int P, int max_kv, const float* q, int q_stride, float* out, int out_stride);
+int launch_hyd_router(hipStream_t st, const RouterArgs& a, int P);
+int launch_hyd_group(hipStream_t st, const int* route_e, int pairs, int E, int* list, int list_stride, int* count);
+int launch_hyd_combine(hipStream_t st, float* X, const float* eout, const float* w, const float* eout_sh, int P, int K, int n);
+
 // ---- engine.cpp helpers shared with ops_api.cpp ----------------------------------
 struct dsk_ctx;
 int ctx_scratch(dsk_ctx* c, int slot, size_t bytes, void** out);

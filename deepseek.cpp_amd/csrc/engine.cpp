@@ -160,6 +160,10 @@ extern "C" int dsk_comm_unique_id(void* uid128) {
 }
 extern "C" int dsk_comm_init(dsk_ctx* c, const void* uid128, int rank, int world) {
   if (!c || world < 1 || rank < 0 || rank >= world) DSK_FAIL(DSK_ERR_INVALID, "comm_init: rank %d / world %d", rank, world);
+  // models already created on this context hold shards sized for the old world and (graph_with_comm) captured graphs whose
+  // nodes reference the old communicator: replacing it under them would be a use-after-free inside RCCL
+  if (c->live_models > 0 && (c->comm || c->world != world || c->rank != rank))
+    DSK_FAIL(DSK_ERR_STATE, "comm_init: %d live model(s) on this context; destroy them before changing the communicator", c->live_models);
   c->rank = rank;
   c->world = world;
   if (!uid128) return DSK_OK;  // world > 1: dry run of one shard (no communicator, the all-reduce is skipped)
@@ -262,6 +266,9 @@ extern "C" int dsk_model_set_option(dsk_model* m, const char* key, int value) {
   else if (k == "force_exchange") m->force_exchange = value != 0;
   else if (k == "graph_with_comm") m->graph_with_comm = value != 0;
   else if (k == "exchange_allgather") m->exchange_allgather = value != 0;
+  else if (k == "hydrate_chunk") { if (value < 1 || value > 1024) DSK_FAIL(DSK_ERR_INVALID, "set_option: hydrate_chunk %d (1 .. 1024)", value); m->hydrate_chunk = value; }
+  else if (k == "hydrate_batched") m->hydrate_batched = value != 0;
+  else if (k == "hydrate_stop_layer") m->hydrate_stop_layer = value;
   else if (k == "q2k_tiles") {
     if (m->any_bound) DSK_FAIL(DSK_ERR_STATE, "set_option: q2k_tiles must be set before the first tensor is bound");
     if (value < 0 || value > 2) DSK_FAIL(DSK_ERR_INVALID, "set_option: q2k_tiles %d (0 none, 1 experts, 2 every converted role)", value);
@@ -275,6 +282,9 @@ extern "C" int dsk_model_get_info(dsk_model* m, const char* key, int* value) {
   if (!m || !key || !value) DSK_FAIL(DSK_ERR_INVALID, "get_info: null argument");
   const std::string k(key);
   if (k == "handoff_fallbacks") *value = m->handoff_fallbacks;
+  else if (k == "graph_capture_fallbacks") *value = m->graph_capture_fallbacks;
+  else if (k == "hydrate_batched_tokens") *value = (int)std::min<long long>(m->hydrate_batched_tokens, 0x7fffffff);
+  else if (k == "hydrate_looped_tokens") *value = (int)std::min<long long>(m->hydrate_looped_tokens, 0x7fffffff);
   else if (k == "fused_moe_layers") { int n = 0; for (auto& a : m->moe_ffn) n += a.grid > 0; *value = n; }
   else if (k == "graph_captured") { int n = 0; for (auto g : m->graph) n += g != nullptr; *value = n; }
   else if (k == "exchange_calls") *value = m->exchange_calls;
@@ -863,6 +873,7 @@ extern "C" int dsk_model_destroy(dsk_model* m) {
                   (void*)m->sp_dev})
     if (p) hipFree(p);
   free_plans(m);
+  hydrate_free(m);
   for (void* p : {(void*)m->tap_qs, (void*)m->tap_d, (void*)m->tap_latent, (void*)m->stage_x_mid})
     if (p) hipFree(p);
   if (m->egather) hipFree(m->egather);

@@ -121,6 +121,7 @@ struct dsk_model {
                                     // its owner's copy) instead of a sum all-reduce
   float* egather = nullptr;         // [world][n_active_routed][dim], allocated at finalize when that option is set
   int exchange_calls = 0;          // RCCL collectives enqueued by this model (eager path) - diagnostics
+  int graph_capture_fallbacks = 0; // a sharded step whose capture / instantiation failed: the model went back to eager enqueueing (dsk_model_get_info)
   int handoff_fallbacks = 0;       // times a hand-off give-up switched this model to the two-launch form (dsk_model_get_info)
   bool sharded() const { return ctx->world > 1 || force_exchange; }
   std::vector<int> lp_sh13;  // shared expert's w1/w3 GLU riding in the router launch (-1: it is a task of lp_w13)
@@ -139,6 +140,13 @@ struct dsk_model {
   unsigned long long* timeline_of(int kind) const { return moe_timeline ? moe_timeline + (size_t)kind * DSK_TL_WGS * 8 : nullptr; }
   unsigned* err_host = nullptr;    // pinned, device-visible: bounded spins report here
   int lp_head = -1;
+  // batched prompt ingestion (hydrate.cpp): buffers allocated by the first dsk_hydrate call that takes the batched path
+  struct HydState* hyd = nullptr;
+  int hydrate_chunk = 128;          // option "hydrate_chunk": tokens per batched chunk
+  int hydrate_stop_layer = 0;       // option "hydrate_stop_layer" (debug): > 0: a batched chunk stops after block value - 1 (dsk_hydrate_get_buffer)
+  bool hydrate_batched = true;      // option "hydrate_batched": 0 = dsk_hydrate always runs the per-token loop
+  long long hydrate_batched_tokens = 0, hydrate_looped_tokens = 0;  // dsk_model_get_info
+  const char* hydrate_why = nullptr;  // why the last dsk_hydrate call looped (nullptr: it did not)
   std::vector<MlaHeadArgs> mla_head;   // per layer (MLA path)
   std::vector<double> head_attn_bytes;
   std::vector<HeadAttnArgs> head_attn;  // per layer (MHA path): second-stage projections + attention, one launch
@@ -181,3 +189,4 @@ extern const int ALL_LAYER_ROLES[];
 extern const int N_LAYER_ROLES;
 int build_plans(dsk_model* m);   // forward.cpp: GEMV launch descriptors, built once at finalize
 void free_plans(dsk_model* m);
+void hydrate_free(dsk_model* m);  // hydrate.cpp

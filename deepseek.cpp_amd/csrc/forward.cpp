@@ -508,9 +508,8 @@ static int run_plan(dsk_model* m, const char* name, int idx) {
 // ---------------------------------------------------------------------------------
 // one token
 // ---------------------------------------------------------------------------------
-static int fill_step_params(dsk_model* m, int token, int pos) {
+int fill_step_params_at(dsk_model* m, int token, int pos, StepParams* sp) {
   const dsk_config& c = m->c;
-  StepParams* sp = m->sp_host;
   const int W = c.rs_original_max_position_embeddings;
   sp->token = token;
   sp->pos = pos;
@@ -531,6 +530,7 @@ static int fill_step_params(dsk_model* m, int token, int pos) {
   }
   return DSK_OK;
 }
+static int fill_step_params(dsk_model* m, int token, int pos) { return fill_step_params_at(m, token, pos, m->sp_host); }
 
 static int attention_mha(dsk_model* m, int l, int max_kv) {
   const dsk_config& c = m->c;
@@ -705,6 +705,13 @@ static int enqueue_forward(dsk_model* m, int mode, int max_kv) {
   return DSK_OK;
 }
 
+// final norm + classifier on the residual stream in m->x, logits to the pinned host buffer (dsk_hydrate's last token)
+int forward_head(dsk_model* m) {
+  DSK_TRY(run_plan(m, "gemv_lm_head", m->lp_head));
+  HIP_TRY(hipMemcpyAsync(m->logits_host, m->logits, (size_t)m->c.vocab_size * 4, hipMemcpyDeviceToHost, m->ctx->stream));
+  return DSK_OK;
+}
+
 static int check_forward_args(dsk_model* m, int token, int pos, int mode, float* host_logits) {
   if (!m) DSK_FAIL(DSK_ERR_INVALID, "forward: null model");
   if (!m->finalized) DSK_FAIL(DSK_ERR_STATE, "forward before finalize");
@@ -761,20 +768,33 @@ static int run_token(dsk_model* m, int token, int pos, int mode, bool retried = 
     m->graph_primed[gi] = true;  // first token of a mode runs eagerly (first-use initialisation), the second is captured
     DSK_TRY(enqueue_forward(m, mode, max_kv));
   } else if (graphable) {
+    bool eager_instead = false;
     if (!m->graph[gi]) {
+      // a graph with the RCCL exchange inside has only ever been validated on a 1-rank communicator (tests/test_comm_gpu.py):
+      // if capture or instantiation fails on this ROCm / RCCL, the model drops to eager enqueueing instead of failing the token
+      const bool comm_graph = m->ctx->comm && m->sharded();
       hipGraph_t g = nullptr;
       HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
       int r = enqueue_forward(m, mode, max_kv);
       hipError_t e = hipStreamEndCapture(st, &g);
-      if (r != DSK_OK) {
-        if (g) hipGraphDestroy(g);
-        return r;
+      hipError_t ei = hipSuccess;
+      if (r == DSK_OK && e == hipSuccess) ei = hipGraphInstantiate(&m->graph[gi], g, nullptr, nullptr, 0);
+      if (g) hipGraphDestroy(g);
+      if (r != DSK_OK || e != hipSuccess || ei != hipSuccess) {
+        m->graph[gi] = nullptr;
+        if (!comm_graph) {
+          if (r != DSK_OK) return r;
+          DSK_FAIL(DSK_ERR_HIP, "graph capture: %s", hipGetErrorString(e != hipSuccess ? e : ei));
+        }
+        (void)hipGetLastError();
+        dsk_clear_error();
+        m->graph_with_comm = false;  // graphable is re-evaluated per token: every later token is enqueued eagerly
+        m->graph_capture_fallbacks++;
+        eager_instead = true;
       }
-      if (e != hipSuccess) DSK_FAIL(DSK_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-      HIP_TRY(hipGraphInstantiate(&m->graph[gi], g, nullptr, nullptr, 0));
-      HIP_TRY(hipGraphDestroy(g));
     }
-    HIP_TRY(hipGraphLaunch(m->graph[gi], st));
+    if (eager_instead) DSK_TRY(enqueue_forward(m, mode, max_kv));
+    else HIP_TRY(hipGraphLaunch(m->graph[gi], st));
   } else {
     DSK_TRY(enqueue_forward(m, mode, max_kv));
   }
@@ -1150,6 +1170,29 @@ extern "C" int dsk_model_set_cache_rows(dsk_model* m, int layer, const char* cac
   if (!base) DSK_FAIL(DSK_ERR_INVALID, "set_cache_rows: this model has no '%s'", cache);
   HIP_TRY(hipStreamSynchronize(m->ctx->stream));
   HIP_TRY(hipMemcpy(base + (size_t)row0 * width, rows, (size_t)nrows * width * 2, hipMemcpyHostToDevice));
+  return DSK_OK;
+}
+
+// ... and the read side: rows [row0, row0 + nrows) of one KV cache of `layer` as f16 bits (tests/test_hydrate_gpu.py compares the
+// caches a batched prompt left with the ones the per-token loop leaves)
+extern "C" int dsk_model_get_cache_rows(dsk_model* m, int layer, const char* cache, int row0, int nrows, uint16_t* rows) {
+  if (!m || !m->finalized || !cache || !rows) DSK_FAIL(DSK_ERR_INVALID, "get_cache_rows: bad argument");
+  if (layer < 0 || layer >= m->c.n_layers || row0 < 0 || nrows < 1 || row0 + nrows > m->c.max_seq_len)
+    DSK_FAIL(DSK_ERR_INVALID, "get_cache_rows: layer %d rows [%d, %d) of %d", layer, row0, row0 + nrows, m->c.max_seq_len);
+  HIP_TRY(hipSetDevice(m->ctx->device));
+  const dsk_config& c = m->c;
+  const Layer& L = m->L[layer];
+  const std::string s(cache);
+  const uint16_t* base = nullptr;
+  size_t width = 0;
+  if (s == "k_cache") { base = L.key_cache; width = (size_t)c.n_heads * m->head_dim; }
+  else if (s == "v_cache") { base = L.value_cache; width = (size_t)c.n_heads * c.v_head_dim; }
+  else if (s == "nope_cache") { base = L.nope_cache; width = (size_t)c.kv_lora_rank; }
+  else if (s == "rope_cache") { base = L.rope_cache; width = (size_t)c.qk_rope_head_dim; }
+  else DSK_FAIL(DSK_ERR_INVALID, "get_cache_rows: unknown cache '%s'", cache);
+  if (!base) DSK_FAIL(DSK_ERR_INVALID, "get_cache_rows: this model has no '%s'", cache);
+  HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+  HIP_TRY(hipMemcpy(rows, base + (size_t)row0 * width, (size_t)nrows * width * 2, hipMemcpyDeviceToHost));
   return DSK_OK;
 }
 

@@ -1,0 +1,349 @@
+// hydrate.cpp -- dsk_hydrate: the prompt phase as batched launches.
+//
+// The reference ingests a prompt one token per forward (src/main.cpp:312-319: Model::forward(token, pos,
+// InferenceMode::HYDRATE_KV_CACHE) for every prompt token but the last; src/infer.cpp:1284-1287 skips the classifier in that
+// mode).  dsk_hydrate(model, tokens, n, pos0, mode, logits) is DEFINED as that loop - dsk_forward(tokens[i], pos0 + i,
+// HYDRATE_KV_CACHE) for i < n - 1, then dsk_forward(tokens[n - 1], pos0 + n - 1, mode) - and, when the model qualifies, runs it
+// as chunks of up to `hydrate_chunk` tokens through every block with each weight matrix read once per chunk
+// (kernels_hydrate.hip): KV-cache rows, residual stream, routing and logits are bit-identical to the loop.
+//
+// Per block and chunk of P tokens (DeepSeek-V3, MHA path; the numbers are the decode launches they replace P times):
+//   rmsnorm + Q8_K of P rows                      (the prologue of launch 1)
+//   GEMM wq_a, wkv_a                              (launch 1)
+//   latent norms + Q8_K                           (prologue of the per-head launch 2)
+//   GEMM wq_b, wkv_b                              (launch 2, projections)
+//   K / V rows of the P positions -> cache; rope(q) + causal attention per (head, token); Q8_K of the outputs   (launch 2)
+//   GEMM wo, x += .                               (launch 3)
+//   router + gate per token (+ Q8_K of rmsnorm(x, ffn_norm)); tokens grouped by expert       (launch 4)
+//   GEMM shared w1/w3 GLU -> Q8_K -> GEMM shared w2                                            (launches 4 / 5)
+//   grouped GEMM experts w1/w3 GLU over the (token, slot) pairs of each expert -> Q8_K -> grouped GEMM w2    (launch 5)
+//   x += sum_k w_k out_k (k order) + shared                                                    (launch 5's combine)
+// A model that does not qualify (float weights, plane layout, MLA, expert-sharded) and positions at or past the ring wrap
+// (the in-place sink rotation of src/infer.cpp:1008-1020 is sequential by nature) take the loop itself.
+#include "engine.h"
+
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+
+int fill_step_params_at(dsk_model* m, int token, int pos, StepParams* sp);  // forward.cpp
+int forward_head(dsk_model* m);                                           // forward.cpp: final norm + classifier on m->x, logits to the pinned host buffer
+
+struct HydQ8 {
+  int8_t* qs = nullptr;
+  float* d = nullptr;
+  int16_t* bsums = nullptr;
+};
+struct HydState {
+  int cap = 0;
+  float *X = nullptr, *q_a = nullptr, *kv_a = nullptr, *q = nullptr, *kv_b = nullptr, *att = nullptr, *hbd = nullptr, *hb = nullptr,
+        *hb_sh = nullptr, *eout = nullptr, *eout_sh = nullptr, *route_w = nullptr, *router_partial = nullptr, *trace = nullptr;
+  HydQ8 a_x, a_qa, a_kva, a_att, a_hd, a_hb, a_hsh;
+  StepParams *sp = nullptr, *sp_host = nullptr;
+  unsigned* router_counter = nullptr;
+  int *route_e = nullptr, *list = nullptr, *count = nullptr;
+  std::vector<void*> allocs;
+};
+
+static int hyd_alloc(HydState* h, void** p, size_t bytes, double* total) {
+  if (bytes == 0) bytes = 16;
+  HIP_TRY(hipMalloc(p, bytes));
+  h->allocs.push_back(*p);
+  *total += (double)bytes;
+  return DSK_OK;
+}
+static int hyd_alloc_q8(HydState* h, HydQ8& q, size_t rows, size_t n, double* total) {
+  DSK_TRY(hyd_alloc(h, (void**)&q.qs, rows * n, total));
+  DSK_TRY(hyd_alloc(h, (void**)&q.d, rows * (n / 256) * 4, total));
+  DSK_TRY(hyd_alloc(h, (void**)&q.bsums, rows * (n / 16) * 2, total));
+  return DSK_OK;
+}
+
+void hydrate_free(dsk_model* m) {
+  if (!m->hyd) return;
+  for (void* p : m->hyd->allocs) hipFree(p);
+  if (m->hyd->sp_host) hipHostFree(m->hyd->sp_host);
+  delete m->hyd;
+  m->hyd = nullptr;
+}
+
+// why this model takes the per-token loop (nullptr: the batched path applies)
+static const char* hyd_why_not(const dsk_model* m) {
+  const dsk_config& c = m->c;
+  if (c.weight_quant != DSK_QUANT_Q2_K) return "weights are not Q2_K";
+  if (c.use_mla) return "MLA attention";
+  if (c.q_lora_rank <= 0) return "no q latent";
+  if (m->sharded()) return "expert-sharded model";
+  if (c.dim % 256 || (c.n_heads * c.v_head_dim) % 256 || c.hidden_dim % 256) return "vector lengths";
+  if (m->head_dim > 256 || c.v_head_dim > 256 || (c.v_head_dim & 3) || (m->head_dim & 3)) return "head dims";
+  if (c.q_lora_rank % 256 || c.kv_lora_rank % 256 || c.q_lora_rank / 256 + c.kv_lora_rank / 256 > 16) return "latent ranks";
+  if (c.n_routed_experts > 256 || c.n_active_routed > 64) return "expert counts";
+  auto tiled = [&](const Layer& L, int role) { return L.t[role].bound() && L.t[role].tiled; };
+  for (int l = 0; l < c.n_layers; ++l) {
+    const Layer& L = m->L[l];
+    for (int role : {DSK_ROLE_WQ_A, DSK_ROLE_WKV_A, DSK_ROLE_WQ_B, DSK_ROLE_WKV_B, DSK_ROLE_WO, DSK_ROLE_W1, DSK_ROLE_W2, DSK_ROLE_W3})
+      if (!tiled(L, role)) return "a Q2_K matrix is not stored as tile records (set option q2k_tiles = 2 before binding)";
+    if (L.is_moe && c.n_shared_experts > 0)
+      for (int role : {DSK_ROLE_SHARED_W1, DSK_ROLE_SHARED_W2, DSK_ROLE_SHARED_W3})
+        if (!tiled(L, role)) return "the shared expert is not stored as tile records";
+    if (L.is_moe && c.moe_intermediate_size % 256) return "moe_intermediate_size";
+  }
+  return nullptr;
+}
+
+static int hyd_ensure(dsk_model* m) {
+  if (m->hyd) return DSK_OK;
+  const dsk_config& c = m->c;
+  HydState* h = new HydState();
+  m->hyd = h;
+  const size_t P = (size_t)std::max(1, m->hydrate_chunk);
+  h->cap = (int)P;
+  const size_t dim = c.dim, H = c.n_heads, hd = m->head_dim, nv = c.qk_nope_head_dim + c.v_head_dim, vd = c.v_head_dim;
+  const size_t K = std::max(1, c.n_active_routed), E = std::max(1, c.n_routed_experts), mi = std::max(256, c.moe_intermediate_size);
+  const size_t shn = std::max<size_t>(256, (size_t)c.n_shared_experts * c.moe_intermediate_size);
+  double tot = 0;
+  DSK_TRY(hyd_alloc(h, (void**)&h->X, P * dim * 4, &tot));
+  DSK_TRY(hyd_alloc(h, (void**)&h->q_a, P * c.q_lora_rank * 4, &tot));
+  DSK_TRY(hyd_alloc(h, (void**)&h->kv_a, P * (c.kv_lora_rank + c.qk_rope_head_dim) * 4, &tot));
+  DSK_TRY(hyd_alloc(h, (void**)&h->q, P * H * hd * 4, &tot));
+  DSK_TRY(hyd_alloc(h, (void**)&h->kv_b, P * H * nv * 4, &tot));
+  DSK_TRY(hyd_alloc(h, (void**)&h->att, P * H * vd * 4, &tot));
+  DSK_TRY(hyd_alloc(h, (void**)&h->hbd, P * c.hidden_dim * 4, &tot));
+  DSK_TRY(hyd_alloc(h, (void**)&h->hb, P * K * mi * 4, &tot));
+  DSK_TRY(hyd_alloc(h, (void**)&h->hb_sh, P * shn * 4, &tot));
+  DSK_TRY(hyd_alloc(h, (void**)&h->eout, P * K * dim * 4, &tot));
+  DSK_TRY(hyd_alloc(h, (void**)&h->eout_sh, P * dim * 4, &tot));
+  DSK_TRY(hyd_alloc(h, (void**)&h->route_w, P * K * 4, &tot));
+  DSK_TRY(hyd_alloc(h, (void**)&h->route_e, P * K * 4, &tot));
+  DSK_TRY(hyd_alloc(h, (void**)&h->router_partial, P * E * 4 + 64, &tot));
+  DSK_TRY(hyd_alloc(h, (void**)&h->router_counter, P * 4, &tot));
+  HIP_TRY(hipMemset(h->router_counter, 0, P * 4));
+  DSK_TRY(hyd_alloc(h, (void**)&h->list, E * P * 4, &tot));
+  DSK_TRY(hyd_alloc(h, (void**)&h->count, E * 4, &tot));
+  DSK_TRY(hyd_alloc_q8(h, h->a_x, P, dim, &tot));
+  DSK_TRY(hyd_alloc_q8(h, h->a_qa, P, c.q_lora_rank, &tot));
+  DSK_TRY(hyd_alloc_q8(h, h->a_kva, P, c.kv_lora_rank, &tot));
+  DSK_TRY(hyd_alloc_q8(h, h->a_att, P, H * vd, &tot));
+  DSK_TRY(hyd_alloc_q8(h, h->a_hd, P, c.hidden_dim, &tot));
+  DSK_TRY(hyd_alloc_q8(h, h->a_hb, P * K, mi, &tot));
+  DSK_TRY(hyd_alloc_q8(h, h->a_hsh, P, shn, &tot));
+  DSK_TRY(hyd_alloc(h, (void**)&h->sp, P * sizeof(StepParams), &tot));
+  HIP_TRY(hipHostMalloc((void**)&h->sp_host, P * sizeof(StepParams), hipHostMallocDefault));
+  if (m->trace) DSK_TRY(hyd_alloc(h, (void**)&h->trace, (size_t)c.n_layers * P * dim * 4, &tot));
+  m->scratch_bytes += tot;
+  return DSK_OK;
+}
+
+// tokens per pass of a GEMM wave: 4 * nq (kernels_hydrate.hip NQ) for a task of `rows_per_task` activation rows on average
+static int hyd_nq(double rows_per_task) { return rows_per_task <= 4.0 ? 1 : (rows_per_task <= 10.0 ? 2 : 4); }
+
+static int hyd_gemm(dsk_model* m, const DTensor& w, const DTensor* w3, const HydQ8& a, int a_rows, int P, float* out, int out_stride, int epilogue) {
+  HydGemmArgs A;
+  memset(&A, 0, sizeof A);
+  A.W = w.qs; A.W3 = w3 ? w3->qs : nullptr;
+  A.rows = w.rows; A.n = w.n;
+  A.a_qs = a.qs; A.a_d = a.d; A.a_bsums = a.bsums; A.a_rows = a_rows; A.a_div = 1;
+  A.m = P; A.out = out; A.out_stride = out_stride; A.epilogue = epilogue; A.act = m->c.act;
+  return launch_hyd_gemm(m->ctx->stream, A, hyd_nq(P));
+}
+
+static int hyd_layer(dsk_model* m, int l, int P, int max_kv) {
+  const dsk_config& c = m->c;
+  HydState& h = *m->hyd;
+  Layer& L = m->L[l];
+  hipStream_t st = m->ctx->stream;
+  const int dim = c.dim, qlr = c.q_lora_rank, kvl = c.kv_lora_rank, rope = c.qk_rope_head_dim, H = c.n_heads, hd = m->head_dim;
+  const int nv = c.qk_nope_head_dim + c.v_head_dim, vd = c.v_head_dim;
+  auto f32w = [](const DTensor& t) { return reinterpret_cast<const float*>(t.qs); };
+  // ---- attention half (src/infer.cpp:823-834, 934-1049) ----
+  DSK_TRY(launch_hyd_norm_q8(st, m->plans[m->lp_qkv_a[l]].NW, h.X, P, dim, f32w(L.t[DSK_ROLE_ATTN_NORM]), c.norm_eps, h.a_x.qs, h.a_x.d, h.a_x.bsums));
+  DSK_TRY(hyd_gemm(m, L.t[DSK_ROLE_WQ_A], nullptr, h.a_x, P, P, h.q_a, qlr, EPI_STORE));
+  DSK_TRY(hyd_gemm(m, L.t[DSK_ROLE_WKV_A], nullptr, h.a_x, P, P, h.kv_a, kvl + rope, EPI_STORE));
+  {
+    HydLatentArgs A;
+    memset(&A, 0, sizeof A);
+    A.q_a = h.q_a; A.kv_a = h.kv_a; A.q_norm = f32w(L.t[DSK_ROLE_Q_A_NORM]); A.kv_norm = f32w(L.t[DSK_ROLE_KV_A_NORM]);
+    A.q_stride = qlr; A.kv_stride = kvl + rope; A.nq = qlr; A.nkv = kvl; A.eps = c.norm_eps;
+    A.qq_qs = h.a_qa.qs; A.qq_d = h.a_qa.d; A.qq_bsums = h.a_qa.bsums;
+    A.kq_qs = h.a_kva.qs; A.kq_d = h.a_kva.d; A.kq_bsums = h.a_kva.bsums;
+    DSK_TRY(launch_hyd_latent_q8(st, A, P));
+  }
+  DSK_TRY(hyd_gemm(m, L.t[DSK_ROLE_WQ_B], nullptr, h.a_qa, P, P, h.q, H * hd, EPI_STORE));
+  DSK_TRY(hyd_gemm(m, L.t[DSK_ROLE_WKV_B], nullptr, h.a_kva, P, P, h.kv_b, H * nv, EPI_STORE));
+  const AttnMhaArgs& a = m->head_attn[l].a;
+  DSK_TRY(launch_hyd_kv_write(st, a, h.sp, P, h.kv_b, H * nv, h.kv_a, kvl + rope));
+  DSK_TRY(launch_hyd_attn(st, a, h.sp, P, max_kv, h.q, H * hd, h.att, H * vd));
+  DSK_TRY(launch_quantize_q8k(st, h.att, P * H * vd, h.a_att.qs, h.a_att.d, h.a_att.bsums));
+  DSK_TRY(hyd_gemm(m, L.t[DSK_ROLE_WO], nullptr, h.a_att, P, P, h.X, dim, EPI_ADD));
+  // ---- FFN half (src/infer.cpp:836-931) ----
+  if (!L.is_moe) {
+    DSK_TRY(launch_hyd_norm_q8(st, m->plans[m->lp_w13[l]].NW, h.X, P, dim, f32w(L.t[DSK_ROLE_FFN_NORM]), c.norm_eps, h.a_x.qs, h.a_x.d, h.a_x.bsums));
+    DSK_TRY(hyd_gemm(m, L.t[DSK_ROLE_W1], &L.t[DSK_ROLE_W3], h.a_x, P, P, h.hbd, c.hidden_dim, EPI_STORE));
+    DSK_TRY(launch_quantize_q8k(st, h.hbd, P * c.hidden_dim, h.a_hd.qs, h.a_hd.d, h.a_hd.bsums));
+    DSK_TRY(hyd_gemm(m, L.t[DSK_ROLE_W2], nullptr, h.a_hd, P, P, h.X, dim, EPI_ADD));
+    return DSK_OK;
+  }
+  const int K = c.n_active_routed, E = c.n_routed_experts, mi = c.moe_intermediate_size, shn = c.n_shared_experts * mi;
+  {
+    RouterArgs r;
+    memset(&r, 0, sizeof r);
+    r.w = f32w(L.t[DSK_ROLE_MOEGATE]);
+    r.x = h.X;
+    r.norm_w = f32w(L.t[DSK_ROLE_FFN_NORM]);
+    r.eps = c.norm_eps;
+    r.n_routed = E; r.dim = dim; r.ksplit = m->router_ksplit;
+    r.partial = h.router_partial; r.counter = h.router_counter;
+    r.bias = L.t[DSK_ROLE_MOEGATE_BIAS].bound() ? f32w(L.t[DSK_ROLE_MOEGATE_BIAS]) : nullptr;
+    r.n_active = K; r.norm_topk_prob = c.norm_topk_prob; r.scoring = c.scoring_func; r.topk_method = c.topk_method;
+    r.n_group = c.n_group; r.topk_group = c.topk_group; r.scaling = c.routed_scaling_factor;
+    r.active_experts = h.route_e; r.active_weights = h.route_w;
+    r.q_qs = h.a_x.qs; r.q_d = h.a_x.d; r.q_bsums = h.a_x.bsums;
+    DSK_TRY(launch_hyd_router(st, r, P));
+  }
+  DSK_TRY(launch_hyd_group(st, h.route_e, P * K, E, h.list, h.cap, h.count));
+  if (shn > 0) {
+    DSK_TRY(hyd_gemm(m, L.t[DSK_ROLE_SHARED_W1], &L.t[DSK_ROLE_SHARED_W3], h.a_x, P, P, h.hb_sh, shn, EPI_STORE));
+    DSK_TRY(launch_quantize_q8k(st, h.hb_sh, P * shn, h.a_hsh.qs, h.a_hsh.d, h.a_hsh.bsums));
+    DSK_TRY(hyd_gemm(m, L.t[DSK_ROLE_SHARED_W2], nullptr, h.a_hsh, P, P, h.eout_sh, dim, EPI_STORE));
+  }
+  const DTensor &w1 = L.t[DSK_ROLE_W1], &w2 = L.t[DSK_ROLE_W2], &w3 = L.t[DSK_ROLE_W3];
+  const int nq_e = hyd_nq((double)P * K / E * 1.5);
+  {
+    HydGemmArgs A;
+    memset(&A, 0, sizeof A);
+    A.W = w1.qs; A.W3 = w3.qs; A.e_bytes = w1.e_qs; A.n_experts = E; A.rows = mi; A.n = dim;
+    A.a_qs = h.a_x.qs; A.a_d = h.a_x.d; A.a_bsums = h.a_x.bsums; A.a_rows = P; A.a_div = K;
+    A.list = h.list; A.count = h.count; A.list_stride = h.cap;
+    A.out = h.hb; A.out_stride = mi; A.act = c.act;
+    DSK_TRY(launch_hyd_gemm(st, A, nq_e));
+  }
+  DSK_TRY(launch_quantize_q8k(st, h.hb, P * K * mi, h.a_hb.qs, h.a_hb.d, h.a_hb.bsums));
+  {
+    HydGemmArgs A;
+    memset(&A, 0, sizeof A);
+    A.W = w2.qs; A.e_bytes = w2.e_qs; A.n_experts = E; A.rows = dim; A.n = mi;
+    A.a_qs = h.a_hb.qs; A.a_d = h.a_hb.d; A.a_bsums = h.a_hb.bsums; A.a_rows = P * K; A.a_div = 1;
+    A.list = h.list; A.count = h.count; A.list_stride = h.cap;
+    A.out = h.eout; A.out_stride = dim; A.epilogue = EPI_STORE; A.act = c.act;
+    DSK_TRY(launch_hyd_gemm(st, A, nq_e));
+  }
+  DSK_TRY(launch_hyd_combine(st, h.X, h.eout, h.route_w, shn > 0 ? h.eout_sh : nullptr, P, K, dim));
+  return DSK_OK;
+}
+
+// one chunk of P tokens at positions pos0 .. pos0 + P - 1 through every block (no ring wrap inside: the caller checked)
+static int hyd_chunk(dsk_model* m, const int32_t* tokens, int P, int pos0) {
+  const dsk_config& c = m->c;
+  HydState& h = *m->hyd;
+  hipStream_t st = m->ctx->stream;
+  for (int p = 0; p < P; ++p) DSK_TRY(fill_step_params_at(m, tokens[p], pos0 + p, h.sp_host + p));
+  HIP_TRY(hipMemcpyAsync(h.sp, h.sp_host, (size_t)P * sizeof(StepParams), hipMemcpyHostToDevice, st));
+  for (int p = 0; p < P; ++p)  // Model::_copy_embedding, src/infer.cpp:1217-1263
+    DSK_TRY(launch_embed(st, m->g[DSK_ROLE_EMBED], nullptr, tokens[p], std::max(1, c.block_size[0]), std::max(1, c.block_size[1]), h.X + (size_t)p * c.dim));
+  const int max_kv = pos0 + P;
+  for (int l = 0; l < c.n_layers; ++l) {
+    DSK_TRY(hyd_layer(m, l, P, max_kv));
+    if (h.trace) HIP_TRY(hipMemcpyAsync(h.trace + (size_t)l * h.cap * c.dim, h.X, (size_t)P * c.dim * 4, hipMemcpyDeviceToDevice, st));
+    if (m->hydrate_stop_layer > 0 && l + 1 >= m->hydrate_stop_layer) break;  // debug: leave this block's intermediates in the buffers
+  }
+  return DSK_OK;
+}
+
+extern "C" int dsk_hydrate(dsk_model* m, const int32_t* tokens, int n_tokens, int pos0, int mode, float* host_logits) {
+  if (!m || !tokens) DSK_FAIL(DSK_ERR_INVALID, "hydrate: null argument");
+  if (!m->finalized) DSK_FAIL(DSK_ERR_STATE, "hydrate before finalize");
+  if (n_tokens < 1 || pos0 < 0) DSK_FAIL(DSK_ERR_INVALID, "hydrate: %d tokens at pos %d", n_tokens, pos0);
+  if (mode != DSK_MODE_HYDRATE_KV_CACHE && mode != DSK_MODE_OUTPUT_LOGITS) DSK_FAIL(DSK_ERR_INVALID, "hydrate: bad mode %d", mode);
+  if (mode == DSK_MODE_OUTPUT_LOGITS && !host_logits) DSK_FAIL(DSK_ERR_INVALID, "hydrate: OUTPUT_LOGITS needs a logits buffer");
+  for (int i = 0; i < n_tokens; ++i)
+    if (tokens[i] < 0 || tokens[i] >= m->c.vocab_size) DSK_FAIL(DSK_ERR_INVALID, "hydrate: token %d out of range", tokens[i]);
+  HIP_TRY(hipSetDevice(m->ctx->device));
+  hipStream_t st = m->ctx->stream;
+  int done = 0;
+  bool last_batched = false;
+  const char* why = m->hydrate_batched ? hyd_why_not(m) : "option hydrate_batched is off";
+  m->hydrate_why = why;
+  if (!why) {
+    DSK_TRY(hyd_ensure(m));
+    // positions before the ring wraps (src/infer.cpp:1271-1277: from pos >= W on the sink keys are rotated in place, token by token)
+    const int limit = std::min(m->c.max_seq_len, std::max(1, m->c.rs_original_max_position_embeddings));
+    int last_P = 0;
+    while (done < n_tokens) {
+      const int P = std::min(std::min(m->hyd->cap, n_tokens - done), limit - (pos0 + done));
+      if (P < 1) break;
+      DSK_TRY(hyd_chunk(m, tokens + done, P, pos0 + done));
+      done += P;
+      last_P = P;
+      m->hydrate_batched_tokens += P;
+      last_batched = done == n_tokens;
+    }
+    if (last_batched && mode == DSK_MODE_OUTPUT_LOGITS) {  // final norm + classifier of the last token only (src/infer.cpp:1292-1316)
+      HIP_TRY(hipMemcpyAsync(m->x, m->hyd->X + (size_t)(last_P - 1) * m->c.dim, (size_t)m->c.dim * 4, hipMemcpyDeviceToDevice, st));
+      DSK_TRY(forward_head(m));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    if (last_batched && mode == DSK_MODE_OUTPUT_LOGITS && host_logits != m->logits_host) memcpy(host_logits, m->logits_host, (size_t)m->c.vocab_size * 4);
+  }
+  for (int i = done; i < n_tokens; ++i) {  // the definition itself: what the batched path must equal
+    const bool last = i == n_tokens - 1;
+    DSK_TRY(dsk_forward(m, tokens[i], pos0 + i, last ? mode : DSK_MODE_HYDRATE_KV_CACHE, last ? host_logits : nullptr));
+    m->hydrate_looped_tokens++;
+  }
+  return DSK_OK;
+}
+
+// the residual stream of token `index` of the LAST batched chunk after block `layer` (dsk_model_set_trace(1) before the first
+// dsk_hydrate call): the batched counterpart of dsk_model_get_trace_x
+extern "C" int dsk_hydrate_get_trace_x(dsk_model* m, int layer, int index, float* x_out) {
+  if (!m || !m->hyd || !m->hyd->trace || !x_out) DSK_FAIL(DSK_ERR_STATE, "hydrate_get_trace_x: no batched trace (dsk_model_set_trace(1) before the first dsk_hydrate)");
+  if (layer < 0 || layer >= m->c.n_layers || index < 0 || index >= m->hyd->cap) DSK_FAIL(DSK_ERR_INVALID, "hydrate_get_trace_x: layer %d index %d", layer, index);
+  HIP_TRY(hipSetDevice(m->ctx->device));
+  HIP_TRY(hipMemcpy(x_out, m->hyd->trace + ((size_t)layer * m->hyd->cap + index) * m->c.dim, (size_t)m->c.dim * 4, hipMemcpyDeviceToHost));
+  return DSK_OK;
+}
+
+extern "C" const char* dsk_hydrate_why_not(dsk_model* m) {
+  if (!m || !m->finalized) return "model not finalized";
+  const char* why = m->hydrate_batched ? hyd_why_not(m) : "option hydrate_batched is off";
+  return why ? why : "";
+}
+
+// Parity harness / debugging: one of the batched path's intermediate buffers as the last chunk left it (rows = tokens, or
+// (token, slot) pairs for "hb" / "eout").  With option "hydrate_stop_layer" = l + 1 the chunk stops after block l, so the
+// buffers hold THAT block's intermediates.
+extern "C" int dsk_hydrate_get_buffer(dsk_model* m, const char* name, void* out, size_t bytes) {
+  if (!m || !m->hyd || !name || !out) DSK_FAIL(DSK_ERR_STATE, "hydrate_get_buffer: no batched chunk has run");
+  const dsk_config& c = m->c;
+  const HydState& h = *m->hyd;
+  const size_t P = h.cap, K = std::max(1, c.n_active_routed), H = c.n_heads;
+  const std::string s(name);
+  const void* src = nullptr;
+  size_t avail = 0;
+  auto f32 = [&](const float* p, size_t n) { src = p; avail = n * 4; };
+  if (s == "x") f32(h.X, P * c.dim);
+  else if (s == "q_a") f32(h.q_a, P * c.q_lora_rank);
+  else if (s == "kv_a") f32(h.kv_a, P * (c.kv_lora_rank + c.qk_rope_head_dim));
+  else if (s == "q") f32(h.q, P * H * m->head_dim);
+  else if (s == "kv_b") f32(h.kv_b, P * H * (c.qk_nope_head_dim + c.v_head_dim));
+  else if (s == "att") f32(h.att, P * H * c.v_head_dim);
+  else if (s == "hbd") f32(h.hbd, P * c.hidden_dim);
+  else if (s == "hb") f32(h.hb, P * K * std::max(256, c.moe_intermediate_size));
+  else if (s == "hb_sh") f32(h.hb_sh, P * std::max(256, c.n_shared_experts * c.moe_intermediate_size));
+  else if (s == "eout") f32(h.eout, P * K * c.dim);
+  else if (s == "eout_sh") f32(h.eout_sh, P * c.dim);
+  else if (s == "route_w") f32(h.route_w, P * K);
+  else if (s == "route_e") { src = h.route_e; avail = P * K * 4; }
+  else if (s == "q8.x.qs") { src = h.a_x.qs; avail = P * c.dim; }
+  else if (s == "q8.x.d") { src = h.a_x.d; avail = P * (c.dim / 256) * 4; }
+  else if (s == "q8.qa.qs") { src = h.a_qa.qs; avail = P * c.q_lora_rank; }
+  else if (s == "q8.kva.qs") { src = h.a_kva.qs; avail = P * c.kv_lora_rank; }
+  else if (s == "q8.att.qs") { src = h.a_att.qs; avail = P * H * c.v_head_dim; }
+  else DSK_FAIL(DSK_ERR_INVALID, "hydrate_get_buffer: unknown buffer '%s'", name);
+  if (bytes > avail) DSK_FAIL(DSK_ERR_INVALID, "hydrate_get_buffer: '%s' holds %zu bytes, %zu requested", name, avail, bytes);
+  HIP_TRY(hipSetDevice(m->ctx->device));
+  HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+  HIP_TRY(hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
+  return DSK_OK;
+}

@@ -1,0 +1,432 @@
+// kernels_hydrate.hip -- batched prompt ingestion ("hydrate"): P prompt tokens through one block with every
+// weight matrix read ONCE, instead of the reference's one forward per prompt token (src/main.cpp:312-319 calling
+// Model::forward(.., HYDRATE_KV_CACHE), src/infer.cpp:1284-1287).
+//
+// The contract is BIT-IDENTITY with P single-token dsk_forward calls on a model whose Q2_K matrices are tile records
+// (option "q2k_tiles" 2): same KV-cache rows, same residual stream, same routing, same logits.  That works because
+//   * the tiled decode kernels define a row's value by an association that does not depend on the launch geometry
+//     (tile_device.h: (S0 + S1) + (S2 + S3), S_g = the in-order sum of the item partials fma-chained over the item's blocks),
+//     and the GEMM below produces exactly those partials for every (token, row);
+//   * Q8_K quantisation is exact arithmetic (IEEE divide / multiply / rint), so any kernel quantising the same floats gives the
+//     same codes;
+//   * every other float stage (rmsnorm trees, router GEMV, gate, rope, attention, GLU, combine) runs the decode path's own
+//     device functions with the decode path's workgroup sizes, once per token.
+//
+// The GEMM (hyd_gemm_kernel) is a real i8 GEMM on v_mfma_i32_16x16x64_i8, not the decode kernels' selector trick: a lane
+// expands its 16 weight bytes to SCALED int8 weights - (q2 & mask) * scale <= 45, a packed 16-bit multiply of four masked
+// codes by one scale cannot carry between bytes - so the matrix instruction returns the reference's
+// sum_j scale_j * sum_l q8 * q2 directly.  To keep the decode association the sums are kept per sub-block GROUP g4 (sub-blocks
+// 4 g4 .. 4 g4 + 3: what one lane of the decode kernel holds): the 16 rows of the activation operand are 4 tokens x 4 groups,
+// row (t, g4) holding token t's codes in the K positions of group g4 and zeros elsewhere.  D[(t, g4)][n] is then the exact
+// integer the decode lane converts to float, and lane (n, t) of the result holds all four groups of ITS (token, row):
+// the float stage - dx * d, the min term, the per-item partials, the final (S0 + S1) + (S2 + S3) - is lane-local.
+#include "dsk_internal.h"
+#include "tile_device.h"
+#include <algorithm>
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+#define HYD_OOB 0x40000000  // a buffer offset beyond any activation array (all far below 1 GiB): the load returns zeros and touches no memory
+
+DEV rsrc_t make_rsrc_n(const void* p, u32 bytes) {
+  const unsigned long long v = (unsigned long long)p;
+  const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, (int)bytes, 0x00020000);
+}
+DEV u32 pkmul16(u32 a, u32 b) {  // two independent 16-bit products (v_pk_mul_lo_u16)
+  const u16x2 r = __builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, b);
+  return __builtin_bit_cast(u32, r);
+}
+
+struct HydTile { u32x4 w; u32 sc[4]; u32 dm; };
+DEV void hyd_tile_load(HydTile& T, rsrc_t W, int lane, int soff) {
+  const int n = lane & 15;
+  T.w = __builtin_amdgcn_raw_buffer_load_b128(W, lane * 16, soff, BUF_NT);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) T.sc[g] = __builtin_amdgcn_raw_buffer_load_b32(W, 1024 + 4 * (n + 16 * g), soff, BUF_NT);
+  T.dm = __builtin_amdgcn_raw_buffer_load_b32(W, 1280 + 4 * n, soff, BUF_NT);
+}
+// the four B operands of a tile: field s of the lane's 16 bytes (row n = lane & 15, K-group kg = lane >> 4) times the 4-bit scale
+// of its sub-block j(kg, s) = 8 (kg >> 1) + 2 s + (kg & 1) = scale byte (2 (s & 1) + (kg & 1)) of word 2 (kg >> 1) + (s >> 1)
+DEV void hyd_expand(const HydTile& T, int kg, i32x4 (&B)[4]) {
+  const u32 wlo = (kg & 2) ? T.sc[2] : T.sc[0], whi = (kg & 2) ? T.sc[3] : T.sc[1];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const u32 word = (s >> 1) ? whi : wlo;
+    const u32 sc = (word >> (8 * (2 * (s & 1) + (kg & 1)))) & 0xFu;
+    const u32 pair = sc | (sc << 16);
+    B[s].x = (int)pkmul16((T.w.x >> (2 * s)) & 0x03030303u, pair);
+    B[s].y = (int)pkmul16((T.w.y >> (2 * s)) & 0x03030303u, pair);
+    B[s].z = (int)pkmul16((T.w.z >> (2 * s)) & 0x03030303u, pair);
+    B[s].w = (int)pkmul16((T.w.w >> (2 * s)) & 0x03030303u, pair);
+  }
+}
+
+// float state of one (token, row) per matrix: the running item chains and the four group sums
+struct HydAcc {
+  float S[4], ad[4], am[4];
+};
+DEV void hyd_acc_zero(HydAcc& a) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) a.S[g] = a.ad[g] = a.am[g] = 0.f;
+}
+// one block of one tile for one token quad: D = the four exact group sums of this lane's (token, row)
+DEV void hyd_block(const HydTile& T, const i32x4 (&B)[4], const u32 (&m4)[4], const i32x4 (&a)[4], const u32x4& bs0, const u32x4& bs1, float dx, HydAcc& acc) {
+  i32x4 D = {0, 0, 0, 0};
+  D = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[0], B[0], D, 0, 0, 0);
+  D = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[1], B[1], D, 0, 0, 0);
+  D = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[2], B[2], D, 0, 0, 0);
+  D = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[3], B[3], D, 0, 0, 0);
+  const u32 bw[8] = {bs0.x, bs0.y, bs0.z, bs0.w, bs1.x, bs1.y, bs1.z, bs1.w};  // 16 int16 sub-block sums of the token
+  const int Dg[4] = {D.x, D.y, D.z, D.w};
+  const float dd = dx * h2f(T.dm & 0xffff), dmn = dx * h2f(T.dm >> 16);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const u32 hi = __builtin_amdgcn_perm(bw[2 * g + 1], bw[2 * g], 0x07050301u);  // the sums' high bytes (signed)
+    const u32 lo = __builtin_amdgcn_perm(bw[2 * g + 1], bw[2 * g], 0x06040200u);  // low bytes (unsigned)
+    const int summs = (sdot4(m4[g], hi, 0) << 8) + (int)__builtin_amdgcn_udot4(m4[g], lo, 0u, false);
+    acc.ad[g] = fmaf(dd, (float)Dg[g], acc.ad[g]);     // tile_device.h tstep_mac, without the in-place mask factors ...
+    acc.am[g] = fmaf(dmn, (float)summs, acc.am[g]);
+  }
+}
+DEV void hyd_item_end(HydAcc& acc) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    acc.S[g] += acc.ad[g] - acc.am[g];  // ... which titem_value undoes exactly: fma(4^k accd, 4^-k, -accm) == accd - accm, one rounding
+    acc.ad[g] = acc.am[g] = 0.f;
+  }
+}
+DEV float hyd_value(const HydAcc& acc) { return (acc.S[0] + acc.S[1]) + (acc.S[2] + acc.S[3]); }  // tile_strip_value
+
+// One wave = one 16-row strip (GLU: the same strip of w1 and w3) of one task (a plain matrix, or expert `task` of a stack) times
+// the task's activation rows, 4 * NQ tokens per pass over the strip's tiles.
+template <bool GLU, int NQ>
+__global__ __launch_bounds__(256) void hyd_gemm_kernel(const HydGemmArgs A) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int strips = (A.rows + 15) >> 4;
+  const int ntask = A.n_experts > 0 ? A.n_experts : 1;
+  const long long unit = (long long)blockIdx.x * 4 + wave;
+  if (unit >= (long long)ntask * strips) return;
+  const int task = (int)(unit / strips), strip = (int)(unit - (long long)task * strips);
+  const int cnt = A.count ? __builtin_amdgcn_readfirstlane(A.count[task]) : A.m;
+  if (cnt <= 0) return;
+  const int* list = A.list ? A.list + (size_t)task * A.list_stride : nullptr;
+  const int n = A.n, nb = n >> 8;
+  const bool seg4 = nb > 8;  // tile_seg
+  const size_t woff = (size_t)task * A.e_bytes + (size_t)strip * nb * TILE_B;
+  const rsrc_t W1 = make_rsrc(A.W + woff);
+  const rsrc_t W3 = make_rsrc(GLU ? A.W3 + woff : A.W + woff);
+  const rsrc_t RA = make_rsrc_n(A.a_qs, (u32)((size_t)A.a_rows * n));
+  const rsrc_t RB = make_rsrc_n(A.a_bsums, (u32)((size_t)A.a_rows * (n >> 4) * 2));
+  const rsrc_t RD = make_rsrc_n(A.a_d, (u32)((size_t)A.a_rows * nb * 4));
+  // activation operand: this lane is row (tl, g4l) of K-group kg; it holds data for fields 2c, 2c + 1 (c = g4l & 1) when its
+  // group's K half is its own
+  const int kg = lane >> 4, tl = (lane & 15) >> 2, g4l = lane & 3, c = g4l & 1;
+  const bool lane_ok = (g4l >> 1) == (kg >> 1);
+  const int jbase = 16 * (8 * (kg >> 1) + (kg & 1));  // byte offset of sub-block j(kg, 0) in a block's codes
+  const int qd = lane >> 4, rown = lane & 15;         // result side: token qd of the quad, row rown of the strip
+  for (int base = 0; base < cnt; base += 4 * NQ) {
+    int off0[NQ], off1[NQ], boff[NQ], doff[NQ], outv[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int eA = base + 4 * q + tl;
+      const bool okA = eA < cnt && lane_ok;
+      const int vA = eA < cnt ? (list ? list[eA] : eA) : 0;
+      const int arow = vA / A.a_div;
+      const int ab = arow * n + jbase;
+      off0[q] = okA && c == 0 ? ab : HYD_OOB;        // fields 0, 1 (+ 32 bytes)
+      off1[q] = okA && c == 1 ? ab + 64 : HYD_OOB;   // fields 2, 3
+      const int eD = base + 4 * q + qd;
+      const bool okD = eD < cnt;
+      const int vD = okD ? (list ? list[eD] : eD) : 0;
+      const int arowD = vD / A.a_div;
+      boff[q] = okD ? arowD * (n >> 4) * 2 : HYD_OOB;
+      doff[q] = okD ? arowD * nb * 4 : HYD_OOB;
+      outv[q] = okD ? vD : -1;
+    }
+    HydAcc acc1[NQ], acc3[GLU ? NQ : 1];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { hyd_acc_zero(acc1[q]); if (GLU) hyd_acc_zero(acc3[q]); }
+    HydTile T1, T3;
+    hyd_tile_load(T1, W1, lane, 0);
+    if (GLU) hyd_tile_load(T3, W3, lane, 0);
+    for (int b = 0; b < nb; ++b) {
+      HydTile N1, N3;
+      if (b + 1 < nb) {  // the next tile travels while this one is multiplied
+        hyd_tile_load(N1, W1, lane, (b + 1) * TILE_B);
+        if (GLU) hyd_tile_load(N3, W3, lane, (b + 1) * TILE_B);
+      }
+      i32x4 B1[4], B3[4];
+      u32 m1[4], m3[4];
+      hyd_expand(T1, kg, B1);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) m1[g] = (T1.sc[g] >> 4) & 0x0F0F0F0Fu;
+      if (GLU) {
+        hyd_expand(T3, kg, B3);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) m3[g] = (T3.sc[g] >> 4) & 0x0F0F0F0Fu;
+      }
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        if (base + 4 * q < cnt) {  // wave-uniform
+          i32x4 a[4];
+          a[0] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(RA, off0[q], b * 256, 0));
+          a[1] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(RA, off0[q] + 32, b * 256, 0));
+          a[2] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(RA, off1[q], b * 256, 0));
+          a[3] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(RA, off1[q] + 32, b * 256, 0));
+          const u32x4 bs0 = __builtin_amdgcn_raw_buffer_load_b128(RB, boff[q], b * 32, 0);
+          const u32x4 bs1 = __builtin_amdgcn_raw_buffer_load_b128(RB, boff[q] + 16, b * 32, 0);
+          const float dx = u2f(__builtin_amdgcn_raw_buffer_load_b32(RD, doff[q], b * 4, 0));
+          hyd_block(T1, B1, m1, a, bs0, bs1, dx, acc1[q]);
+          if (GLU) hyd_block(T3, B3, m3, a, bs0, bs1, dx, acc3[q]);
+          if (!seg4 || (b & 3) == 3 || b == nb - 1) {  // the item ends here (tile_device.h: 4 blocks, or 1 for rows of <= 8)
+            hyd_item_end(acc1[q]);
+            if (GLU) hyd_item_end(acc3[q]);
+          }
+        }
+      }
+      if (b + 1 < nb) {
+        T1 = N1;
+        if (GLU) T3 = N3;
+      }
+    }
+    const int row = strip * 16 + rown;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      if (outv[q] >= 0 && row < A.rows) {
+        float* o = A.out + (size_t)outv[q] * A.out_stride + row;
+        const float v = hyd_value(acc1[q]);
+        if (GLU) *o = act_fn(v, A.act) * hyd_value(acc3[q]);   // src/infer.cpp:859-872
+        else if (A.epilogue == EPI_ADD) *o += v;                // src/infer.cpp:832-834, 928-930
+        else *o = v;
+      }
+    }
+  }
+}
+
+template <bool GLU, int NQ>
+static void hyd_gemm_launch(hipStream_t st, const HydGemmArgs& A) {
+  const long long units = (long long)(A.n_experts > 0 ? A.n_experts : 1) * ((A.rows + 15) >> 4);
+  hipLaunchKernelGGL((hyd_gemm_kernel<GLU, NQ>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st, A);
+}
+int launch_hyd_gemm(hipStream_t st, const HydGemmArgs& A, int nq) {
+  if (A.n % 256 || A.rows < 1 || A.a_rows < 1 || A.a_div < 1) DSK_FAIL(DSK_ERR_INVALID, "hyd_gemm: bad shape");
+  if ((size_t)A.a_rows * A.n >= (size_t)HYD_OOB) DSK_FAIL(DSK_ERR_UNSUPPORTED, "hyd_gemm: activation array too large for 31-bit offsets");
+  const bool glu = A.W3 != nullptr;
+  if (nq >= 4) { if (glu) hyd_gemm_launch<true, 4>(st, A); else hyd_gemm_launch<false, 4>(st, A); }
+  else if (nq >= 2) { if (glu) hyd_gemm_launch<true, 2>(st, A); else hyd_gemm_launch<false, 2>(st, A); }
+  else { if (glu) hyd_gemm_launch<true, 1>(st, A); else hyd_gemm_launch<false, 1>(st, A); }
+  return DSK_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// rmsnorm + Q8_K of P rows (src/infer.cpp:601-611, quant.cpp:616-653) with the staging routine - and therefore the
+// sum-of-squares tree - of the decode launch that consumes the vector (gemv_device.h stage_q8 at the launch's NW)
+// ------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void hyd_norm_q8_kernel(const float* __restrict__ X, int n, const float* __restrict__ norm_w, float eps,
+                                                                int8_t* __restrict__ qs, float* __restrict__ d, int16_t* __restrict__ bsums) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ float scratch[16];
+  const int p = blockIdx.x, tid = threadIdx.x;
+  ActSrc S;
+  S.act_mode = ACT_F32_NORM; S.n = n; S.eps = eps; S.pre_scale = 0.f;
+  S.a_f32 = X + (size_t)p * n; S.norm_w = norm_w;
+  S.a_qs = nullptr; S.a_d = nullptr; S.a_bsums = nullptr;
+  stage_q8<LAY_TILE, NW>(S, smem, tid, scratch);
+  __syncthreads();
+  dump_staged_q8<LAY_TILE>(smem, n, qs + (size_t)p * n, d + (size_t)p * (n >> 8), tid, NW * 64);
+  for (int i = tid; i < (n >> 4); i += NW * 64) {
+    const int b = i >> 4, j = i & 15;
+    const uint8_t* rec = smem + (size_t)b * TREC;
+    const int hi = (int8_t)rec[TREC_BS + 8 * (j >> 2) + (j & 3)], lo = rec[TREC_BS + 4 + 8 * (j >> 2) + (j & 3)];
+    bsums[(size_t)p * (n >> 4) + i] = (int16_t)((hi << 8) | lo);
+  }
+}
+int launch_hyd_norm_q8(hipStream_t st, int NW, const float* X, int P, int n, const float* norm_w, float eps, int8_t* qs, float* d, int16_t* bsums) {
+  const size_t lds = (size_t)(n >> 8) * TREC;
+  if (n % 256 || lds > 150 * 1024) DSK_FAIL(DSK_ERR_UNSUPPORTED, "hyd_norm_q8: n=%d", n);
+#define HN(NWV)                                                                                                         \
+  do {                                                                                                                  \
+    auto k = hyd_norm_q8_kernel<NWV>;                                                                                   \
+    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+    hipLaunchKernelGGL(k, dim3(P), dim3(NWV * 64), lds, st, X, n, norm_w, eps, qs, d, bsums);                           \
+  } while (0)
+  if (NW == 16) HN(16);
+  else if (NW == 8) HN(8);
+  else if (NW == 4) HN(4);
+  else DSK_FAIL(DSK_ERR_UNSUPPORTED, "hyd_norm_q8: %d waves", NW);
+#undef HN
+  return DSK_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// the two latents of the MHA path, normed and quantised as head_attn_kernel does it (kernels_gemv.hip latent_finish: wave w
+// owns block w of q_a || kv_a[:lora], the sums of squares meet in LDS in block order), once per token instead of once per head
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void hyd_latent_q8_kernel(const HydLatentArgs A) {
+  __shared__ float scratch[16];
+  const int p = blockIdx.x, tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int nbq = A.nq >> 8, nbkv = A.nkv >> 8;
+  const bool mine = wave < nbq + nbkv, is_q = wave < nbq;
+  const int b = mine ? (is_q ? wave : wave - nbq) : 0;
+  const float* src = is_q ? A.q_a + (size_t)p * A.q_stride : A.kv_a + (size_t)p * A.kv_stride;
+  const float* nw = is_q ? A.q_norm : A.kv_norm;
+  const f32x4 t = *reinterpret_cast<const f32x4*>(src + b * 256 + lane * 4);
+  const f32x4 wv = *reinterpret_cast<const f32x4*>(nw + b * 256 + lane * 4);
+  float ss = fmaf(t.x, t.x, fmaf(t.y, t.y, fmaf(t.z, t.z, t.w * t.w)));
+  ss = wave_sum(ss);
+  if (lane == 0) scratch[wave] = mine ? ss : 0.f;
+  __syncthreads();
+  float total = 0.f;
+  if (is_q) for (int i = 0; i < nbq; ++i) total += scratch[i];
+  else for (int i = nbq; i < nbq + nbkv; ++i) total += scratch[i];
+  if (!mine) return;
+  const int nn = is_q ? A.nq : A.nkv;
+  const float scale = 1.0f / sqrtf(total / (float)nn + A.eps);
+  const float v[4] = {t.x * scale * wv.x, t.y * scale * wv.y, t.z * scale * wv.z, t.w * scale * wv.w};
+  if (is_q) ad::q8k_block(v, lane, A.qq_qs + (size_t)p * A.nq + b * 256, A.qq_d + (size_t)p * nbq + b, A.qq_bsums + (size_t)p * (A.nq >> 4) + b * 16);
+  else ad::q8k_block(v, lane, A.kq_qs + (size_t)p * A.nkv + b * 256, A.kq_d + (size_t)p * nbkv + b, A.kq_bsums + (size_t)p * (A.nkv >> 4) + b * 16);
+}
+int launch_hyd_latent_q8(hipStream_t st, const HydLatentArgs& A, int P) {
+  if (A.nq % 256 || A.nkv % 256 || (A.nq >> 8) + (A.nkv >> 8) > 16) DSK_FAIL(DSK_ERR_UNSUPPORTED, "hyd_latent_q8: latents of %d + %d", A.nq, A.nkv);
+  hipLaunchKernelGGL(hyd_latent_q8_kernel, dim3(P), dim3(1024), 0, st, A);
+  return DSK_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// MHA: this position's key / value rows of every head (src/infer.cpp:978-1006; attn_device.h rope_kv_from_lds without the
+// query).  All P rows are in the cache before any token's attention reads them.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hyd_kv_write_kernel(const AttnMhaArgs a, const StepParams* __restrict__ sps, const float* __restrict__ kv_b,
+                                                           int kvb_stride, const float* __restrict__ kv_a, int kva_stride) {
+  const int h = blockIdx.x, p = blockIdx.y, tid = threadIdx.x;
+  const StepParams* sp = sps + p;
+  const int hd = a.head_dim, nope = a.nope, rope = a.rope, vd = a.v_dim;
+  const int kv_pos = sp->kv_pos;
+  const float* kvb = kv_b + (size_t)p * kvb_stride + (size_t)h * (nope + vd);
+  uint16_t* kc = a.key_cache + ((size_t)kv_pos * a.n_heads + h) * hd;
+  uint16_t* vc = a.value_cache + ((size_t)kv_pos * a.n_heads + h) * vd;
+  for (int i = tid; i < nope; i += 256) kc[i] = ad::f2h(kvb[i]);
+  for (int i = tid; i < vd; i += 256) vc[i] = ad::f2h(kvb[nope + i]);
+  if (tid < rope / 2) {
+    const float* kr = kv_a + (size_t)p * kva_stride + a.lora;
+    const float v0 = kr[2 * tid], v1 = kr[2 * tid + 1];
+    const float c = sp->rope_cs[2 * tid], s = sp->rope_cs[2 * tid + 1];
+    float re, im;
+    ad::rope_rot(v0, v1, c, s, re, im);
+    if (a.is_v3) {
+      kc[nope + 2 * tid] = ad::f2h(re);
+      kc[nope + 2 * tid + 1] = ad::f2h(im);
+    } else {
+      kc[nope + tid] = ad::f2h(re);
+      kc[nope + tid + rope / 2] = ad::f2h(im);
+    }
+  }
+}
+// MHA: rope of the query + attention over positions [0, kv_len) of the cache, per (head, token): head_attn_kernel's second half
+// (same attn_mha_body<1024>: same score / softmax / value-mix trees)
+__global__ __launch_bounds__(1024) void hyd_attn_kernel(const AttnMhaArgs a, const StepParams* __restrict__ sps, const float* __restrict__ q, int q_stride,
+                                                        float* __restrict__ out, int out_stride) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ float scratch[16];
+  __shared__ __attribute__((aligned(16))) float q_s[256];
+  __shared__ __attribute__((aligned(16))) float part[4096];
+  const int h = blockIdx.x, p = blockIdx.y, tid = threadIdx.x;
+  const StepParams* sp = sps + p;
+  float* att = reinterpret_cast<float*>(smem);
+  const int hd = a.head_dim, nope = a.nope, rope = a.rope, vd = a.v_dim;
+  for (int i = tid; i < hd; i += 1024) q_s[i] = q[(size_t)p * q_stride + (size_t)h * hd + i];
+  __syncthreads();
+  float qre = 0.f, qim = 0.f;
+  if (tid < rope / 2) {  // rope_kv_from_lds, the query part
+    const float v0 = q_s[nope + 2 * tid], v1 = q_s[nope + 2 * tid + 1];
+    const float c = sp->rope_cs[2 * tid], s = sp->rope_cs[2 * tid + 1];
+    ad::rope_rot(v0, v1, c, s, qre, qim);
+  }
+  __syncthreads();
+  if (tid < rope / 2) {
+    if (a.is_v3) {
+      q_s[nope + 2 * tid] = qre;
+      q_s[nope + 2 * tid + 1] = qim;
+    } else {
+      q_s[nope + tid] = qre;
+      q_s[nope + tid + rope / 2] = qim;
+    }
+  }
+  __syncthreads();
+  const float o = ad::attn_mha_body<1024>(a, q_s, 0, sp->kv_len, h, tid, att, scratch, part);
+  if (tid < vd) out[(size_t)p * out_stride + (size_t)h * vd + tid] = o;
+}
+int launch_hyd_kv_write(hipStream_t st, const AttnMhaArgs& a, const StepParams* sps, int P, const float* kv_b, int kvb_stride, const float* kv_a, int kva_stride) {
+  hipLaunchKernelGGL(hyd_kv_write_kernel, dim3(a.n_heads, P), dim3(256), 0, st, a, sps, kv_b, kvb_stride, kv_a, kva_stride);
+  return DSK_OK;
+}
+int launch_hyd_attn(hipStream_t st, const AttnMhaArgs& a, const StepParams* sps, int P, int max_kv, const float* q, int q_stride, float* out, int out_stride) {
+  const size_t lds = (size_t)max_kv * 4;
+  if (lds > 96 * 1024) DSK_FAIL(DSK_ERR_UNSUPPORTED, "hyd_attn: kv_len %d does not fit LDS", max_kv);
+  if (a.head_dim > 256 || a.v_dim > 256) DSK_FAIL(DSK_ERR_UNSUPPORTED, "hyd_attn: head_dim %d / v_head_dim %d", a.head_dim, a.v_dim);
+  auto k = hyd_attn_kernel;
+  if (lds > 32 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k, dim3(a.n_heads, P), dim3(1024), lds, st, a, sps, q, q_stride, out, out_stride);
+  return DSK_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// router + gate of P tokens: the decode launch's router_body (router_device.h), one grid row per token.  It also leaves the
+// Q8_K copy of rmsnorm(x, ffn_norm) behind, quantised with the router's own norm scale - what the experts AND the shared
+// expert's rider consume in the decode path.
+// ------------------------------------------------------------------------------------
+template <int RW>
+__global__ __launch_bounds__(1024) void hyd_router_kernel(const RouterArgs a0, int K) {
+  RouterArgs a = a0;
+  const int p = blockIdx.y;
+  const int dim = a.dim, E = a.n_routed;
+  a.x += (size_t)p * dim;
+  a.partial += (size_t)p * E;
+  a.counter += p;
+  a.active_experts += (size_t)p * K;
+  a.active_weights += (size_t)p * K;
+  if (a.scores_out) a.scores_out += (size_t)p * E;
+  if (a.q_qs) { a.q_qs += (size_t)p * dim; a.q_d += (size_t)p * (dim >> 8); a.q_bsums += (size_t)p * (dim >> 4); }
+  rd::router_body<RW>(a, (int)blockIdx.x, (int)gridDim.x);
+}
+int launch_hyd_router(hipStream_t st, const RouterArgs& a, int P) {
+  if (a.ksplit >= 8) hipLaunchKernelGGL(hyd_router_kernel<2>, dim3((a.n_routed + 1) / 2, P), dim3(1024), 0, st, a, a.n_active);
+  else hipLaunchKernelGGL(hyd_router_kernel<4>, dim3((a.n_routed + 3) / 4, P), dim3(1024), 0, st, a, a.n_active);
+  return DSK_OK;
+}
+
+// tokens grouped by expert: list[e] = the (token, slot) pairs p * K + k routed to expert e, in pair order; count[e]
+__global__ __launch_bounds__(256) void hyd_group_kernel(const int* __restrict__ route_e, int pairs, int E, int* __restrict__ list, int list_stride,
+                                                        int* __restrict__ count) {
+  extern __shared__ int r_s[];
+  for (int i = threadIdx.x; i < pairs; i += 256) r_s[i] = route_e[i];
+  __syncthreads();
+  for (int e = threadIdx.x; e < E; e += 256) {
+    int c = 0;
+    for (int i = 0; i < pairs; ++i)
+      if (r_s[i] == e) list[(size_t)e * list_stride + c++] = i;
+    count[e] = c;
+  }
+}
+int launch_hyd_group(hipStream_t st, const int* route_e, int pairs, int E, int* list, int list_stride, int* count) {
+  if ((size_t)pairs * 4 > 60 * 1024) DSK_FAIL(DSK_ERR_UNSUPPORTED, "hyd_group: %d (token, slot) pairs", pairs);
+  hipLaunchKernelGGL(hyd_group_kernel, dim3(1), dim3(256), (size_t)pairs * 4, st, route_e, pairs, E, list, list_stride, count);
+  return DSK_OK;
+}
+
+// x[p] += sum_k w[p][k] * eout[p * K + k] in k order, then the shared expert's row (src/infer.cpp:874-877, 900-903; the
+// multiply-adds of the decode launches' fused combine)
+__global__ __launch_bounds__(256) void hyd_combine_kernel(float* __restrict__ X, const float* __restrict__ eout, const float* __restrict__ w,
+                                                          const float* __restrict__ eout_sh, int K, int n) {
+  const int p = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float xv = X[(size_t)p * n + i];
+  for (int k = 0; k < K; ++k) xv = fmaf(eout[((size_t)p * K + k) * n + i], w[(size_t)p * K + k], xv);
+  if (eout_sh) xv += eout_sh[(size_t)p * n + i];
+  X[(size_t)p * n + i] = xv;
+}
+int launch_hyd_combine(hipStream_t st, float* X, const float* eout, const float* w, const float* eout_sh, int P, int K, int n) {
+  hipLaunchKernelGGL(hyd_combine_kernel, dim3((n + 255) / 256, P), dim3(256), 0, st, X, eout, w, eout_sh, K, n);
+  return DSK_OK;
+}

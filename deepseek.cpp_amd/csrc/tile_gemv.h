@@ -109,6 +109,7 @@ DEV void gemv_tile_body(const GemvLaunch* __restrict__ Lp, const void* h_a0, con
   float* red = reinterpret_cast<float*>(smem + t_act);
   const TLane TL = tlane_init(lane);
   bool first = true;
+  bool red_live = false;   // a previous round's partials may still be read by a slower wave (also across TASKS)
   int comb_rows = 0;       // combine: this workgroup's rows [r_lo, r_lo + comb_rows) of its ONE task
   float* comb_out = nullptr;
 
@@ -145,6 +146,10 @@ DEV void gemv_tile_body(const GemvLaunch* __restrict__ Lp, const void* h_a0, con
     if (cap > TILE_MAX_ROUND_STRIPS) cap = TILE_MAX_ROUND_STRIPS;
     for (int tb = lo >> 4; tb < (hi >> 4); tb += cap) {
       const int nt = (hi >> 4) - tb < cap ? (hi >> 4) - tb : cap;
+      // the partials region is reused by every round of every task of this workgroup: wait until the previous round's
+      // readers (tile_strip_value) are done - a share that straddles two tasks used to skip this barrier
+      if (red_live) __syncthreads();
+      red_live = true;
       // static deal: the round's items as contiguous ranges (a wave streams one contiguous byte range of tiles), a barrier,
       // then one wave per strip adds its partials (the association of tile_device.h) and runs the epilogue.
       // (Measured and rejected: the waves pulling 8-step units from an LDS counter, the wave that delivers a
@@ -173,7 +178,6 @@ DEV void gemv_tile_body(const GemvLaunch* __restrict__ Lp, const void* h_a0, con
           else *o = v;
         }
       }
-      if (tb + cap < (hi >> 4)) __syncthreads();  // another round follows: its partials reuse the region
       if (tl && tid == 0 && first) { tl[2] = wall_clock64(); first = false; }
     }
   }

@@ -416,6 +416,43 @@ class Model:
         f.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_void_p]
         check(f(self.h, layer, cache.encode(), row0, rows.shape[0], rows.ctypes.data))
 
+    def get_cache_rows(self, layer: int, cache: str, row0: int, nrows: int, width: int):
+        """dsk_model_get_cache_rows: (nrows, width) uint16 f16 bits of cache rows [row0, row0 + nrows)"""
+        out = np.zeros((nrows, width), np.uint16)
+        f = lib().dsk_model_get_cache_rows
+        f.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_void_p]
+        check(f(self.h, layer, cache.encode(), row0, nrows, out.ctypes.data))
+        return out
+
+    def hydrate(self, tokens, pos0: int = 0, mode: int = MODE_HYDRATE_KV_CACHE):
+        """dsk_hydrate: the prompt loop of src/main.cpp:312-319 (one forward per token), run as batched launches when the
+        model qualifies; returns the last token's logits when mode == MODE_OUTPUT_LOGITS"""
+        toks = np.ascontiguousarray(tokens, np.int32)
+        f = lib().dsk_hydrate
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        check(f(self.h, toks.ctypes.data, int(toks.size), pos0, mode, self._logits.ctypes.data))
+        return self._logits.copy() if mode == MODE_OUTPUT_LOGITS else None
+
+    def hydrate_why_not(self) -> str:
+        f = lib().dsk_hydrate_why_not
+        f.argtypes = [C.c_void_p]
+        f.restype = C.c_char_p
+        return f(self.h).decode()
+
+    def hydrate_buffer(self, name: str, shape, dtype=np.float32):
+        out = np.zeros(shape, dtype)
+        f = lib().dsk_hydrate_get_buffer
+        f.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
+        check(f(self.h, name.encode(), out.ctypes.data, out.nbytes))
+        return out
+
+    def hydrate_trace_x(self, layer: int, index: int):
+        x = np.zeros(self.cfg.dim, np.float32)
+        f = lib().dsk_hydrate_get_trace_x
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        check(f(self.h, layer, index, x.ctypes.data))
+        return x
+
     def timeline(self, kind: int, n_wgs: int = 1024):
         """(n_wgs, 8) wall-clock stamps (100 MHz ticks) of the LAST launch of one kind in a token; the model must have been
         created with options={"timeline": 1} (include/dsk.h dsk_model_get_timeline; rows of unused workgroups are 0)"""

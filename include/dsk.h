@@ -243,6 +243,27 @@ int dsk_model_load_dseek(dsk_ctx* ctx, const char* dir, int context, dsk_model**
 /* One token.  mode == OUTPUT_LOGITS: host_logits receives vocab_size floats
  * (what InferenceState::logits() holds, src/model.h:137).  HYDRATE: host_logits may be NULL. */
 int dsk_forward(dsk_model* m, int token, int pos, int mode, float* host_logits);
+/* The prompt phase.  The reference feeds a prompt to Model::forward one token at a time
+ * (src/main.cpp:312-319, InferenceMode::HYDRATE_KV_CACHE for every token but the last; src/infer.cpp:1284-1287).
+ * dsk_hydrate is DEFINED as that loop:
+ *     for i < n_tokens - 1:  dsk_forward(m, tokens[i], pos0 + i, DSK_MODE_HYDRATE_KV_CACHE, NULL)
+ *     dsk_forward(m, tokens[n_tokens - 1], pos0 + n_tokens - 1, mode, host_logits)
+ * and runs it as batched launches - every weight matrix read once per chunk of up to "hydrate_chunk" tokens (option,
+ * default 128), the Q2_K row products as i8 GEMMs on the matrix pipe - when the model qualifies: Q2_K weights stored as tile
+ * records (option "q2k_tiles" = 2 before binding), MHA attention with a q latent, one GPU, and positions below the ring
+ * wrap (rs_original_max_position_embeddings).  KV-cache rows, routing and logits are then BIT-identical to the loop
+ * (tests/test_hydrate_gpu.py).  Anything else - other models, the tokens at and past the wrap - runs the loop itself, so
+ * the call is always valid.  dsk_hydrate_why_not: "" when the batched path applies to this model, else the reason.
+ * dsk_model_get_info "hydrate_batched_tokens" / "hydrate_looped_tokens" count what ran where. */
+int dsk_hydrate(dsk_model* m, const int32_t* tokens, int n_tokens, int pos0, int mode, float* host_logits);
+const char* dsk_hydrate_why_not(dsk_model* m);
+/* Parity harness: residual stream of token `index` of the last batched chunk after block `layer`
+ * (dsk_model_set_trace(m, 1) before the first dsk_hydrate call); the per-token counterpart is dsk_model_get_trace_x. */
+int dsk_hydrate_get_trace_x(dsk_model* m, int layer, int index, float* x_out);
+/* Debugging: an intermediate buffer of the batched path as the last chunk left it ("x", "q_a", "kv_a", "q", "kv_b", "att",
+ * "hbd", "hb", "hb_sh", "eout", "eout_sh", "route_e", "route_w", "q8.x.qs", ...; rows of hydrate_chunk tokens).  With option
+ * "hydrate_stop_layer" = l + 1 a chunk stops after block l and the buffers hold that block's intermediates. */
+int dsk_hydrate_get_buffer(dsk_model* m, const char* name, void* out, size_t bytes);
 /* Enable/disable replaying the token step from a captured hipGraph (default on). */
 /* The engine's own pinned host buffer of vocab_size floats (the D2H target of every OUTPUT_LOGITS step).  Passing it
    as `host_logits` to dsk_forward skips the extra host copy: a host application can make InferenceState::logits()
@@ -302,6 +323,8 @@ int dsk_model_get_stage(dsk_model* m, const char* name, void* out, size_t bytes)
  * bits, so that ONE block can be audited at a long context (the attention regimes that start at 320 / 1024 cached
  * positions) without decoding thousands of tokens first. */
 int dsk_model_set_cache_rows(dsk_model* m, int layer, const char* cache, int row0, int nrows, const uint16_t* rows);
+/* ... and the read side: the same rows as f16 bits (what a prompt left in the cache). */
+int dsk_model_get_cache_rows(dsk_model* m, int layer, const char* cache, int row0, int nrows, uint16_t* rows);
 
 /* Per-kernel-class device time of ONE eager forward bracketed by HIP events on the
  * engine stream.  names: up to max_classes pointers to static strings. */

@@ -1,0 +1,173 @@
+"""Batched prompt ingestion: dsk_hydrate against its own definition.
+
+The reference feeds a prompt to Model::forward one token at a time (src/main.cpp:312-319, HYDRATE_KV_CACHE for all tokens but
+the last; src/infer.cpp:1284-1287).  dsk_hydrate is defined as that loop over dsk_forward and runs it as batched launches
+(kernels_hydrate.hip: every weight matrix read once per chunk, the Q2_K row products as i8 GEMMs on the matrix pipe) when the
+model qualifies.  The bar is BIT-IDENTITY with the loop on the same model: every KV-cache row the prompt wrote, the residual
+stream after every block for every token, and the last token's logits - which covers Q8_K codes, integer sums and routing
+(a single different code or expert changes the bits downstream).  Parity of the loop itself with the reference is the
+business of the other test files; this one proves that the batched path is the same function.
+"""
+import numpy as np
+import pytest
+
+from tools import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _caches(M, c, n_rows):
+    H, hd, vd = c.n_heads, c.qk_nope_head_dim + c.qk_rope_head_dim, c.v_head_dim
+    out = []
+    for l in range(c.n_layers):
+        out.append((M.get_cache_rows(l, "k_cache", 0, n_rows, H * hd), M.get_cache_rows(l, "v_cache", 0, n_rows, H * vd)))
+    return out
+
+
+def _loop(M, tokens, pos0, trace=False):
+    """the definition: one dsk_forward per token; returns the last logits (+ x after every block per token)"""
+    import dsk
+    xs = []
+    lo = None
+    for i, t in enumerate(tokens):
+        last = i == len(tokens) - 1
+        lo = M.forward(int(t), pos0 + i, dsk.MODE_OUTPUT_LOGITS if last else dsk.MODE_HYDRATE_KV_CACHE)
+        if trace:
+            xs.append(np.stack([M.trace_x(l) for l in range(M.cfg.n_layers)]))
+    return lo, (np.stack(xs) if trace else None)
+
+
+def compare_hydrate(ctx, c, T=None, seed=None, tokens=(), pos0=0, chunk=None, report=None):
+    """two models of the same weights: A runs the per-token loop, B dsk_hydrate; returns a dict of mismatch counts"""
+    import dsk
+    opts = {"q2k_tiles": 2}
+    A = dsk.Model(ctx, c, T, synth_seed=seed, options=opts)
+    ob = dict(opts)
+    if chunk:
+        ob["hydrate_chunk"] = chunk
+    B = dsk.Model(ctx, c, T, synth_seed=seed, options=ob)
+    try:
+        assert B.hydrate_why_not() == "", B.hydrate_why_not()
+        A.set_trace(True)
+        B.set_trace(True)
+        tokens = [int(t) % c.vocab_size for t in tokens]
+        pre = [(7 * i + 3) % c.vocab_size for i in range(pos0)]
+        if pos0:  # an existing context, written by the loop on A and by an earlier dsk_hydrate call on B
+            _loop(A, pre, 0)
+            B.hydrate(pre, 0, dsk.MODE_HYDRATE_KV_CACHE)
+        la, xa = _loop(A, tokens, pos0, trace=True)
+        lb = B.hydrate(tokens, pos0, dsk.MODE_OUTPUT_LOGITS)
+        P = len(tokens)
+        res = {"batched": B.info("hydrate_batched_tokens"), "looped": B.info("hydrate_looped_tokens")}
+        cap = chunk or 128
+        first_of_last_chunk = ((P - 1) // cap) * cap
+        bad_x = []
+        for i in range(first_of_last_chunk, P):  # the batched trace holds the last chunk
+            for l in range(c.n_layers):
+                xb = B.hydrate_trace_x(l, i - first_of_last_chunk)
+                if not np.array_equal(xb, xa[i][l]):
+                    bad_x.append((i, l, float(np.abs(xb - xa[i][l]).max() / max(1e-30, np.abs(xa[i][l]).max()))))
+        res["bad_x"] = bad_x
+        ca, cb = _caches(A, c, pos0 + P), _caches(B, c, pos0 + P)
+        bad_kv = []
+        for l in range(c.n_layers):
+            for name, a, b in (("k", ca[l][0], cb[l][0]), ("v", ca[l][1], cb[l][1])):
+                rows = np.nonzero((a != b).any(axis=1))[0]
+                if rows.size:
+                    bad_kv.append((l, name, rows[:8].tolist(), int(rows.size)))
+        res["bad_kv"] = bad_kv
+        res["logits_equal"] = bool(np.array_equal(la, lb))
+        res["logits_err"] = float(np.abs(la - lb).max() / max(1e-30, np.abs(la).max()))
+        if report is not None:
+            report(res)
+        return res
+    finally:
+        A.close()
+        B.close()
+
+
+def _assert_identical(res, P, pos0):
+    assert res["batched"] == P + pos0 and res["looped"] == 0, res
+    assert not res["bad_x"], res["bad_x"][:6]
+    assert not res["bad_kv"], res["bad_kv"][:6]
+    assert res["logits_equal"], res["logits_err"]
+
+
+@pytest.mark.parametrize("P,pos0,chunk", [(1, 0, None), (2, 0, None), (5, 3, None), (16, 0, None), (17, 0, None), (37, 5, None), (37, 0, 16), (48, 9, 7)])
+def test_hydrate_equals_the_loop_tiny(ctx, P, pos0, chunk):
+    """tiny DeepSeek-V3 Q2_K MHA model (1 dense + 2 MoE blocks, 16 experts top-4, rows of <= 8 blocks: single-block items):
+    token quads that are full, ragged and single; chunks that split the prompt (attention over rows an earlier chunk wrote)"""
+    c = synth.preset("tiny_v3", "q2_k", False)
+    T = synth.synth_model(c, seed=41)
+    rng = np.random.default_rng(P * 31 + pos0)
+    tokens = rng.integers(0, c.vocab_size, P)
+    _assert_identical(compare_hydrate(ctx, c, T, tokens=tokens, pos0=pos0, chunk=chunk), P, pos0)
+
+
+@pytest.mark.parametrize("P,pos0", [(1, 0), (16, 0), (37, 2), (128, 0)])
+def test_hydrate_equals_the_loop_v3_width(ctx, P, pos0):
+    """1 dense + 1 MoE block at DeepSeek-V3 width (dim 7168: 4-block items with a full last item; wo's 64-block rows; 2048-wide
+    hidden vectors: single-block items), 256 routed experts top-8 in 8 groups, weights synthesised in HBM"""
+    c = synth.preset("v3", "q2_k", False, n_layers=2, first_k_dense_replace=1, max_seq_len=192)
+    rng = np.random.default_rng(P)
+    tokens = rng.integers(0, c.vocab_size, P)
+    _assert_identical(compare_hydrate(ctx, c, None, seed=11, tokens=tokens, pos0=pos0), P, pos0)
+
+
+def test_hydrate_across_the_ring_wrap_takes_the_loop_there(ctx):
+    """positions at and past rs_original_max_position_embeddings rotate the sink keys in place, token by token
+    (src/infer.cpp:1008-1020): dsk_hydrate batches up to the wrap and loops from there - still the same bits as the loop"""
+    import dsk
+    c = synth.preset("tiny_v3", "q2_k", False, rs_original_max_position_embeddings=24, max_seq_len=64)
+    T = synth.synth_model(c, seed=43)
+    tokens = [(11 * i + 5) % c.vocab_size for i in range(40)]
+    A = dsk.Model(ctx, c, T, options={"q2k_tiles": 2})
+    B = dsk.Model(ctx, c, T, options={"q2k_tiles": 2, "hydrate_chunk": 16})
+    la, _ = _loop(A, tokens, 0)
+    lb = B.hydrate(tokens, 0, dsk.MODE_OUTPUT_LOGITS)
+    assert B.info("hydrate_batched_tokens") == 24 and B.info("hydrate_looped_tokens") == 16
+    assert np.array_equal(la, lb)
+    for (ka, va), (kb, vb) in zip(_caches(A, c, 24), _caches(B, c, 24)):
+        assert np.array_equal(ka, kb) and np.array_equal(va, vb)
+    A.close()
+    B.close()
+
+
+@pytest.mark.parametrize("quant,mla,level", [("f8e5m2", False, 2), ("q2_k", True, 2), ("q2_k", False, 1), ("q3_k", False, 2)])
+def test_models_that_do_not_qualify_run_the_loop(ctx, quant, mla, level):
+    """float weights, MLA, the default plane layout, Q3_K: dsk_hydrate IS the loop there (and says why)"""
+    import dsk
+    c = synth.preset("tiny_v3", quant, mla)
+    T = synth.synth_model(c, seed=47)
+    tokens = [3, 99, 512, 7, 1000, 64]
+    A = dsk.Model(ctx, c, T, options={"q2k_tiles": level})
+    B = dsk.Model(ctx, c, T, options={"q2k_tiles": level})
+    assert B.hydrate_why_not() != ""
+    la, _ = _loop(A, tokens, 0)
+    lb = B.hydrate(tokens, 0, dsk.MODE_OUTPUT_LOGITS)
+    assert B.info("hydrate_batched_tokens") == 0 and B.info("hydrate_looped_tokens") == len(tokens)
+    assert np.array_equal(la, lb)
+    A.close()
+    B.close()
+
+
+def test_hydrate_then_decode_continues_the_same_stream(ctx):
+    """a prompt through dsk_hydrate, then greedy decoding with dsk_forward: the same tokens as the all-loop run"""
+    import dsk
+    c = synth.preset("tiny_v3", "q2_k", False)
+    T = synth.synth_model(c, seed=53)
+    prompt = [(13 * i + 1) % c.vocab_size for i in range(21)]
+    outs = []
+    for batched in (0, 1):
+        M = dsk.Model(ctx, c, T, options={"q2k_tiles": 2, "hydrate_batched": batched})
+        lo = M.hydrate(prompt, 0, dsk.MODE_OUTPUT_LOGITS)
+        seq = []
+        for i in range(12):
+            t = int(np.argmax(lo))
+            seq.append(t)
+            lo = M.forward(t, len(prompt) + i)
+        outs.append((seq, lo.copy(), M.info("hydrate_batched_tokens")))
+        M.close()
+    assert outs[0][2] == 0 and outs[1][2] == len(prompt)
+    assert outs[0][0] == outs[1][0]
+    assert np.array_equal(outs[0][1], outs[1][1])
