@@ -237,6 +237,8 @@ static int hyd_chunk(dsk_model* m, const int32_t* tokens, int P, int pos0) {
   const dsk_config& c = m->c;
   HydState& h = *m->hyd;
   hipStream_t st = m->ctx->stream;
+  // (the pinned step-parameter rows are re-used by every chunk: the previous chunk's asynchronous copy must have read them)
+  HIP_TRY(hipStreamSynchronize(st));
   for (int p = 0; p < P; ++p) DSK_TRY(fill_step_params_at(m, tokens[p], pos0 + p, h.sp_host + p));
   HIP_TRY(hipMemcpyAsync(h.sp, h.sp_host, (size_t)P * sizeof(StepParams), hipMemcpyHostToDevice, st));
   for (int p = 0; p < P; ++p)  // Model::_copy_embedding, src/infer.cpp:1217-1263
