@@ -496,7 +496,7 @@ struct HydLatentArgs {
 int launch_hyd_latent_q8(hipStream_t st, const HydLatentArgs& A, int P);
 int launch_hyd_kv_write(hipStream_t st, const AttnMhaArgs& a, const StepParams* sps, int P, const float* kv_b, int kvb_stride, const float* kv_a, int kva_stride);
 int launch_hyd_attn(hipStream_t st, const AttnMhaArgs& a, const StepParams* sps, int P, int max_kv, const float* q, int q_stride, float* out, int out_stride);
-int launch_hyd_router(hipStream_t st, const RouterArgs& a, int P);
+int launch_hyd_router(hipStream_t st, const RouterArgs& a, int P, float* Y);
 int launch_hyd_group(hipStream_t st, const int* route_e, int pairs, int E, int* list, int list_stride, int* count);
 int launch_hyd_combine(hipStream_t st, float* X, const float* eout, const float* w, const float* eout_sh, int P, int K, int n);
 

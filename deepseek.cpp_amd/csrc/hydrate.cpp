@@ -109,7 +109,7 @@ static int hyd_ensure(dsk_model* m) {
   DSK_TRY(hyd_alloc(h, (void**)&h->q, P * H * hd * 4, &tot));
   DSK_TRY(hyd_alloc(h, (void**)&h->kv_b, P * H * nv * 4, &tot));
   DSK_TRY(hyd_alloc(h, (void**)&h->att, P * H * vd * 4, &tot));
-  DSK_TRY(hyd_alloc(h, (void**)&h->hbd, P * c.hidden_dim * 4, &tot));
+  DSK_TRY(hyd_alloc(h, (void**)&h->hbd, P * std::max<size_t>(c.hidden_dim, dim) * 4, &tot));  // (also the router's normed vectors)
   DSK_TRY(hyd_alloc(h, (void**)&h->hb, P * K * mi * 4, &tot));
   DSK_TRY(hyd_alloc(h, (void**)&h->hb_sh, P * shn * 4, &tot));
   DSK_TRY(hyd_alloc(h, (void**)&h->eout, P * K * dim * 4, &tot));
@@ -136,7 +136,6 @@ static int hyd_ensure(dsk_model* m) {
 }
 
 // tokens per pass of a GEMM wave: 4 * nq (kernels_hydrate.hip NQ) for a task of `rows_per_task` activation rows on average
-static int hyd_nq(double rows_per_task) { return rows_per_task <= 4.0 ? 1 : (rows_per_task <= 10.0 ? 2 : 4); }
 
 static int hyd_gemm(dsk_model* m, const DTensor& w, const DTensor* w3, const HydQ8& a, int a_rows, int P, float* out, int out_stride, int epilogue) {
   HydGemmArgs A;
@@ -145,7 +144,9 @@ static int hyd_gemm(dsk_model* m, const DTensor& w, const DTensor* w3, const Hyd
   A.rows = w.rows; A.n = w.n;
   A.a_qs = a.qs; A.a_d = a.d; A.a_bsums = a.bsums; A.a_rows = a_rows; A.a_div = 1;
   A.m = P; A.out = out; A.out_stride = out_stride; A.epilogue = epilogue; A.act = m->c.act;
-  return launch_hyd_gemm(m->ctx->stream, A, hyd_nq(P));
+  // plain matrices: 8 tokens per wave and pass (168 / 236 VGPRs: 3 / 2 waves per SIMD; 16 tokens need 260 / 366 and leave one),
+  // the four waves of a workgroup on consecutive chunks of the same strip
+  return launch_hyd_gemm(m->ctx->stream, A, P <= 4 ? 1 : 2);
 }
 
 static int hyd_layer(dsk_model* m, int l, int P, int max_kv) {
@@ -199,7 +200,7 @@ static int hyd_layer(dsk_model* m, int l, int P, int max_kv) {
     r.n_group = c.n_group; r.topk_group = c.topk_group; r.scaling = c.routed_scaling_factor;
     r.active_experts = h.route_e; r.active_weights = h.route_w;
     r.q_qs = h.a_x.qs; r.q_d = h.a_x.d; r.q_bsums = h.a_x.bsums;
-    DSK_TRY(launch_hyd_router(st, r, P));
+    DSK_TRY(launch_hyd_router(st, r, P, h.hbd));  // (the dense FFN's hidden buffer holds the normed vectors: P x dim <= P x hidden_dim)
   }
   DSK_TRY(launch_hyd_group(st, h.route_e, P * K, E, h.list, h.cap, h.count));
   if (shn > 0) {
@@ -208,7 +209,9 @@ static int hyd_layer(dsk_model* m, int l, int P, int max_kv) {
     DSK_TRY(hyd_gemm(m, L.t[DSK_ROLE_SHARED_W2], nullptr, h.a_hsh, P, P, h.eout_sh, dim, EPI_STORE));
   }
   const DTensor &w1 = L.t[DSK_ROLE_W1], &w2 = L.t[DSK_ROLE_W2], &w3 = L.t[DSK_ROLE_W3];
-  const int nq_e = hyd_nq((double)P * K / E * 1.5);
+  // 4 tokens per wave and pass unless the experts are crowded: 8 tokens cost the GLU pair half of its waves (260 registers), while a
+  // second pass over a strip re-reads 75 KB that the first pass just pulled through L2
+  const int nq_e = (double)P * K / E > 6.0 ? 2 : 1;
   {
     HydGemmArgs A;
     memset(&A, 0, sizeof A);

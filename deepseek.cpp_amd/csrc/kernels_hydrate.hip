@@ -69,21 +69,37 @@ DEV void hyd_acc_zero(HydAcc& a) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) a.S[g] = a.ad[g] = a.am[g] = 0.f;
 }
+// the activation side of one block for one token quad: the four selector-row operands, the tokens' sub-block sums and scale
+struct HydAct {
+  i32x4 a[4];
+  u32x4 bs0, bs1;
+  float dx;
+};
+DEV void hyd_act_load(HydAct& X, const rsrc_t& RA, const rsrc_t& RB, const rsrc_t& RD, int off0, int off1, int boff, int doff, int b) {
+  X.a[0] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(RA, off0, b * 256, 0));
+  X.a[1] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(RA, off0 + 32, b * 256, 0));
+  X.a[2] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(RA, off1, b * 256, 0));
+  X.a[3] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(RA, off1 + 32, b * 256, 0));
+  X.bs0 = __builtin_amdgcn_raw_buffer_load_b128(RB, boff, b * 32, 0);
+  X.bs1 = __builtin_amdgcn_raw_buffer_load_b128(RB, boff + 16, b * 32, 0);
+  X.dx = u2f(__builtin_amdgcn_raw_buffer_load_b32(RD, doff, b * 4, 0));
+}
 // one block of one tile for one token quad: D = the four exact group sums of this lane's (token, row)
-DEV void hyd_block(const HydTile& T, const i32x4 (&B)[4], const u32 (&m4)[4], const i32x4 (&a)[4], const u32x4& bs0, const u32x4& bs1, float dx, HydAcc& acc) {
+DEV void hyd_block(const HydTile& T, const i32x4 (&B)[4], const HydAct& X, HydAcc& acc) {
   i32x4 D = {0, 0, 0, 0};
-  D = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[0], B[0], D, 0, 0, 0);
-  D = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[1], B[1], D, 0, 0, 0);
-  D = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[2], B[2], D, 0, 0, 0);
-  D = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[3], B[3], D, 0, 0, 0);
-  const u32 bw[8] = {bs0.x, bs0.y, bs0.z, bs0.w, bs1.x, bs1.y, bs1.z, bs1.w};  // 16 int16 sub-block sums of the token
+  D = __builtin_amdgcn_mfma_i32_16x16x64_i8(X.a[0], B[0], D, 0, 0, 0);
+  D = __builtin_amdgcn_mfma_i32_16x16x64_i8(X.a[1], B[1], D, 0, 0, 0);
+  D = __builtin_amdgcn_mfma_i32_16x16x64_i8(X.a[2], B[2], D, 0, 0, 0);
+  D = __builtin_amdgcn_mfma_i32_16x16x64_i8(X.a[3], B[3], D, 0, 0, 0);
+  const u32 bw[8] = {X.bs0.x, X.bs0.y, X.bs0.z, X.bs0.w, X.bs1.x, X.bs1.y, X.bs1.z, X.bs1.w};  // 16 int16 sub-block sums of the token
   const int Dg[4] = {D.x, D.y, D.z, D.w};
-  const float dd = dx * h2f(T.dm & 0xffff), dmn = dx * h2f(T.dm >> 16);
+  const float dd = X.dx * h2f(T.dm & 0xffff), dmn = X.dx * h2f(T.dm >> 16);
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
+    const u32 m4 = (T.sc[g] >> 4) & 0x0F0F0F0Fu;                                   // the group's four 4-bit mins
     const u32 hi = __builtin_amdgcn_perm(bw[2 * g + 1], bw[2 * g], 0x07050301u);  // the sums' high bytes (signed)
     const u32 lo = __builtin_amdgcn_perm(bw[2 * g + 1], bw[2 * g], 0x06040200u);  // low bytes (unsigned)
-    const int summs = (sdot4(m4[g], hi, 0) << 8) + (int)__builtin_amdgcn_udot4(m4[g], lo, 0u, false);
+    const int summs = (sdot4(m4, hi, 0) << 8) + (int)__builtin_amdgcn_udot4(m4, lo, 0u, false);
     acc.ad[g] = fmaf(dd, (float)Dg[g], acc.ad[g]);     // tile_device.h tstep_mac, without the in-place mask factors ...
     acc.am[g] = fmaf(dmn, (float)summs, acc.am[g]);
   }
@@ -98,23 +114,40 @@ DEV void hyd_item_end(HydAcc& acc) {
 DEV float hyd_value(const HydAcc& acc) { return (acc.S[0] + acc.S[1]) + (acc.S[2] + acc.S[3]); }  // tile_strip_value
 
 // One wave = one 16-row strip (GLU: the same strip of w1 and w3) of one task (a plain matrix, or expert `task` of a stack) times
-// the task's activation rows, 4 * NQ tokens per pass over the strip's tiles.
-template <bool GLU, int NQ>
-__global__ __launch_bounds__(256) void hyd_gemm_kernel(const HydGemmArgs A) {
+// 4 * NQ of the task's activation rows per pass over the strip's tiles.
+//   SPREAD false (expert stacks: a handful of rows per task): the four waves of a workgroup take four consecutive strips and
+//                loop over the task's rows, 4 * NQ at a time;
+//   SPREAD true  (plain matrices times all P tokens): the waves of a workgroup (up to 8) take the SAME strip and consecutive
+//                chunks of 4 * NQ tokens - they stream the same tiles at the same time (one HBM read, L1 hits for the others) and
+//                each wave's chain of dependent loads is short.
+// Software pipeline of a pass: the tiles of blocks b + 1 and b + 2 and the activation operands of block b + 1 are in flight
+// while block b is multiplied (a wave is a chain of dependent memory round trips otherwise: measured 3 - 15x the streaming time).
+// Quads past the task's rows read zeros (out-of-range buffer offsets) and are not stored.
+template <bool GLU, int NQ, bool SPREAD>
+__global__ __launch_bounds__(SPREAD && !GLU ? 512 : 256) void hyd_gemm_kernel(const HydGemmArgs A) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int nwaves = (int)blockDim.x >> 6;
   const int strips = (A.rows + 15) >> 4;
   const int ntask = A.n_experts > 0 ? A.n_experts : 1;
-  const long long unit = (long long)blockIdx.x * 4 + wave;
+  const long long unit = SPREAD ? (long long)blockIdx.x : (long long)blockIdx.x * nwaves + wave;
   if (unit >= (long long)ntask * strips) return;
   const int task = (int)(unit / strips), strip = (int)(unit - (long long)task * strips);
-  const int cnt = A.count ? __builtin_amdgcn_readfirstlane(A.count[task]) : A.m;
-  if (cnt <= 0) return;
-  const int* list = A.list ? A.list + (size_t)task * A.list_stride : nullptr;
   const int n = A.n, nb = n >> 8;
-  const bool seg4 = nb > 8;  // tile_seg
   const size_t woff = (size_t)task * A.e_bytes + (size_t)strip * nb * TILE_B;
   const rsrc_t W1 = make_rsrc(A.W + woff);
   const rsrc_t W3 = make_rsrc(GLU ? A.W3 + woff : A.W + woff);
+  // the strip's first tiles are requested before anything is known about the task's rows (a task without rows costs one tile)
+  HydTile T1, T3, N1, N3;
+  hyd_tile_load(T1, W1, lane, 0);
+  if (GLU) hyd_tile_load(T3, W3, lane, 0);
+  if (nb > 1) {
+    hyd_tile_load(N1, W1, lane, TILE_B);
+    if (GLU) hyd_tile_load(N3, W3, lane, TILE_B);
+  }
+  const int cnt = A.count ? __builtin_amdgcn_readfirstlane(A.count[task]) : A.m;
+  if (cnt <= 0) return;
+  const int* list = A.list ? A.list + (size_t)task * A.list_stride : nullptr;
+  const bool seg4 = nb > 8;  // tile_seg
   const rsrc_t RA = make_rsrc_n(A.a_qs, (u32)((size_t)A.a_rows * n));
   const rsrc_t RB = make_rsrc_n(A.a_bsums, (u32)((size_t)A.a_rows * (n >> 4) * 2));
   const rsrc_t RD = make_rsrc_n(A.a_d, (u32)((size_t)A.a_rows * nb * 4));
@@ -124,7 +157,9 @@ __global__ __launch_bounds__(256) void hyd_gemm_kernel(const HydGemmArgs A) {
   const bool lane_ok = (g4l >> 1) == (kg >> 1);
   const int jbase = 16 * (8 * (kg >> 1) + (kg & 1));  // byte offset of sub-block j(kg, 0) in a block's codes
   const int qd = lane >> 4, rown = lane & 15;         // result side: token qd of the quad, row rown of the strip
-  for (int base = 0; base < cnt; base += 4 * NQ) {
+  const int first = SPREAD ? wave * 4 * NQ : 0, step = SPREAD ? nwaves * 4 * NQ : 4 * NQ;
+  bool first_pass = true;
+  for (int base = first; base < cnt; base += step) {
     int off0[NQ], off1[NQ], boff[NQ], doff[NQ], outv[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -143,51 +178,53 @@ __global__ __launch_bounds__(256) void hyd_gemm_kernel(const HydGemmArgs A) {
       doff[q] = okD ? arowD * nb * 4 : HYD_OOB;
       outv[q] = okD ? vD : -1;
     }
+    HydAct X[NQ], Y[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) hyd_act_load(X[q], RA, RB, RD, off0[q], off1[q], boff[q], doff[q], 0);
+    if (!first_pass) {  // a further pass over the same strip (L2 hits)
+      hyd_tile_load(T1, W1, lane, 0);
+      if (GLU) hyd_tile_load(T3, W3, lane, 0);
+      if (nb > 1) {
+        hyd_tile_load(N1, W1, lane, TILE_B);
+        if (GLU) hyd_tile_load(N3, W3, lane, TILE_B);
+      }
+    }
+    first_pass = false;
     HydAcc acc1[NQ], acc3[GLU ? NQ : 1];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { hyd_acc_zero(acc1[q]); if (GLU) hyd_acc_zero(acc3[q]); }
-    HydTile T1, T3;
-    hyd_tile_load(T1, W1, lane, 0);
-    if (GLU) hyd_tile_load(T3, W3, lane, 0);
     for (int b = 0; b < nb; ++b) {
-      HydTile N1, N3;
-      if (b + 1 < nb) {  // the next tile travels while this one is multiplied
-        hyd_tile_load(N1, W1, lane, (b + 1) * TILE_B);
-        if (GLU) hyd_tile_load(N3, W3, lane, (b + 1) * TILE_B);
+      HydTile M1, M3;
+      if (b + 2 < nb) {
+        hyd_tile_load(M1, W1, lane, (b + 2) * TILE_B);
+        if (GLU) hyd_tile_load(M3, W3, lane, (b + 2) * TILE_B);
       }
-      i32x4 B1[4], B3[4];
-      u32 m1[4], m3[4];
-      hyd_expand(T1, kg, B1);
+      if (b + 1 < nb) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) m1[g] = (T1.sc[g] >> 4) & 0x0F0F0F0Fu;
-      if (GLU) {
-        hyd_expand(T3, kg, B3);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) m3[g] = (T3.sc[g] >> 4) & 0x0F0F0F0Fu;
+        for (int q = 0; q < NQ; ++q) hyd_act_load(Y[q], RA, RB, RD, off0[q], off1[q], boff[q], doff[q], b + 1);
       }
+      const bool item_end = !seg4 || (b & 3) == 3 || b == nb - 1;  // tile_device.h: items of 4 blocks, or 1 for rows of <= 8
+      {
+        i32x4 B[4];
+        hyd_expand(T1, kg, B);
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        if (base + 4 * q < cnt) {  // wave-uniform
-          i32x4 a[4];
-          a[0] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(RA, off0[q], b * 256, 0));
-          a[1] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(RA, off0[q] + 32, b * 256, 0));
-          a[2] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(RA, off1[q], b * 256, 0));
-          a[3] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(RA, off1[q] + 32, b * 256, 0));
-          const u32x4 bs0 = __builtin_amdgcn_raw_buffer_load_b128(RB, boff[q], b * 32, 0);
-          const u32x4 bs1 = __builtin_amdgcn_raw_buffer_load_b128(RB, boff[q] + 16, b * 32, 0);
-          const float dx = u2f(__builtin_amdgcn_raw_buffer_load_b32(RD, doff[q], b * 4, 0));
-          hyd_block(T1, B1, m1, a, bs0, bs1, dx, acc1[q]);
-          if (GLU) hyd_block(T3, B3, m3, a, bs0, bs1, dx, acc3[q]);
-          if (!seg4 || (b & 3) == 3 || b == nb - 1) {  // the item ends here (tile_device.h: 4 blocks, or 1 for rows of <= 8)
-            hyd_item_end(acc1[q]);
-            if (GLU) hyd_item_end(acc3[q]);
+        for (int q = 0; q < NQ; ++q) {
+          hyd_block(T1, B, X[q], acc1[q]);
+          if (item_end) hyd_item_end(acc1[q]);
+        }
+        if (GLU) {
+          hyd_expand(T3, kg, B);
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            hyd_block(T3, B, X[q], acc3[q]);
+            if (item_end) hyd_item_end(acc3[q]);
           }
         }
       }
-      if (b + 1 < nb) {
-        T1 = N1;
-        if (GLU) T3 = N3;
-      }
+      T1 = N1; N1 = M1;
+      if (GLU) { T3 = N3; N3 = M3; }
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) X[q] = Y[q];
     }
     const int row = strip * 16 + rown;
 #pragma unroll
@@ -206,14 +243,22 @@ __global__ __launch_bounds__(256) void hyd_gemm_kernel(const HydGemmArgs A) {
 template <bool GLU, int NQ>
 static void hyd_gemm_launch(hipStream_t st, const HydGemmArgs& A) {
   const long long units = (long long)(A.n_experts > 0 ? A.n_experts : 1) * ((A.rows + 15) >> 4);
-  hipLaunchKernelGGL((hyd_gemm_kernel<GLU, NQ>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st, A);
+  // plain matrices with more rows of activations than one wave takes per pass: the waves of a workgroup share a strip
+  if (A.n_experts == 0 && A.m > 4 * NQ) {
+    int nw = (A.m + 4 * NQ - 1) / (4 * NQ);
+    const int maxw = GLU ? 4 : 8;  // (a GLU pair holds two matrices' tiles: 4 waves keep 512 registers per lane in reach)
+    if (nw > maxw) nw = maxw;
+    hipLaunchKernelGGL((hyd_gemm_kernel<GLU, NQ, true>), dim3((unsigned)units), dim3(64 * nw), 0, st, A);
+  } else {
+    hipLaunchKernelGGL((hyd_gemm_kernel<GLU, NQ, false>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st, A);
+  }
 }
 int launch_hyd_gemm(hipStream_t st, const HydGemmArgs& A, int nq) {
   if (A.n % 256 || A.rows < 1 || A.a_rows < 1 || A.a_div < 1) DSK_FAIL(DSK_ERR_INVALID, "hyd_gemm: bad shape");
-  if ((size_t)A.a_rows * A.n >= (size_t)HYD_OOB) DSK_FAIL(DSK_ERR_UNSUPPORTED, "hyd_gemm: activation array too large for 31-bit offsets");
+  if ((size_t)A.a_rows * A.n >= (size_t)HYD_OOB) DSK_FAIL(DSK_ERR_UNSUPPORTED, "hyd_gemm: activation array too large for 30-bit offsets");
   const bool glu = A.W3 != nullptr;
-  if (nq >= 4) { if (glu) hyd_gemm_launch<true, 4>(st, A); else hyd_gemm_launch<false, 4>(st, A); }
-  else if (nq >= 2) { if (glu) hyd_gemm_launch<true, 2>(st, A); else hyd_gemm_launch<false, 2>(st, A); }
+  // (16 tokens per wave and pass - NQ 4 - needs 260 / 366 registers with the pipeline's double buffers: not built)
+  if (nq >= 2) { if (glu) hyd_gemm_launch<true, 2>(st, A); else hyd_gemm_launch<false, 2>(st, A); }
   else { if (glu) hyd_gemm_launch<true, 1>(st, A); else hyd_gemm_launch<false, 1>(st, A); }
   return DSK_OK;
 }
@@ -372,10 +417,90 @@ int launch_hyd_attn(hipStream_t st, const AttnMhaArgs& a, const StepParams* sps,
 }
 
 // ------------------------------------------------------------------------------------
-// router + gate of P tokens: the decode launch's router_body (router_device.h), one grid row per token.  It also leaves the
-// Q8_K copy of rmsnorm(x, ffn_norm) behind, quantised with the router's own norm scale - what the experts AND the shared
-// expert's rider consume in the decode path.
+// router + gate of P tokens (src/infer.cpp:839-851, 493-599).  The decode launch (router_device.h router_body) recomputes the
+// norm and re-reads the 7.3 MB of router weights per token; here
+//   1. hyd_router_norm_kernel  per token: the router's own rmsnorm scale (router_norm_scale: the 1024-thread tree), the normed
+//      vector y = x * scale * w as f32, and its Q8_K copy - what the experts AND the shared expert's rider consume in decode;
+//   2. hyd_router_rows_kernel  per workgroup RW rows x 16 / RW column slices like router_body, the weights of a (row, slice)
+//      held in REGISTERS across all P tokens: per token the same fma chain over the same values, the same wave tree, the
+//      same slice-order sum;
+//   3. hyd_gate_kernel         per token: gate_body on the scores.
+// Falls back to router_body per token (hyd_router_kernel) when a slice does not fit the registers.
 // ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void hyd_router_norm_kernel(RouterArgs a0, float* __restrict__ Y) {
+  __shared__ float scratch[16];
+  RouterArgs a = a0;
+  const int p = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, dim = a.dim;
+  a.x += (size_t)p * dim;
+  const float scale = rd::router_norm_scale(a, tid, scratch);
+  float* y = Y + (size_t)p * dim;
+  for (int b = wave; b < (dim >> 8); b += 16) {
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(a.x + b * 256 + lane * 4);
+    const f32x4 nw = *reinterpret_cast<const f32x4*>(a.norm_w + b * 256 + lane * 4);
+    const float v[4] = {xv.x * scale * nw.x, xv.y * scale * nw.y, xv.z * scale * nw.z, xv.w * scale * nw.w};
+    *reinterpret_cast<f32x4*>(y + b * 256 + lane * 4) = f32x4{v[0], v[1], v[2], v[3]};
+    if (a.q_qs) ad::q8k_block(v, lane, a.q_qs + (size_t)p * dim + b * 256, a.q_d + (size_t)p * (dim >> 8) + b, a.q_bsums + (size_t)p * (dim >> 4) + b * 16);
+  }
+}
+template <int RW>
+__global__ __launch_bounds__(1024) void hyd_router_rows_kernel(const float* __restrict__ W, const float* __restrict__ Y, int dim, int E, int P,
+                                                               float* __restrict__ partial) {
+  constexpr int SL = 16 / RW;
+  extern __shared__ float part_s[];  // [P][16]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, bid = blockIdx.x;
+  const int r = wave % RW, sl = wave / RW;
+  const int row = bid * RW + r;
+  const int chunk = ((dim / 4 + SL - 1) / SL + 63) / 64 * 64 * 4;  // floats per column slice (router_body)
+  const int k0 = sl * chunk, k1 = min(dim, k0 + chunk);
+  const int i0 = k0 + lane * 4;
+  f32x4 wv[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    wv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (row < E && i0 + k * 256 < k1) wv[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(W + (size_t)row * dim + i0 + k * 256));
+  }
+  for (int t = 0; t < P; ++t) {
+    const float* y = Y + (size_t)t * dim;
+    float acc = 0.f;
+    if (row < E) {
+      f32x4 yv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (i0 + k * 256 < k1) yv[k] = *reinterpret_cast<const f32x4*>(y + i0 + k * 256);
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (i0 + k * 256 < k1) {
+          acc = fmaf(wv[k].x, yv[k].x, acc);
+          acc = fmaf(wv[k].y, yv[k].y, acc);
+          acc = fmaf(wv[k].z, yv[k].z, acc);
+          acc = fmaf(wv[k].w, yv[k].w, acc);
+        }
+      acc = ad::wave_sum_dpp(acc);
+    }
+    if (lane == 0) part_s[t * 16 + wave] = acc;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < P * RW; idx += 1024) {
+    const int t = idx / RW, rr = idx - t * RW;
+    if (bid * RW + rr < E) {
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < SL; ++k) v += part_s[t * 16 + k * RW + rr];  // slice order, like router_body
+      partial[(size_t)t * E + bid * RW + rr] = v;
+    }
+  }
+}
+__global__ __launch_bounds__(1024) void hyd_gate_kernel(const RouterArgs a, int K) {
+  __shared__ __attribute__((aligned(16))) float s[512];
+  __shared__ __attribute__((aligned(16))) int surv[256];
+  __shared__ float scratch[16];
+  __shared__ int sel[256];
+  const int p = blockIdx.x, tid = threadIdx.x, E = a.n_routed;
+  float v = 0.f;
+  if (tid < E) v = a.partial[(size_t)p * E + tid];
+  rd::gate_body(tid, v, a.bias, E, a.n_active, a.norm_topk_prob, a.scaling, a.scoring, a.topk_method, a.n_group, a.topk_group,
+                a.active_experts + (size_t)p * K, a.active_weights + (size_t)p * K, nullptr, s, surv, sel, scratch, 1024);
+}
 template <int RW>
 __global__ __launch_bounds__(1024) void hyd_router_kernel(const RouterArgs a0, int K) {
   RouterArgs a = a0;
@@ -390,28 +515,51 @@ __global__ __launch_bounds__(1024) void hyd_router_kernel(const RouterArgs a0, i
   if (a.q_qs) { a.q_qs += (size_t)p * dim; a.q_d += (size_t)p * (dim >> 8); a.q_bsums += (size_t)p * (dim >> 4); }
   rd::router_body<RW>(a, (int)blockIdx.x, (int)gridDim.x);
 }
-int launch_hyd_router(hipStream_t st, const RouterArgs& a, int P) {
-  if (a.ksplit >= 8) hipLaunchKernelGGL(hyd_router_kernel<2>, dim3((a.n_routed + 1) / 2, P), dim3(1024), 0, st, a, a.n_active);
+// Y: P x dim floats of scratch (the normed vectors); a.partial: P x E
+int launch_hyd_router(hipStream_t st, const RouterArgs& a, int P, float* Y) {
+  const int RW = a.ksplit >= 8 ? 2 : 4, SL = 16 / RW;
+  const int chunk = ((a.dim / 4 + SL - 1) / SL + 63) / 64 * 64 * 4;
+  const size_t lds = (size_t)P * 16 * 4;
+  if (Y && a.norm_w && a.dim % 256 == 0 && chunk <= 2048 && lds <= 60 * 1024 && a.n_routed <= 1024) {
+    hipLaunchKernelGGL(hyd_router_norm_kernel, dim3(P), dim3(1024), 0, st, a, Y);
+    if (RW == 2) hipLaunchKernelGGL(hyd_router_rows_kernel<2>, dim3((a.n_routed + 1) / 2), dim3(1024), lds, st, a.w, Y, a.dim, a.n_routed, P, a.partial);
+    else hipLaunchKernelGGL(hyd_router_rows_kernel<4>, dim3((a.n_routed + 3) / 4), dim3(1024), lds, st, a.w, Y, a.dim, a.n_routed, P, a.partial);
+    hipLaunchKernelGGL(hyd_gate_kernel, dim3(P), dim3(1024), 0, st, a, a.n_active);
+    return DSK_OK;
+  }
+  if (RW == 2) hipLaunchKernelGGL(hyd_router_kernel<2>, dim3((a.n_routed + 1) / 2, P), dim3(1024), 0, st, a, a.n_active);
   else hipLaunchKernelGGL(hyd_router_kernel<4>, dim3((a.n_routed + 3) / 4, P), dim3(1024), 0, st, a, a.n_active);
   return DSK_OK;
 }
 
-// tokens grouped by expert: list[e] = the (token, slot) pairs p * K + k routed to expert e, in pair order; count[e]
-__global__ __launch_bounds__(256) void hyd_group_kernel(const int* __restrict__ route_e, int pairs, int E, int* __restrict__ list, int list_stride,
+// tokens grouped by expert: list[e] = the (token, slot) pairs p * K + k routed to expert e, in pair order; count[e].
+// One workgroup per expert scans the pairs 256 at a time (ballot + prefix counts: the order is the pair order, deterministic).
+__global__ __launch_bounds__(256) void hyd_group_kernel(const int* __restrict__ route_e, int pairs, int* __restrict__ list, int list_stride,
                                                         int* __restrict__ count) {
-  extern __shared__ int r_s[];
-  for (int i = threadIdx.x; i < pairs; i += 256) r_s[i] = route_e[i];
-  __syncthreads();
-  for (int e = threadIdx.x; e < E; e += 256) {
-    int c = 0;
-    for (int i = 0; i < pairs; ++i)
-      if (r_s[i] == e) list[(size_t)e * list_stride + c++] = i;
-    count[e] = c;
+  __shared__ int wcnt[4];
+  const int e = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  int base = 0;
+  for (int i0 = 0; i0 < pairs; i0 += 256) {
+    const int i = i0 + tid;
+    const bool hit = i < pairs && route_e[i] == e;
+    const unsigned long long m = __ballot(hit);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wcnt[wave] = __popcll(m);
+    __syncthreads();
+    int wbase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (w < wave) wbase += wcnt[w];
+      total += wcnt[w];
+    }
+    if (hit) list[(size_t)e * list_stride + base + wbase + before] = i;
+    base += total;
+    __syncthreads();
   }
+  if (tid == 0) count[e] = base;
 }
 int launch_hyd_group(hipStream_t st, const int* route_e, int pairs, int E, int* list, int list_stride, int* count) {
-  if ((size_t)pairs * 4 > 60 * 1024) DSK_FAIL(DSK_ERR_UNSUPPORTED, "hyd_group: %d (token, slot) pairs", pairs);
-  hipLaunchKernelGGL(hyd_group_kernel, dim3(1), dim3(256), (size_t)pairs * 4, st, route_e, pairs, E, list, list_stride, count);
+  hipLaunchKernelGGL(hyd_group_kernel, dim3(E), dim3(256), 0, st, route_e, pairs, list, list_stride, count);
   return DSK_OK;
 }
 

@@ -1,0 +1,75 @@
+"""Prompt ingestion rate of dsk_hydrate on the full DeepSeek-V3 Q2_K model (61 blocks, 256 experts, tile records everywhere),
+next to the single-token rate of the same model: what the batched path buys over the reference's one forward per prompt token
+(src/main.cpp:312-319).
+
+  python tools/hydrate_bench.py [--P 16,64,128] [--layers 0] [--reps 2]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "deepseek.cpp_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def measure(ctx, c, Ps, reps=2, seed=0, chunk=128, opts=None):
+    import dsk
+    o = {"q2k_tiles": 2, "hydrate_chunk": chunk}
+    o.update(opts or {})
+    M = dsk.Model(ctx, c, None, synth_seed=seed, options=o)
+    why = M.hydrate_why_not()
+    rng = np.random.default_rng(1)
+    out = {"why_not": why, "device_gb": round(M.device_bytes() / 1e9, 1)}
+    # the loop's rate: single-token forwards in HYDRATE mode (no classifier), graph replay
+    toks = rng.integers(0, c.vocab_size, 40)
+    for i in range(8):
+        M.forward(int(toks[i]), i, dsk.MODE_HYDRATE_KV_CACHE)
+    t0 = time.perf_counter()
+    for i in range(8, 40):
+        M.forward(int(toks[i]), i, dsk.MODE_HYDRATE_KV_CACHE)
+    dt = (time.perf_counter() - t0) / 32
+    out["loop_tok_s"] = round(1.0 / dt, 1)
+    res = {}
+    for P in Ps:
+        toks = rng.integers(0, c.vocab_size, P)
+        M.hydrate(toks, 0, dsk.MODE_HYDRATE_KV_CACHE)  # warm-up (allocations, code objects)
+        best = 1e9
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            M.hydrate(toks, 0, dsk.MODE_HYDRATE_KV_CACHE)
+            best = min(best, time.perf_counter() - t0)
+        res[str(P)] = {"ms": round(best * 1e3, 3), "tok_s": round(P / best, 1), "x_loop": round(P / best * dt, 2)}
+    out["hydrate"] = res
+    out["batched_tokens"] = M.info("hydrate_batched_tokens")
+    M.close()
+    return out
+
+
+def main():
+    import dsk
+    from tools import synth
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--P", default="16,64,128")
+    ap.add_argument("--layers", type=int, default=0)
+    ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--chunk", type=int, default=128)
+    ap.add_argument("--opt", action="append", default=[])
+    a = ap.parse_args()
+    c = synth.preset("v3", "q2_k", False)
+    if a.layers:
+        c.n_layers = a.layers
+        c.first_k_dense_replace = min(c.first_k_dense_replace, a.layers)
+    c.max_seq_len = 1100
+    ctx = dsk.Ctx(0)
+    opts = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.opt}
+    print(json.dumps(measure(ctx, c, [int(p) for p in a.P.split(",")], a.reps, chunk=a.chunk, opts=opts)))
+
+
+if __name__ == "__main__":
+    main()
