@@ -435,6 +435,39 @@ def main():
             except Exception as e:  # noqa: BLE001
                 v2[q] = {"error": repr(e)[:160]}
         extras["v2lite"] = v2
+    if rank == 0 and world == 1 and not a.no_extras and not a.dry_shard and full_v3 and a.attn == "mha":
+        # the prompt phase through dsk_hydrate (batched launches, every weight read once per chunk) on the same
+        # shapes with every Q2_K matrix stored as tile records, next to the per-token loop of the same model (what the reference
+        # does with a prompt, src/main.cpp:312-319)
+        try:
+            from tools import hydrate_bench
+            c3 = synth.preset(a.model, a.quant, False)
+            if a.layers > 0:
+                c3.n_layers = a.layers
+                c3.first_k_dense_replace = min(c3.first_k_dense_replace, a.layers)
+            c3.max_seq_len = 1100
+            extras["hydrate"] = hydrate_bench.measure(ctx, c3, [16, 64, 128, 512], reps=2)
+        except Exception as e:  # noqa: BLE001
+            extras["hydrate"] = {"error": repr(e)[:160]}
+    block_floor = None
+    if rank == 0 and world == 1 and not a.no_extras and full_v3:
+        # the floor of a five-launch block on THIS chip (tools/block_floor.hip: five dependent pure-streaming kernels with the
+        # block's byte profile); built by __graft_entry__.build()
+        try:
+            import subprocess
+            exe = os.path.join(ROOT, "tools", "_build", "block_floor")
+            if os.path.exists(exe):
+                outp = subprocess.run([exe, "58"], capture_output=True, timeout=120).stdout.decode()
+                for line in outp.splitlines():
+                    if line.startswith("256 x 16 waves:"):
+                        block_floor = float(line.split(":")[1].split("us")[0])
+        except Exception:  # noqa: BLE001
+            block_floor = None
+    if roof is not None:
+        roof["block_floor_us"] = block_floor
+        if block_floor and kernels:
+            per_block = sum(kernels[k]["us_per_launch"] for k in ("gemv_qkv_a", "attn_mha", "gemv_wo", "router_gate", "moe_ffn") if k in kernels)
+            roof["block_us"] = round(per_block, 2) if per_block else None
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:

@@ -434,6 +434,12 @@ extern "C" int dsk_dseek_read_config(const char* dir, int context, dsk_config* o
 }
 
 extern "C" int dsk_model_load_dseek(dsk_ctx* ctx, const char* dir, int context, dsk_model** out, dsk_load_stats* stats) {
+  return dsk_model_load_dseek_opts(ctx, dir, context, nullptr, out, stats);
+}
+
+// ... with model options ("key=value,key=value": dsk_model_set_option between create and the first bind), e.g. "q2k_tiles=2"
+// for a checkpoint whose prompts should go through the batched dsk_hydrate path
+extern "C" int dsk_model_load_dseek_opts(dsk_ctx* ctx, const char* dir, int context, const char* options, dsk_model** out, dsk_load_stats* stats) {
   if (!ctx || !dir || !out) DSK_FAIL(DSK_ERR_INVALID, "load_dseek: null argument");
   *out = nullptr;
   const auto t0 = std::chrono::steady_clock::now();
@@ -443,6 +449,20 @@ extern "C" int dsk_model_load_dseek(dsk_ctx* ctx, const char* dir, int context, 
   DSK_TRY(config_from_meta(ck.meta, context, &c));
   dsk_model* m = nullptr;
   DSK_TRY(dsk_model_create(ctx, &c, &m));
+  for (const char* p = options; p && *p;) {  // key=value[,key=value...]
+    const char* e = strchr(p, ',');
+    const std::string kv(p, e ? (size_t)(e - p) : strlen(p));
+    const size_t eq = kv.find('=');
+    int r = DSK_ERR_INVALID;
+    if (eq != std::string::npos && eq > 0 && eq + 1 < kv.size()) r = dsk_model_set_option(m, kv.substr(0, eq).c_str(), atoi(kv.c_str() + eq + 1));
+    else dsk_set_error(DSK_ERR_INVALID, "load_dseek: malformed option '%s' (key=value expected)", kv.c_str());
+    if (r != DSK_OK) {
+      const std::string keep = dsk_last_error();
+      dsk_model_destroy(m);
+      DSK_FAIL(r, "%s", keep.c_str());
+    }
+    p = e ? e + 1 : nullptr;
+  }
   const double staged0 = ctx->staged_bytes, fill0 = ctx->staged_fill_s;
   Walk W{m, ck, m->c};
   {

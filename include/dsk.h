@@ -238,6 +238,9 @@ int dsk_dseek_read_config(const char* dir, int context, dsk_config* out, int32_t
                           uint64_t* tensor_bytes);
 /* create + bind every tensor + finalize.  `stats` may be NULL. */
 int dsk_model_load_dseek(dsk_ctx* ctx, const char* dir, int context, dsk_model** out, dsk_load_stats* stats);
+/* ... with model options applied between create and the first bind: "key=value,key=value" (dsk_model_set_option keys),
+ * e.g. "q2k_tiles=2" so that prompts take dsk_hydrate's batched path.  options may be NULL. */
+int dsk_model_load_dseek_opts(dsk_ctx* ctx, const char* dir, int context, const char* options, dsk_model** out, dsk_load_stats* stats);
 
 /* ---- the hot path (replaces Model::forward, src/model.cpp:874-883) -------- */
 /* One token.  mode == OUTPUT_LOGITS: host_logits receives vocab_size floats

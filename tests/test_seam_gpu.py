@@ -1,6 +1,7 @@
 """The drop-in seam, end to end: the reference's OWN `main`, built twice from /root/reference (oracle/Makefile `seam`):
 `oracle/_ref/main` unmodified, and `oracle/_ref/main_hip` = the same sources + integration/device_hip.patch
-(`enum class Device { CPU, HIP }`, `-d hip`: Model::forward -> dsk_forward, checkpoint -> dsk_model_load_dseek), linked
+(`enum class Device { CPU, HIP }`, `-d hip`: Model::forward -> dsk_forward, run_completion's prompt loop -> Model::hydrate ->
+dsk_hydrate, checkpoint -> dsk_model_load_dseek_opts), linked
 with deepseek.cpp_amd/libdsk_hip.so.  Tokenizer, sampler, codec, CLI and the perplexity / completion drivers are the
 reference's in both binaries (src/main.cpp:277-431); only the forward pass changes device.
 
@@ -55,7 +56,8 @@ def _completion(out: bytes):
     return out[i:j].strip(b"\n"), int(m.group(1))
 
 
-CASES = [("tiny_v3", "fp16", False), ("tiny_v3", "f8e5m2", True), ("tiny_v2lite", "fp32", False), ("tiny_v3", "q2_k", True)]
+# (the Q2_K MHA case: the patched main loads with "q2k_tiles=2" and hands the whole prompt to dsk_hydrate - the batched path)
+CASES = [("tiny_v3", "fp16", False), ("tiny_v3", "f8e5m2", True), ("tiny_v2lite", "fp32", False), ("tiny_v3", "q2_k", True), ("tiny_v3", "q2_k", False)]
 
 
 @pytest.mark.timeout(900)

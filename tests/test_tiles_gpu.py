@@ -89,18 +89,25 @@ def test_tiled_gemv_is_bit_exact_against_the_restated_association(ctx, oracle, r
     assert np.array_equal(got, want), (np.abs(got - want).max(), np.abs(want).max())
 
 
-def test_full_width_block_tiled_fused_equals_two_launch(ctx):
-    """one dense + one MoE block at DeepSeek-V3 width (256 experts, top-8, 7168 / 2048): the tiled fused expert launch
-    (kernels_moe_tile.hip: 8 steps in registers + parked steps, Q8_K hand-over) against the tiled two-launch form, bit for bit"""
+@pytest.mark.parametrize("experts,mla", [(64, False), (256, False), (256, True)], ids=["64-mha", "256-mha", "256-mla"])
+def test_full_width_block_tiled_fused_equals_two_launch(ctx, experts, mla):
+    """one dense + one MoE block at DeepSeek-V3 width (top-8, 7168 / 2048) with 64 and with ALL 256 routed experts (the benchmarked
+    count: 1.23 GB per W2 stack, the fused launch's 31-bit buffer offsets), MHA and MLA: the tiled fused expert launch
+    (kernels_moe_tile.hip: 8 steps in registers + parked steps, Q8_K hand-over) against the tiled two-launch form and against the
+    two-launch form without the shared expert's rider, bit for bit (logits and slot outputs)"""
     import dsk
-    c = synth.preset("v3", "q2_k", False, n_layers=2, first_k_dense_replace=1, n_routed_experts=64, max_seq_len=64)
+    c = synth.preset("v3", "q2_k", mla, n_layers=2, first_k_dense_replace=1, n_routed_experts=experts, max_seq_len=64)
     A = dsk.Model(ctx, c, None, synth_seed=5)
     B = dsk.Model(ctx, c, None, synth_seed=5, options={"fuse_moe": 0})
-    assert A.info("fused_moe_layers") == 1 and B.info("fused_moe_layers") == 0
+    D = dsk.Model(ctx, c, None, synth_seed=5, options={"fuse_moe": 0, "fuse_shared": 0})
+    assert A.info("fused_moe_layers") == 1 and B.info("fused_moe_layers") == 0 and D.info("fused_moe_layers") == 0
     assert A.info("tiled_tensors") > 0
     for pos, t in enumerate([3, 77, 1500, 9]):
-        la, lb = A.forward(t, pos), B.forward(t, pos)
+        la, lb, ld = A.forward(t, pos), B.forward(t, pos), D.forward(t, pos)
         assert np.array_equal(la, lb), pos
+        assert np.array_equal(la, ld), pos
         assert np.array_equal(A.slot_outputs(), B.slot_outputs()), pos
-    A.close()
-    B.close()
+        assert np.array_equal(A.slot_outputs(), D.slot_outputs()), pos
+        assert np.array_equal(A.routing()[0], B.routing()[0]), pos
+    for M in (A, B, D):
+        M.close()
