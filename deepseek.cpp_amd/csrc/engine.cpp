@@ -630,6 +630,26 @@ extern "C" int dsk_model_synthesize(dsk_model* m, uint64_t seed) {
   HIP_TRY(hipSetDevice(m->ctx->device));
   hipStream_t st = m->ctx->stream;
   const dsk_config& c = m->c;
+  // One matrix of `view` (a plain tensor, or one expert of a stack).  Tile records are filled THROUGH the plane layout - the
+  // same random planes, then re-laid-out on the device - so that a seed gives the same logical weights at every "q2k_tiles"
+  // level (the layouts used to draw from different random streams; A/B runs across levels could not double as a
+  // correctness check, and per-expert routing load differed between the compared runs).
+  auto fill_matrix = [&](const DTensor& view, uint64_t sd, float wscale) -> int {
+    if (!view.tiled) return launch_fill_tensor(st, view, sd, wscale);
+    const size_t nblk = (size_t)view.rows * (view.n / 256);
+    void* scratch = nullptr;
+    DSK_TRY(ctx_scratch(m->ctx, 7, nblk * 84, &scratch));
+    DTensor tmp = view;
+    tmp.tiled = false;
+    tmp.qs = static_cast<uint8_t*>(scratch);
+    tmp.sc = tmp.qs + nblk * 64;
+    tmp.dm = tmp.sc + nblk * 16;
+    tmp.hm = nullptr;
+    tmp.n_experts = 0; tmp.local_experts = 0; tmp.expert_base = 0;
+    tmp.e_qs = tmp.e_sc = tmp.e_hm = tmp.e_dm = 0;
+    DSK_TRY(launch_fill_tensor(st, tmp, sd, wscale));
+    return launch_planes_to_tiles_q2k(st, tmp.qs, tmp.sc, tmp.dm, 0, nblk, view.rows, view.n / 256, tile_mat_bytes(view.rows, view.n), view.qs);
+  };
   auto one = [&](int role, int layer) -> int {
     const RoleShape rs = role_shape(m, role, layer);
     if (!rs.ok) return DSK_OK;
@@ -662,7 +682,7 @@ extern "C" int dsk_model_synthesize(dsk_model* m, uint64_t seed) {
         one_e.hm = t->hm ? t->hm + (size_t)le * t->e_hm : nullptr;
         one_e.dm = t->dm ? t->dm + (size_t)le * t->e_dm : nullptr;
         one_e.scale = t->scale ? t->scale + (size_t)le * t->e_scale : nullptr;
-        DSK_TRY(launch_fill_tensor(st, one_e, s + (uint64_t)(base + le) * 0x100000001B3ull, wscale));
+        DSK_TRY(fill_matrix(one_e, s + (uint64_t)(base + le) * 0x100000001B3ull, wscale));
       }
       return DSK_OK;
     }
@@ -675,11 +695,11 @@ extern "C" int dsk_model_synthesize(dsk_model* m, uint64_t seed) {
         one_e.hm = t->hm ? t->hm + (size_t)le * t->e_hm : nullptr;
         one_e.dm = t->dm ? t->dm + (size_t)le * t->e_dm : nullptr;
         one_e.scale = t->scale ? t->scale + (size_t)le * t->e_scale : nullptr;
-        DSK_TRY(launch_fill_tensor(st, one_e, s + (uint64_t)le * 0x100000001B3ull, wscale));
+        DSK_TRY(fill_matrix(one_e, s + (uint64_t)le * 0x100000001B3ull, wscale));
       }
       return DSK_OK;
     }
-    return launch_fill_tensor(st, *t, s, wscale);
+    return fill_matrix(*t, s, wscale);
   };
   DSK_TRY(one(DSK_ROLE_EMBED, -1));
   DSK_TRY(one(DSK_ROLE_FINAL_NORM, -1));
@@ -688,6 +708,11 @@ extern "C" int dsk_model_synthesize(dsk_model* m, uint64_t seed) {
     for (int role : ALL_LAYER_ROLES) DSK_TRY(one(role, l));
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipGetLastError());
+  if (m->ctx->op_buf[7]) {  // the plane staging of fill_matrix (as large as the classifier): not kept
+    hipFree(m->ctx->op_buf[7]);
+    m->ctx->op_buf[7] = nullptr;
+    m->ctx->op_cap[7] = 0;
+  }
   return DSK_OK;
 }
 

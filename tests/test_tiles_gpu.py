@@ -111,3 +111,20 @@ def test_full_width_block_tiled_fused_equals_two_launch(ctx, experts, mla):
         assert np.array_equal(A.routing()[0], B.routing()[0]), pos
     for M in (A, B, D):
         M.close()
+
+
+def test_synthesized_weights_do_not_depend_on_the_layout(ctx):
+    """dsk_model_synthesize fills tile records THROUGH the plane layout: one seed = one logical model at every q2k_tiles
+    level, so an A/B across levels compares layouts, not models - first-token logits agree to float precision, routing identical"""
+    import dsk
+    c = synth.preset("tiny_v3", "q2_k", False)
+    outs = []
+    for level in (0, 1, 2):
+        M = dsk.Model(ctx, c, None, synth_seed=3, options={"q2k_tiles": level})
+        outs.append((M.forward(17, 0).copy(), M.routing()[0].copy()))
+        M.close()
+    scale = np.abs(outs[0][0]).max()
+    assert np.isfinite(scale) and scale > 0
+    for lo, r in outs[1:]:
+        assert np.array_equal(r, outs[0][1])
+        assert np.abs(lo - outs[0][0]).max() <= 3e-4 * scale, np.abs(lo - outs[0][0]).max() / scale
