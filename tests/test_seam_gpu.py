@@ -22,19 +22,21 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MAIN = os.path.join(ROOT, "oracle", "_ref", "main")
 MAIN_HIP = os.path.join(ROOT, "oracle", "_ref", "main_hip")
+MAIN_HIP_BIND = os.path.join(ROOT, "oracle", "_ref", "main_hip_bind")  # integration/device_hip_bind.patch: main.cpp untouched
 TEXT = "the quick brown fox jumps over the lazy dog while seven wizards mix a jolly good brew of quartz and onyx powder"
 
 
 def _need_binaries():
-    if not (os.path.exists(MAIN) and os.path.exists(MAIN_HIP)):
+    if not (os.path.exists(MAIN) and os.path.exists(MAIN_HIP) and os.path.exists(MAIN_HIP_BIND)):
         if os.path.isdir("/root/reference"):
             subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "seam"])
         else:
             pytest.skip("oracle/_ref/main(_hip) not present (built where /root/reference exists)")
 
 
-def _run(binary, d, *args):
+def _run(binary, d, *args, env_extra=None):
     env = dict(os.environ, OMP_NUM_THREADS="8")
+    env.update(env_extra or {})
     r = subprocess.run([binary, d, *args], capture_output=True, env=env, timeout=600)
     assert r.returncode == 0, (binary, args, r.stdout[-600:], r.stderr[-600:])
     return r.stdout
@@ -86,6 +88,21 @@ def test_reference_main_with_device_hip_matches_reference_main(preset, quant, ml
         # the patched binary without -d hip is the reference
         n2, ppl2 = _perplexity(_run(MAIN_HIP, d, "-m", "perplexity", "-i", TEXT))
         assert (n2, ppl2) == (n_cpu, ppl_cpu)
+        # the second form of the seam: main.cpp byte-identical, the device chosen in Model::Model (DSK_DEVICE=hip), the weights
+        # bound from the QTensors the reference's constructors hold (dsk_model_bind from the mmap: no second read of the files).
+        # Same engine, same default options as a plain dsk_model_load_dseek: for float weights the same numbers as main_hip.
+        hip_env = {"DSK_DEVICE": "hip"}
+        n3, ppl3 = _perplexity(_run(MAIN_HIP_BIND, d, "-m", "perplexity", "-i", TEXT, env_extra=hip_env))
+        t3, k3 = _completion(_run(MAIN_HIP_BIND, d, "-m", "completion", "-t", "0", "-n", "32", "-i", TEXT[:40], env_extra=hip_env))
+        assert n3 == n_cpu and k3 == k_cpu
+        rel3 = abs(ppl3 - ppl_cpu) / ppl_cpu
+        if quant in ("q2_k", "q3_k"):
+            assert rel3 < 5e-2
+        else:
+            assert rel3 < 1e-3 and t3 == t_cpu, (ppl_cpu, ppl3)
+            assert ppl3 == ppl_hip
+        n4, ppl4 = _perplexity(_run(MAIN_HIP_BIND, d, "-m", "perplexity", "-i", TEXT))  # without the variable: the reference
+        assert (n4, ppl4) == (n_cpu, ppl_cpu)
     finally:
         for f in os.listdir(d):
             os.unlink(os.path.join(d, f))
