@@ -35,7 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "deepseek.cpp_amd"))
 
-PMC_FILE = "r04_pmc.json"
+PMC_FILE = "r05_pmc.json"
 
 
 def csrc_sha() -> str:

@@ -479,6 +479,7 @@ struct HydGemmArgs {
   const int* list;        // per task: entries (null: 0 .. m - 1); count (null: m for the one task)
   const int* count;
   int list_stride, m;
+  int cnt_min, cnt_max;   // only tasks whose row count lies in [cnt_min, cnt_max] are processed (cnt_max 0: no upper bound)
   float* out;
   int out_stride;
   int epilogue, act;      // EPI_STORE / EPI_ADD (ignored for GLU pairs); DSK_ACT_*
@@ -497,6 +498,7 @@ int launch_hyd_latent_q8(hipStream_t st, const HydLatentArgs& A, int P);
 int launch_hyd_kv_write(hipStream_t st, const AttnMhaArgs& a, const StepParams* sps, int P, const float* kv_b, int kvb_stride, const float* kv_a, int kva_stride);
 int launch_hyd_attn(hipStream_t st, const AttnMhaArgs& a, const StepParams* sps, int P, int max_kv, const float* q, int q_stride, float* out, int out_stride);
 int launch_hyd_router(hipStream_t st, const RouterArgs& a, int P, float* Y);
+int launch_hyd_route_override(hipStream_t st, int* route_e, int P, int K, int E, unsigned seed);
 int launch_hyd_group(hipStream_t st, const int* route_e, int pairs, int E, int* list, int list_stride, int* count);
 int launch_hyd_combine(hipStream_t st, float* X, const float* eout, const float* w, const float* eout_sh, int P, int K, int n);
 

@@ -143,6 +143,7 @@ struct dsk_model {
   // batched prompt ingestion (hydrate.cpp): buffers allocated by the first dsk_hydrate call that takes the batched path
   struct HydState* hyd = nullptr;
   int hydrate_chunk = 128;          // option "hydrate_chunk": tokens per batched chunk
+  int hydrate_route_seed = 0;       // option "hydrate_route_seed" (measurement only): > 0 = the batched path routes every token to K uniformly drawn experts
   int hydrate_stop_layer = 0;       // option "hydrate_stop_layer" (debug): > 0: a batched chunk stops after block value - 1 (dsk_hydrate_get_buffer)
   bool hydrate_batched = true;      // option "hydrate_batched": 0 = dsk_hydrate always runs the per-token loop
   long long hydrate_batched_tokens = 0, hydrate_looped_tokens = 0;  // dsk_model_get_info

@@ -202,6 +202,8 @@ static int hyd_layer(dsk_model* m, int l, int P, int max_kv) {
     r.q_qs = h.a_x.qs; r.q_d = h.a_x.d; r.q_bsums = h.a_x.bsums;
     DSK_TRY(launch_hyd_router(st, r, P, h.hbd));  // (the dense FFN's hidden buffer holds the normed vectors: P x dim <= P x hidden_dim)
   }
+  if (m->hydrate_route_seed > 0)  // measurement only: uniform routing instead of the synthetic model's skewed one
+    DSK_TRY(launch_hyd_route_override(st, h.route_e, P, K, E, (unsigned)m->hydrate_route_seed * 1000003u + (unsigned)l));
   DSK_TRY(launch_hyd_group(st, h.route_e, P * K, E, h.list, h.cap, h.count));
   if (shn > 0) {
     DSK_TRY(hyd_gemm(m, L.t[DSK_ROLE_SHARED_W1], &L.t[DSK_ROLE_SHARED_W3], h.a_x, P, P, h.hb_sh, shn, EPI_STORE));

@@ -136,7 +136,12 @@ __global__ __launch_bounds__(SPREAD && !GLU ? 512 : 256) void hyd_gemm_kernel(co
   const size_t woff = (size_t)task * A.e_bytes + (size_t)strip * nb * TILE_B;
   const rsrc_t W1 = make_rsrc(A.W + woff);
   const rsrc_t W3 = make_rsrc(GLU ? A.W3 + woff : A.W + woff);
-  // the strip's first tiles are requested before anything is known about the task's rows (a task without rows costs one tile)
+  // expert stacks: most tasks may be outside this launch's window - look first; plain matrices: the strip's first tiles are requested
+  // before anything else
+  if (A.count) {
+    const int c0 = __builtin_amdgcn_readfirstlane(A.count[task]);
+    if (c0 <= 0 || c0 < A.cnt_min || (A.cnt_max > 0 && c0 > A.cnt_max)) return;
+  }
   HydTile T1, T3, N1, N3;
   hyd_tile_load(T1, W1, lane, 0);
   if (GLU) hyd_tile_load(T3, W3, lane, 0);
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(SPREAD && !GLU ? 512 : 256) void hyd_gemm_kernel(co
     if (GLU) hyd_tile_load(N3, W3, lane, TILE_B);
   }
   const int cnt = A.count ? __builtin_amdgcn_readfirstlane(A.count[task]) : A.m;
-  if (cnt <= 0) return;
+  if (cnt <= 0 || cnt < A.cnt_min || (A.cnt_max > 0 && cnt > A.cnt_max)) return;  // (a launch may be restricted to tasks with a row count in [cnt_min, cnt_max])
   const int* list = A.list ? A.list + (size_t)task * A.list_stride : nullptr;
   const bool seg4 = nb > 8;  // tile_seg
   const rsrc_t RA = make_rsrc_n(A.a_qs, (u32)((size_t)A.a_rows * n));
@@ -529,6 +534,31 @@ int launch_hyd_router(hipStream_t st, const RouterArgs& a, int P, float* Y) {
   }
   if (RW == 2) hipLaunchKernelGGL(hyd_router_kernel<2>, dim3((a.n_routed + 1) / 2, P), dim3(1024), 0, st, a, a.n_active);
   else hipLaunchKernelGGL(hyd_router_kernel<4>, dim3((a.n_routed + 3) / 4, P), dim3(1024), 0, st, a, a.n_active);
+  return DSK_OK;
+}
+
+// MEASUREMENT ONLY (option "hydrate_route_seed"): replace the gate's choice by K distinct experts per token drawn uniformly by a
+// hash of (seed, layer, token, slot).  The synthetic benchmark model routes most tokens of a chunk to the same ~125 experts (its
+// random router sees strongly correlated inputs), which flatters a batched prompt: a trained model balances its experts, and the
+// bytes a chunk touches are what the prompt phase is made of.  Never used by the parity tests.
+__global__ void hyd_route_override_kernel(int* __restrict__ route_e, int P, int K, int E, unsigned seed) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  for (int k = 0; k < K; ++k) {
+    unsigned h = seed * 2654435761u ^ (unsigned)(p * 7919 + k * 104729 + 1);
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    int e = (int)(h % (unsigned)E);
+    for (;;) {  // distinct within the token: linear probing
+      bool dup = false;
+      for (int j = 0; j < k; ++j) dup = dup || route_e[p * K + j] == e;
+      if (!dup) break;
+      e = (e + 1) % E;
+    }
+    route_e[p * K + k] = e;
+  }
+}
+int launch_hyd_route_override(hipStream_t st, int* route_e, int P, int K, int E, unsigned seed) {
+  hipLaunchKernelGGL(hyd_route_override_kernel, dim3((P + 63) / 64), dim3(64), 0, st, route_e, P, K, E, seed);
   return DSK_OK;
 }
 

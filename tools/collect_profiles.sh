@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round evidence, one gpurun call on one box (profiles/README.md): bench line, rocprofv3 kernel traces (MHA, MLA, kv_len 4096),
 # a PMC pass of its own for HBM traffic, SQ counters in situ, the op-level GEMV table, the in-kernel timelines, the probes.
-#   bash tools/collect_profiles.sh r04        (every step bounded by `timeout`, nothing reads stdin)
-R=${1:-r04}
+#   bash tools/collect_profiles.sh r05        (every step bounded by `timeout`, nothing reads stdin)
+R=${1:-r05}
 N="round ${R#r0} final build"
 mkdir -p gpurun_out profiles
 export TMPDIR=/tmp
@@ -23,8 +23,15 @@ $T python tools/prof_summary.py --trace gpurun_out/trace_mla --out gpurun_out/${
 $T python tools/kbench.py < /dev/null 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_kbench.txt
 $T python tools/timeline.py < /dev/null 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_timeline_mha.txt
 $T python tools/moe_timeline.py < /dev/null 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_timeline_moe.txt
-$T python tools/moe_timeline.py --opt q2k_tiles=0 < /dev/null 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_timeline_moe_planes.txt
 timeout 400 bash tools/pmc_sq.sh ${R}_final < /dev/null > /dev/null 2>&1
+# round 5: the floor of a five-launch block on this box; the prompt phase (dsk_hydrate) on the full model and its kernel trace
+timeout 120 tools/_build/block_floor 58 < /dev/null > gpurun_out/${R}_block_floor.txt 2>&1
+$T python tools/hydrate_bench.py --P 16,64,128,256,512 < /dev/null 2>&1 | grep '^{' | tail -1 > gpurun_out/${R}_hydrate.json
+cd /tmp
+timeout 240 rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/trace_hyd -- python $ROOT/tools/hydrate_bench.py --P 64 --layers 8 --reps 1 --no-loop < /dev/null > $ROOT/gpurun_out/trace_hyd.log 2>&1
+cd $ROOT
+$T python tools/prof_summary.py --trace gpurun_out/trace_hyd --out gpurun_out/${R}_hydrate --note "MI355X, $N, dsk_hydrate of 64 tokens (warm-up + one timed call) on 8 blocks (3 dense + 5 MoE) of DeepSeek-V3 Q2_K, tile records everywhere" < /dev/null >> gpurun_out/${R}_summary.log 2>&1
+rm -rf gpurun_out/trace_hyd
 # DeepSeek-V2-Lite (BASELINE configs C3) in both Q2_K layouts; the Q8_K hand-over of the fused expert launch against f32 hidden vectors
 $T python bench.py --model v2lite --steps 32 --warmup 4 --no-cpu-baseline --no-extras < /dev/null 2>&1 | grep '^{' | tail -1 > gpurun_out/${R}_bench_v2lite.json
 $T python bench.py --model v2lite --steps 32 --warmup 4 --no-cpu-baseline --no-extras --opt q2k_tiles=0 < /dev/null 2>&1 | grep '^{' | tail -1 > gpurun_out/${R}_bench_v2lite_planes.json

@@ -18,7 +18,7 @@ for p in (ROOT, os.path.join(ROOT, "deepseek.cpp_amd")):
         sys.path.insert(0, p)
 
 
-def measure(ctx, c, Ps, reps=2, seed=0, chunk=128, opts=None):
+def measure(ctx, c, Ps, reps=2, seed=0, chunk=128, opts=None, loop=True):
     import dsk
     o = {"q2k_tiles": 2, "hydrate_chunk": chunk}
     o.update(opts or {})
@@ -28,13 +28,15 @@ def measure(ctx, c, Ps, reps=2, seed=0, chunk=128, opts=None):
     out = {"why_not": why, "device_gb": round(M.device_bytes() / 1e9, 1)}
     # the loop's rate: single-token forwards in HYDRATE mode (no classifier), graph replay
     toks = rng.integers(0, c.vocab_size, 40)
-    for i in range(8):
-        M.forward(int(toks[i]), i, dsk.MODE_HYDRATE_KV_CACHE)
-    t0 = time.perf_counter()
-    for i in range(8, 40):
-        M.forward(int(toks[i]), i, dsk.MODE_HYDRATE_KV_CACHE)
-    dt = (time.perf_counter() - t0) / 32
-    out["loop_tok_s"] = round(1.0 / dt, 1)
+    dt = None
+    if loop:
+        for i in range(8):
+            M.forward(int(toks[i]), i, dsk.MODE_HYDRATE_KV_CACHE)
+        t0 = time.perf_counter()
+        for i in range(8, 40):
+            M.forward(int(toks[i]), i, dsk.MODE_HYDRATE_KV_CACHE)
+        dt = (time.perf_counter() - t0) / 32
+        out["loop_tok_s"] = round(1.0 / dt, 1)
     res = {}
     for P in Ps:
         toks = rng.integers(0, c.vocab_size, P)
@@ -44,8 +46,16 @@ def measure(ctx, c, Ps, reps=2, seed=0, chunk=128, opts=None):
             t0 = time.perf_counter()
             M.hydrate(toks, 0, dsk.MODE_HYDRATE_KV_CACHE)
             best = min(best, time.perf_counter() - t0)
-        res[str(P)] = {"ms": round(best * 1e3, 3), "tok_s": round(P / best, 1), "x_loop": round(P / best * dt, 2)}
+        res[str(P)] = {"ms": round(best * 1e3, 3), "tok_s": round(P / best, 1), "x_loop": round(P / best * dt, 2) if dt else None}
     out["hydrate"] = res
+    # distinct experts the LAST chunk's last MoE block touched (the bytes a chunk streams are proportional to it)
+    try:
+        cap = chunk
+        re = M.hydrate_buffer("route_e", (cap, max(1, c.n_active_routed)), np.int32)[:min(Ps[-1], cap)]
+        cnt = np.bincount(re.reshape(-1), minlength=c.n_routed_experts)
+        out["last_chunk_experts"] = {"distinct": int((cnt > 0).sum()), "max_tokens": int(cnt.max())}
+    except Exception as e:  # noqa: BLE001
+        out["last_chunk_experts"] = {"error": repr(e)[:80]}
     out["batched_tokens"] = M.info("hydrate_batched_tokens")
     M.close()
     return out
@@ -60,6 +70,7 @@ def main():
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--chunk", type=int, default=128)
     ap.add_argument("--opt", action="append", default=[])
+    ap.add_argument("--no-loop", action="store_true", help="skip the per-token loop (a kernel trace of the batched path only)")
     a = ap.parse_args()
     c = synth.preset("v3", "q2_k", False)
     if a.layers:
@@ -68,7 +79,7 @@ def main():
     c.max_seq_len = 1100
     ctx = dsk.Ctx(0)
     opts = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.opt}
-    print(json.dumps(measure(ctx, c, [int(p) for p in a.P.split(",")], a.reps, chunk=a.chunk, opts=opts)))
+    print(json.dumps(measure(ctx, c, [int(p) for p in a.P.split(",")], a.reps, chunk=a.chunk, opts=opts, loop=not a.no_loop)))
 
 
 if __name__ == "__main__":
