@@ -434,6 +434,7 @@ struct MlaHeadArgs {
   AttnMlaArgs a;          // q_rope (un-rotated), q_c, caches; out unused
   GemvTask twv;           // the (H * v_head_dim, lora) stack; the kernel takes rows [h * v, +v)
   int quant, b0, b1, lpr_log2, lds_act;
+  int tiled;              // Q2_K wv_b stored as tile records: the head's strips on the matrix pipe (tile_device.h)
   unsigned long long* timeline;  // debug (DSK_TIMELINE=1): 8 stamps per workgroup
   AttnMhaArgs fin;        // out (H, v), v_dim, n_heads, Q8_K outputs + counter (only these fields are used)
   // long contexts: kv_len >= flash_thresh (> 0) => the attention part is the merge of mla_flash_kernel's partials
@@ -497,6 +498,10 @@ struct HydLatentArgs {
 int launch_hyd_latent_q8(hipStream_t st, const HydLatentArgs& A, int P);
 int launch_hyd_kv_write(hipStream_t st, const AttnMhaArgs& a, const StepParams* sps, int P, const float* kv_b, int kvb_stride, const float* kv_a, int kva_stride);
 int launch_hyd_attn(hipStream_t st, const AttnMhaArgs& a, const StepParams* sps, int P, int max_kv, const float* q, int q_stride, float* out, int out_stride);
+int launch_hyd_mla_kv_write(hipStream_t st, const MlaKvArgs& kv, const StepParams* sps, int P, int kva_stride);
+int launch_hyd_mla_attn(hipStream_t st, const AttnMlaArgs& a, const StepParams* sps, int P, int max_kv, const float* q_c, int qc_stride, const float* q_rope,
+                        int qr_stride, float* latent, int lat_stride);
+int launch_hyd_head_list(hipStream_t st, int* list, int* count, int H, int P, int stride);
 int launch_hyd_router(hipStream_t st, const RouterArgs& a, int P, float* Y);
 int launch_hyd_route_override(hipStream_t st, int* route_e, int P, int K, int E, unsigned seed);
 int launch_hyd_group(hipStream_t st, const int* route_e, int pairs, int E, int* list, int list_stride, int* count);

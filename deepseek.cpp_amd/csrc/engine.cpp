@@ -349,7 +349,8 @@ static bool is_routed_role(int role) { return role == DSK_ROLE_W1 || role == DSK
 //      (kernels_moe_tile.hip: hidden vectors of <= 2048 values): same-box A/B on the full model, phase A of the fused launch
 //      16.6 -> 14.0 us, the launch 34.3 -> 34.1 us; the other converted roles are at parity or behind in the model (wo 10.9 -> 11.9 us:
 //      448 strips of 16 rows deal 2 : 1 over 256 CUs where 7168 rows deal evenly), so they stay on planes
-//   2  every converted role (experts, shared expert, dense FFN, first-stage projections, wo, embedding / classifier): tests, kbench
+//   2  every converted role (experts, shared expert, dense FFN, first-stage projections, wq_b / wkv_b or the MLA second stage and wv_b, wo,
+//      embedding / classifier): tests, kbench, and what dsk_hydrate's batched path needs
 #ifndef TILE_LEVEL_HEAD
 #define TILE_LEVEL_HEAD 2  // the q2k_tiles level from which wq_b / wkv_b are tiled
 #endif
@@ -370,6 +371,15 @@ static bool role_tiled(const dsk_model* m, int role, int e, int quant) {
       const bool ok = !c.use_mla && c.q_lora_rank > 0 && c.q_lora_rank % 256 == 0 && c.kv_lora_rank % 256 == 0 && c.q_lora_rank / 256 <= 8 &&
                       c.kv_lora_rank / 256 <= 8 && hd % 16 == 0 && nv % 16 == 0;
       return ok && m->q2k_tiles >= TILE_LEVEL_HEAD;
+    }
+    case DSK_ROLE_WQ_ROPE_B: case DSK_ROLE_WC: {  // MLA second stage (gemv_kvwrite_tile_kernel): rows of q_lora_rank values
+      const dsk_config& c = m->c;
+      return all && c.use_mla && c.q_lora_rank > 0 && c.q_lora_rank % 256 == 0;
+    }
+    case DSK_ROLE_WV_B: {  // MLA per-head value projection inside mla_head_kernel: whole 16-row strips per head, rows of <= 8 blocks
+      const dsk_config& c = m->c;
+      return all && c.use_mla && c.v_head_dim % 16 == 0 && c.kv_lora_rank % 256 == 0 && c.kv_lora_rank / 256 <= 8 &&
+             (c.v_head_dim / 16) * (c.kv_lora_rank / 256) <= 64;
     }
     default: return false;
   }

@@ -231,6 +231,7 @@ int build_plans(dsk_model* m) {
       memset(&A, 0, sizeof A);
       A.quant = wq; A.b0 = std::max(1, c.block_size[0]); A.b1 = std::max(1, c.block_size[1]);
       A.twv = m->plans[m->lp_wv_b[l]].t[0];
+      A.tiled = m->plans[m->lp_wv_b[l]].tiled;
       A.timeline = m->timeline_of(1);
       A.a.q_rope = m->q_rope; A.a.q_c = m->q_c; A.a.kv_a = m->kv_a; A.a.nope_cache = L.nope_cache; A.a.rope_cache = L.rope_cache;
       A.a.out = m->att_out; A.a.n_heads = H; A.a.head_dim = m->head_dim; A.a.rope = c.qk_rope_head_dim; A.a.lora = c.kv_lora_rank;

@@ -39,7 +39,9 @@ struct HydState {
   int cap = 0;
   float *X = nullptr, *q_a = nullptr, *kv_a = nullptr, *q = nullptr, *kv_b = nullptr, *att = nullptr, *hbd = nullptr, *hb = nullptr,
         *hb_sh = nullptr, *eout = nullptr, *eout_sh = nullptr, *route_w = nullptr, *router_partial = nullptr, *trace = nullptr;
-  HydQ8 a_x, a_qa, a_kva, a_att, a_hd, a_hb, a_hsh;
+  HydQ8 a_x, a_qa, a_kva, a_att, a_hd, a_hb, a_hsh, a_lat;
+  float *q_rope = nullptr, *q_c = nullptr, *latent = nullptr;  // MLA: (P, H * rope), (P, H * lora), (P, H * lora)
+  int *head_list = nullptr, *head_count = nullptr;              // MLA: wv_b as one GEMM task per head
   StepParams *sp = nullptr, *sp_host = nullptr;
   unsigned* router_counter = nullptr;
   int *route_e = nullptr, *list = nullptr, *count = nullptr;
@@ -72,8 +74,9 @@ void hydrate_free(dsk_model* m) {
 static const char* hyd_why_not(const dsk_model* m) {
   const dsk_config& c = m->c;
   if (c.weight_quant != DSK_QUANT_Q2_K) return "weights are not Q2_K";
-  if (c.use_mla) return "MLA attention";
   if (c.q_lora_rank <= 0) return "no q latent";
+  if (c.use_mla && (c.kv_lora_rank > 512 || c.kv_lora_rank % 64 || c.qk_rope_head_dim > 64 || c.qk_rope_head_dim % 4 || c.v_head_dim % 16))
+    return "MLA head shapes";
   if (m->sharded()) return "expert-sharded model";
   if (c.dim % 256 || (c.n_heads * c.v_head_dim) % 256 || c.hidden_dim % 256) return "vector lengths";
   if (m->head_dim > 256 || c.v_head_dim > 256 || (c.v_head_dim & 3) || (m->head_dim & 3)) return "head dims";
@@ -82,8 +85,15 @@ static const char* hyd_why_not(const dsk_model* m) {
   auto tiled = [&](const Layer& L, int role) { return L.t[role].bound() && L.t[role].tiled; };
   for (int l = 0; l < c.n_layers; ++l) {
     const Layer& L = m->L[l];
-    for (int role : {DSK_ROLE_WQ_A, DSK_ROLE_WKV_A, DSK_ROLE_WQ_B, DSK_ROLE_WKV_B, DSK_ROLE_WO, DSK_ROLE_W1, DSK_ROLE_W2, DSK_ROLE_W3})
+    for (int role : {DSK_ROLE_WQ_A, DSK_ROLE_WKV_A, DSK_ROLE_WO, DSK_ROLE_W1, DSK_ROLE_W2, DSK_ROLE_W3})
       if (!tiled(L, role)) return "a Q2_K matrix is not stored as tile records (set option q2k_tiles = 2 before binding)";
+    if (c.use_mla) {
+      for (int role : {DSK_ROLE_WQ_ROPE_B, DSK_ROLE_WC, DSK_ROLE_WV_B})
+        if (!tiled(L, role)) return "an MLA projection is not stored as tile records (set option q2k_tiles = 2 before binding)";
+    } else {
+      for (int role : {DSK_ROLE_WQ_B, DSK_ROLE_WKV_B})
+        if (!tiled(L, role)) return "a Q2_K matrix is not stored as tile records (set option q2k_tiles = 2 before binding)";
+    }
     if (L.is_moe && c.n_shared_experts > 0)
       for (int role : {DSK_ROLE_SHARED_W1, DSK_ROLE_SHARED_W2, DSK_ROLE_SHARED_W3})
         if (!tiled(L, role)) return "the shared expert is not stored as tile records";
@@ -106,8 +116,18 @@ static int hyd_ensure(dsk_model* m) {
   DSK_TRY(hyd_alloc(h, (void**)&h->X, P * dim * 4, &tot));
   DSK_TRY(hyd_alloc(h, (void**)&h->q_a, P * c.q_lora_rank * 4, &tot));
   DSK_TRY(hyd_alloc(h, (void**)&h->kv_a, P * (c.kv_lora_rank + c.qk_rope_head_dim) * 4, &tot));
-  DSK_TRY(hyd_alloc(h, (void**)&h->q, P * H * hd * 4, &tot));
-  DSK_TRY(hyd_alloc(h, (void**)&h->kv_b, P * H * nv * 4, &tot));
+  if (c.use_mla) {
+    const size_t lora = c.kv_lora_rank;
+    DSK_TRY(hyd_alloc(h, (void**)&h->q_rope, P * H * c.qk_rope_head_dim * 4, &tot));
+    DSK_TRY(hyd_alloc(h, (void**)&h->q_c, P * H * lora * 4, &tot));
+    DSK_TRY(hyd_alloc(h, (void**)&h->latent, P * H * lora * 4, &tot));
+    DSK_TRY(hyd_alloc_q8(h, h->a_lat, P * H, lora, &tot));
+    DSK_TRY(hyd_alloc(h, (void**)&h->head_list, H * P * 4, &tot));
+    DSK_TRY(hyd_alloc(h, (void**)&h->head_count, H * 4, &tot));
+  } else {
+    DSK_TRY(hyd_alloc(h, (void**)&h->q, P * H * hd * 4, &tot));
+    DSK_TRY(hyd_alloc(h, (void**)&h->kv_b, P * H * nv * 4, &tot));
+  }
   DSK_TRY(hyd_alloc(h, (void**)&h->att, P * H * vd * 4, &tot));
   DSK_TRY(hyd_alloc(h, (void**)&h->hbd, P * std::max<size_t>(c.hidden_dim, dim) * 4, &tot));  // (also the router's normed vectors)
   DSK_TRY(hyd_alloc(h, (void**)&h->hb, P * K * mi * 4, &tot));
@@ -161,7 +181,30 @@ static int hyd_layer(dsk_model* m, int l, int P, int max_kv) {
   DSK_TRY(launch_hyd_norm_q8(st, m->plans[m->lp_qkv_a[l]].NW, h.X, P, dim, f32w(L.t[DSK_ROLE_ATTN_NORM]), c.norm_eps, h.a_x.qs, h.a_x.d, h.a_x.bsums));
   DSK_TRY(hyd_gemm(m, L.t[DSK_ROLE_WQ_A], nullptr, h.a_x, P, P, h.q_a, qlr, EPI_STORE));
   DSK_TRY(hyd_gemm(m, L.t[DSK_ROLE_WKV_A], nullptr, h.a_x, P, P, h.kv_a, kvl + rope, EPI_STORE));
-  {
+  if (c.use_mla) {
+    // second stage on norm(q_a): wq_rope_b, wc (the prologue of gemv_kvwrite_tile_kernel: stage_q8 at that plan's workgroup size)
+    DSK_TRY(launch_hyd_norm_q8(st, m->plans[m->lp_qkv_b[l]].NW, h.q_a, P, qlr, f32w(L.t[DSK_ROLE_Q_A_NORM]), c.norm_eps, h.a_qa.qs, h.a_qa.d, h.a_qa.bsums));
+    DSK_TRY(hyd_gemm(m, L.t[DSK_ROLE_WQ_ROPE_B], nullptr, h.a_qa, P, P, h.q_rope, H * rope, EPI_STORE));
+    DSK_TRY(hyd_gemm(m, L.t[DSK_ROLE_WC], nullptr, h.a_qa, P, P, h.q_c, H * kvl, EPI_STORE));
+    MlaKvArgs kv;
+    kv.kv_a = h.kv_a; kv.norm_w = f32w(L.t[DSK_ROLE_KV_A_NORM]); kv.eps = c.norm_eps;
+    kv.nope_cache = L.nope_cache; kv.rope_cache = L.rope_cache; kv.lora = kvl; kv.rope = rope; kv.is_v3 = c.has_moegate_bias;
+    DSK_TRY(launch_hyd_mla_kv_write(st, kv, h.sp, P, kvl + rope));
+    const AttnMlaArgs& am = m->mla_head[l].a;
+    DSK_TRY(launch_hyd_mla_attn(st, am, h.sp, P, max_kv, h.q_c, H * kvl, h.q_rope, H * rope, h.latent, H * kvl));
+    DSK_TRY(launch_quantize_q8k(st, h.latent, P * H * kvl, h.a_lat.qs, h.a_lat.d, h.a_lat.bsums));
+    {  // per-head wv_b (src/infer.cpp:1134-1137): one task per head over all tokens
+      const DTensor& wv = L.t[DSK_ROLE_WV_B];
+      DSK_TRY(launch_hyd_head_list(st, h.head_list, h.head_count, H, P, h.cap));
+      HydGemmArgs A;
+      memset(&A, 0, sizeof A);
+      A.W = wv.qs; A.e_bytes = tile_mat_bytes(vd, kvl); A.n_experts = H; A.rows = vd; A.n = kvl;
+      A.a_qs = h.a_lat.qs; A.a_d = h.a_lat.d; A.a_bsums = h.a_lat.bsums; A.a_rows = P * H; A.a_div = 1;
+      A.list = h.head_list; A.count = h.head_count; A.list_stride = h.cap;
+      A.out = h.att; A.out_stride = vd; A.epilogue = EPI_STORE; A.act = c.act;
+      DSK_TRY(launch_hyd_gemm(st, A, P <= 4 ? 1 : 2));
+    }
+  } else {
     HydLatentArgs A;
     memset(&A, 0, sizeof A);
     A.q_a = h.q_a; A.kv_a = h.kv_a; A.q_norm = f32w(L.t[DSK_ROLE_Q_A_NORM]); A.kv_norm = f32w(L.t[DSK_ROLE_KV_A_NORM]);
@@ -169,12 +212,12 @@ static int hyd_layer(dsk_model* m, int l, int P, int max_kv) {
     A.qq_qs = h.a_qa.qs; A.qq_d = h.a_qa.d; A.qq_bsums = h.a_qa.bsums;
     A.kq_qs = h.a_kva.qs; A.kq_d = h.a_kva.d; A.kq_bsums = h.a_kva.bsums;
     DSK_TRY(launch_hyd_latent_q8(st, A, P));
+    DSK_TRY(hyd_gemm(m, L.t[DSK_ROLE_WQ_B], nullptr, h.a_qa, P, P, h.q, H * hd, EPI_STORE));
+    DSK_TRY(hyd_gemm(m, L.t[DSK_ROLE_WKV_B], nullptr, h.a_kva, P, P, h.kv_b, H * nv, EPI_STORE));
+    const AttnMhaArgs& a = m->head_attn[l].a;
+    DSK_TRY(launch_hyd_kv_write(st, a, h.sp, P, h.kv_b, H * nv, h.kv_a, kvl + rope));
+    DSK_TRY(launch_hyd_attn(st, a, h.sp, P, max_kv, h.q, H * hd, h.att, H * vd));
   }
-  DSK_TRY(hyd_gemm(m, L.t[DSK_ROLE_WQ_B], nullptr, h.a_qa, P, P, h.q, H * hd, EPI_STORE));
-  DSK_TRY(hyd_gemm(m, L.t[DSK_ROLE_WKV_B], nullptr, h.a_kva, P, P, h.kv_b, H * nv, EPI_STORE));
-  const AttnMhaArgs& a = m->head_attn[l].a;
-  DSK_TRY(launch_hyd_kv_write(st, a, h.sp, P, h.kv_b, H * nv, h.kv_a, kvl + rope));
-  DSK_TRY(launch_hyd_attn(st, a, h.sp, P, max_kv, h.q, H * hd, h.att, H * vd));
   DSK_TRY(launch_quantize_q8k(st, h.att, P * H * vd, h.a_att.qs, h.a_att.d, h.a_att.bsums));
   DSK_TRY(hyd_gemm(m, L.t[DSK_ROLE_WO], nullptr, h.a_att, P, P, h.X, dim, EPI_ADD));
   // ---- FFN half (src/infer.cpp:836-931) ----
@@ -274,7 +317,10 @@ extern "C" int dsk_hydrate(dsk_model* m, const int32_t* tokens, int n_tokens, in
   if (!why) {
     DSK_TRY(hyd_ensure(m));
     // positions before the ring wraps (src/infer.cpp:1271-1277: from pos >= W on the sink keys are rotated in place, token by token)
-    const int limit = std::min(m->c.max_seq_len, std::max(1, m->c.rs_original_max_position_embeddings));
+    int limit = std::min(m->c.max_seq_len, std::max(1, m->c.rs_original_max_position_embeddings));
+    // MLA: from mla_flash_min_kv cached positions on the decode path scores on the matrix cores (mla_flash_kernel: its own
+    // association); the batched path reproduces the short-context kernel only
+    if (m->c.use_mla && m->fl_part_o) limit = std::min(limit, std::max(1, m->mla_flash_min_kv - 1));
     int last_P = 0;
     while (done < n_tokens) {
       const int P = std::min(std::min(m->hyd->cap, n_tokens - done), limit - (pos0 + done));

@@ -887,10 +887,12 @@ __global__ __launch_bounds__(1024) void mla_head_kernel(const MlaHeadArgs A, con
   if (tl && tid == 0) tl[2] = wall_clock64();
   // ---- this head's wv_b rows on the latent output (src/infer.cpp:1134-1137) ----
   const int vd = A.fin.v_dim;
+  const bool wv_tiled = QT == DSK_QUANT_Q2_K && A.tiled;
   if constexpr (KQ) {
     if (wave < (lora >> 8)) {  // Q8_K of o_s: one 256-block per wave
       float v[4] = {o_s[wave * 256 + lane * 4], o_s[wave * 256 + lane * 4 + 1], o_s[wave * 256 + lane * 4 + 2], o_s[wave * 256 + lane * 4 + 3]};
-      q8k_block_lds<QT == DSK_QUANT_Q2_K>(v, lane, act + (size_t)wave * 4 * ITEM_LDS);
+      if (wv_tiled) q8k_block_lds<LAY_TILE>(v, lane, act + (size_t)wave * TREC);
+      else q8k_block_lds<QT == DSK_QUANT_Q2_K>(v, lane, act + (size_t)wave * 4 * ITEM_LDS);
     }
   } else {
     for (int i = tid; i < lora; i += NT) reinterpret_cast<float*>(act)[i] = o_s[i];
@@ -899,10 +901,34 @@ __global__ __launch_bounds__(1024) void mla_head_kernel(const MlaHeadArgs A, con
 #ifndef DSK_NO_TAPS
   if (A.tap_o) {  // parity tap: this head's latent output and the Q8_K vector staged for wv_b
     for (int i = tid; i < lora; i += NT) A.tap_o[(size_t)h * lora + i] = o_s[i];
-    if constexpr (KQ) dump_staged_q8<QT == DSK_QUANT_Q2_K>(act, lora, A.tap_qs + (size_t)h * lora, A.tap_d + (size_t)h * (lora >> 8), tid, NT);
+    if constexpr (KQ) {
+      if (wv_tiled) dump_staged_q8<LAY_TILE>(act, lora, A.tap_qs + (size_t)h * lora, A.tap_d + (size_t)h * (lora >> 8), tid, NT);
+      else dump_staged_q8<QT == DSK_QUANT_Q2_K>(act, lora, A.tap_qs + (size_t)h * lora, A.tap_d + (size_t)h * (lora >> 8), tid, NT);
+    }
   }
 #endif
-  {
+  if (wv_tiled) {
+    // Tiled wv_b (tile_device.h): head h's v_dim / 16 strips x lora / 256 blocks as one list of steps (rows of <= 8 blocks: one item per
+    // block), one or more per wave, partials in LDS (`part` is free again), one wave per strip adds them in the fixed order
+    if constexpr (QT == DSK_QUANT_Q2_K) {
+      const TLane TL = tlane_init(lane);
+      const int nb = lora >> 8, strips = vd >> 4, J = strips * nb;
+      const rsrc_t Wv = make_rsrc(A.twv.qs);
+      for (int j = wave; j < J; j += NW) {
+        const int st = j / nb, b = j - st * nb;
+        TStep S;
+        tstep_load(S, Wv, TL, ((h * strips + st) * nb + b) * TILE_B);
+        float ad_ = 0.f, am_ = 0.f;
+        tstep_mac(S, act + (size_t)b * TREC, TL, ad_, am_);
+        part[(size_t)j * 64 + lane] = titem_value(ad_, am_, TL);
+      }
+      __syncthreads();
+      for (int st = wave; st < strips; st += NW) {
+        const float v = tile_strip_value(part + (size_t)st * nb * 64, nb, lane);
+        if (lane < 16) out_s[st * 16 + lane] = v;
+      }
+    }
+  } else {
     const int lpr_log2 = A.lpr_log2, RPW = 64 >> lpr_log2;
     const int rloc = lane >> lpr_log2, sub = lane & ((1 << lpr_log2) - 1);
     const WPtr P = resolve(A.twv);

@@ -422,6 +422,177 @@ int launch_hyd_attn(hipStream_t st, const AttnMhaArgs& a, const StepParams* sps,
 }
 
 // ------------------------------------------------------------------------------------
+// MLA (src/infer.cpp:1051-1141): the latent's cache entries of the P positions (one workgroup per token running the decode
+// launch's own mla_kv_write_body), then per (head, token) the attention of mla_head_kernel's short-context path - rope of q_rope,
+// scores over the shared latent cache, softmax, the latent value mix - leaving the head's latent output; the per-head wv_b rows
+// are a block-diagonal GEMM over all tokens afterwards (launch_hyd_gemm with one task per head).  The code below is the decode
+// kernel's (kernels_gemv.hip mla_head_kernel, `!merged` branch), statement for statement: the same trees, the same bits.
+// Contexts from MLA_FLASH_MIN_KV positions on take the matrix-core path in decode (its own association): the host keeps such
+// positions out of the batched path.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void hyd_mla_kv_write_kernel(MlaKvArgs kv, const StepParams* __restrict__ sps, int kva_stride) {
+  const int p = blockIdx.x;
+  kv.kv_a += (size_t)p * kva_stride;
+  rd::mla_kv_write_body(kv, sps + p, threadIdx.x, 1024);
+}
+__global__ __launch_bounds__(1024) void hyd_mla_attn_kernel(const AttnMlaArgs a, const StepParams* __restrict__ sps, const float* __restrict__ q_c,
+                                                            int qc_stride, const float* __restrict__ q_rope, int qr_stride, float* __restrict__ latent,
+                                                            int lat_stride) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ float scratch[16];
+  __shared__ __attribute__((aligned(16))) float q_s[768];    // q_c | rotated q_rope
+  __shared__ __attribute__((aligned(16))) float part[4096];
+  constexpr int NT = 1024, NW = 16;
+  typedef ad::f16x4 h4;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int grp = lane >> 4, sl = lane & 15;
+  const int h = blockIdx.x, p = blockIdx.y;
+  const StepParams* sp = sps + p;
+  const int lora = a.lora, rope = a.rope, kv_len = sp->kv_len;
+  float* att = reinterpret_cast<float*>(smem);
+  const int nj = lora >> 6;
+  h4 kc[2][8], kr[2];
+  auto request_rows = [&](int t0) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int t = t0 + u * 4 + grp;
+      if (t < kv_len) {
+        const uint16_t* c = a.nope_cache + (size_t)t * lora;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j < nj) kc[u][j] = *reinterpret_cast<const h4*>(c + 64 * j + sl * 4);
+        if (sl * 4 < rope) kr[u] = *reinterpret_cast<const h4*>(a.rope_cache + (size_t)t * rope + sl * 4);
+      }
+    }
+  };
+  request_rows(wave * 8);
+  // ---- q: latent part as is, rope part rotated (src/infer.cpp:1075-1084) ----
+  for (int i = tid; i < lora; i += NT) q_s[i] = q_c[(size_t)p * qc_stride + (size_t)h * lora + i];
+  if (tid < rope / 2) {
+    const float* qr = q_rope + (size_t)p * qr_stride + (size_t)h * rope;
+    const float v0 = qr[2 * tid], v1 = qr[2 * tid + 1];
+    const float c = sp->rope_cs[2 * tid], s = sp->rope_cs[2 * tid + 1];
+    float re, im;
+    ad::rope_rot(v0, v1, c, s, re, im);
+    if (a.is_v3) {
+      q_s[lora + 2 * tid] = re;
+      q_s[lora + 2 * tid + 1] = im;
+    } else {
+      q_s[lora + tid] = re;
+      q_s[lora + tid + rope / 2] = im;
+    }
+  }
+  __syncthreads();
+  // ---- scores: 16 lanes per position, 2 positions per group and step ----
+  float qv[8][4], qr4[4];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qv[j][i] = j < nj ? q_s[64 * j + sl * 4 + i] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) qr4[i] = sl * 4 + i < rope ? q_s[lora + sl * 4 + i] : 0.f;
+  const float inv = sqrtf((float)a.head_dim);
+  for (int t0 = wave * 8; t0 < kv_len; t0 += NW * 8) {
+    if (t0 != wave * 8) request_rows(t0);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int t = t0 + u * 4 + grp;
+      float pp = 0.f;
+      if (t < kv_len) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j < nj) {
+            pp = fmaf(qv[j][0], (float)kc[u][j].x, pp);
+            pp = fmaf(qv[j][1], (float)kc[u][j].y, pp);
+            pp = fmaf(qv[j][2], (float)kc[u][j].z, pp);
+            pp = fmaf(qv[j][3], (float)kc[u][j].w, pp);
+          }
+        if (sl * 4 < rope) {
+          pp = fmaf(qr4[0], (float)kr[u].x, pp);
+          pp = fmaf(qr4[1], (float)kr[u].y, pp);
+          pp = fmaf(qr4[2], (float)kr[u].z, pp);
+          pp = fmaf(qr4[3], (float)kr[u].w, pp);
+        }
+      }
+      pp = ad::row16_sum(pp);
+      if (sl == 0 && t < kv_len) att[t] = pp / inv;
+    }
+  }
+  __syncthreads();
+  // ---- softmax (src/infer.cpp:472-487) ----
+  float mx = -INFINITY;
+  for (int t = tid; t < kv_len; t += NT) mx = fmaxf(mx, att[t]);
+  mx = ad::block_max(mx, scratch, tid, NT);
+  float sum = 0.f;
+  for (int t = tid; t < kv_len; t += NT) {
+    const float e = expf(att[t] - mx);
+    att[t] = e;
+    sum += e;
+  }
+  sum = ad::block_sum(sum, scratch, tid, NT);
+  for (int t = tid; t < kv_len; t += NT) att[t] = att[t] / sum;
+  __syncthreads();
+  // ---- latent values: lora / 4 threads per position, NT / (lora / 4) positions in flight, 4 rows per thread ----
+  {
+    const int tpp = lora >> 2, TG = NT / tpp;
+    const int g = tid / tpp, i4 = tid - g * tpp;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g < TG) {
+      for (int t0 = g; t0 < kv_len; t0 += 4 * TG) {
+        h4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (t0 + k * TG < kv_len) v[k] = *reinterpret_cast<const h4*>(a.nope_cache + (size_t)(t0 + k * TG) * lora + i4 * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (t0 + k * TG < kv_len) {
+            const float w = att[t0 + k * TG];
+            acc[0] = fmaf(w, (float)v[k].x, acc[0]);
+            acc[1] = fmaf(w, (float)v[k].y, acc[1]);
+            acc[2] = fmaf(w, (float)v[k].z, acc[2]);
+            acc[3] = fmaf(w, (float)v[k].w, acc[3]);
+          }
+      }
+      *reinterpret_cast<f32x4*>(part + (size_t)g * lora + i4 * 4) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    }
+    __syncthreads();
+    if (tid < lora) {
+      float o = 0.f;
+      for (int gg = 0; gg < TG; ++gg) o += part[gg * lora + tid];
+      latent[(size_t)p * lat_stride + (size_t)h * lora + tid] = o;
+    }
+  }
+}
+// list[h][p] = p * H + h (the rows of head h in the (token, head)-major latent array), count[h] = P: wv_b as one task per head
+__global__ void hyd_head_list_kernel(int* __restrict__ list, int* __restrict__ count, int H, int P, int stride) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < H * P) {
+    const int h = i / P, p = i - h * P;
+    list[(size_t)h * stride + p] = p * H + h;
+  }
+  if (i < H) count[i] = P;
+}
+int launch_hyd_mla_kv_write(hipStream_t st, const MlaKvArgs& kv, const StepParams* sps, int P, int kva_stride) {
+  if (kv.rope > 128 || (kv.rope & 1)) DSK_FAIL(DSK_ERR_UNSUPPORTED, "rope dim %d (max 128, even)", kv.rope);
+  hipLaunchKernelGGL(hyd_mla_kv_write_kernel, dim3(P), dim3(1024), 0, st, kv, sps, kva_stride);
+  return DSK_OK;
+}
+int launch_hyd_mla_attn(hipStream_t st, const AttnMlaArgs& a, const StepParams* sps, int P, int max_kv, const float* q_c, int qc_stride, const float* q_rope,
+                        int qr_stride, float* latent, int lat_stride) {
+  if (a.lora > 512 || a.lora % 64 || a.rope > 64 || a.rope % 4) DSK_FAIL(DSK_ERR_UNSUPPORTED, "hyd_mla_attn: kv_lora_rank %d / rope %d", a.lora, a.rope);
+  const size_t lds = (size_t)max_kv * 4;
+  if (lds > 96 * 1024) DSK_FAIL(DSK_ERR_UNSUPPORTED, "hyd_mla_attn: kv_len %d does not fit LDS", max_kv);
+  auto k = hyd_mla_attn_kernel;
+  if (lds > 32 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k, dim3(a.n_heads, P), dim3(1024), lds, st, a, sps, q_c, qc_stride, q_rope, qr_stride, latent, lat_stride);
+  return DSK_OK;
+}
+int launch_hyd_head_list(hipStream_t st, int* list, int* count, int H, int P, int stride) {
+  hipLaunchKernelGGL(hyd_head_list_kernel, dim3((H * P + 255) / 256), dim3(256), 0, st, list, count, H, P, stride);
+  return DSK_OK;
+}
+
+// ------------------------------------------------------------------------------------
 // router + gate of P tokens (src/infer.cpp:839-851, 493-599).  The decode launch (router_device.h router_body) recomputes the
 // norm and re-reads the 7.3 MB of router weights per token; here
 //   1. hyd_router_norm_kernel  per token: the router's own rmsnorm scale (router_norm_scale: the 1024-thread tree), the normed

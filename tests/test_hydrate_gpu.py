@@ -20,7 +20,10 @@ def _caches(M, c, n_rows):
     H, hd, vd = c.n_heads, c.qk_nope_head_dim + c.qk_rope_head_dim, c.v_head_dim
     out = []
     for l in range(c.n_layers):
-        out.append((M.get_cache_rows(l, "k_cache", 0, n_rows, H * hd), M.get_cache_rows(l, "v_cache", 0, n_rows, H * vd)))
+        if c.use_mla:
+            out.append((M.get_cache_rows(l, "nope_cache", 0, n_rows, c.kv_lora_rank), M.get_cache_rows(l, "rope_cache", 0, n_rows, c.qk_rope_head_dim)))
+        else:
+            out.append((M.get_cache_rows(l, "k_cache", 0, n_rows, H * hd), M.get_cache_rows(l, "v_cache", 0, n_rows, H * vd)))
     return out
 
 
@@ -93,22 +96,25 @@ def _assert_identical(res, P, pos0):
     assert res["logits_equal"], res["logits_err"]
 
 
+@pytest.mark.parametrize("mla", [False, True], ids=["mha", "mla"])
 @pytest.mark.parametrize("P,pos0,chunk", [(1, 0, None), (2, 0, None), (5, 3, None), (16, 0, None), (17, 0, None), (37, 5, None), (37, 0, 16), (48, 9, 7)])
-def test_hydrate_equals_the_loop_tiny(ctx, P, pos0, chunk):
-    """tiny DeepSeek-V3 Q2_K MHA model (1 dense + 2 MoE blocks, 16 experts top-4, rows of <= 8 blocks: single-block items):
+def test_hydrate_equals_the_loop_tiny(ctx, P, pos0, chunk, mla):
+    """tiny DeepSeek-V3 Q2_K model, MHA and MLA (1 dense + 2 MoE blocks, 16 experts top-4, rows of <= 8 blocks: single-block items):
     token quads that are full, ragged and single; chunks that split the prompt (attention over rows an earlier chunk wrote)"""
-    c = synth.preset("tiny_v3", "q2_k", False)
+    c = synth.preset("tiny_v3", "q2_k", mla)
     T = synth.synth_model(c, seed=41)
     rng = np.random.default_rng(P * 31 + pos0)
     tokens = rng.integers(0, c.vocab_size, P)
     _assert_identical(compare_hydrate(ctx, c, T, tokens=tokens, pos0=pos0, chunk=chunk), P, pos0)
 
 
+@pytest.mark.parametrize("mla", [False, True], ids=["mha", "mla"])
 @pytest.mark.parametrize("P,pos0", [(1, 0), (16, 0), (37, 2), (128, 0)])
-def test_hydrate_equals_the_loop_v3_width(ctx, P, pos0):
+def test_hydrate_equals_the_loop_v3_width(ctx, P, pos0, mla):
     """1 dense + 1 MoE block at DeepSeek-V3 width (dim 7168: 4-block items with a full last item; wo's 64-block rows; 2048-wide
-    hidden vectors: single-block items), 256 routed experts top-8 in 8 groups, weights synthesised in HBM"""
-    c = synth.preset("v3", "q2_k", False, n_layers=2, first_k_dense_replace=1, max_seq_len=192)
+    hidden vectors: single-block items), 256 routed experts top-8 in 8 groups, 128 heads, MHA and MLA (absorbed weights: wc of
+    65536 rows, per-head wv_b), weights synthesised in HBM"""
+    c = synth.preset("v3", "q2_k", mla, n_layers=2, first_k_dense_replace=1, max_seq_len=192)
     rng = np.random.default_rng(P)
     tokens = rng.integers(0, c.vocab_size, P)
     _assert_identical(compare_hydrate(ctx, c, None, seed=11, tokens=tokens, pos0=pos0), P, pos0)
@@ -133,9 +139,32 @@ def test_hydrate_across_the_ring_wrap_takes_the_loop_there(ctx):
     B.close()
 
 
-@pytest.mark.parametrize("quant,mla,level", [("f8e5m2", False, 2), ("q2_k", True, 2), ("q2_k", False, 1), ("q3_k", False, 2)])
+def test_mla_batches_up_to_the_matrix_core_regime(ctx):
+    """MLA at DeepSeek-V3 width: from mla_flash_min_kv (320) cached positions on decode scores on the matrix cores - another
+    association - so dsk_hydrate batches positions below and loops from there; the result is the loop's either way"""
+    import dsk
+    c = synth.preset("v3", "q2_k", True, n_layers=2, first_k_dense_replace=1, max_seq_len=352)
+    tokens = [(17 * i + 3) % c.vocab_size for i in range(40)]
+    pre = [(5 * i + 1) % c.vocab_size for i in range(300)]
+    A = dsk.Model(ctx, c, None, synth_seed=13, options={"q2k_tiles": 2})
+    B = dsk.Model(ctx, c, None, synth_seed=13, options={"q2k_tiles": 2})
+    assert B.hydrate_why_not() == ""
+    _loop(A, pre, 0)
+    B.hydrate(pre, 0, dsk.MODE_HYDRATE_KV_CACHE)
+    assert B.info("hydrate_batched_tokens") == 300
+    la, _ = _loop(A, tokens, 300)
+    lb = B.hydrate(tokens, 300, dsk.MODE_OUTPUT_LOGITS)
+    assert B.info("hydrate_batched_tokens") == 319 and B.info("hydrate_looped_tokens") == 21
+    assert np.array_equal(la, lb)
+    for (ka, va), (kb, vb) in zip(_caches(A, c, 340), _caches(B, c, 340)):
+        assert np.array_equal(ka, kb) and np.array_equal(va, vb)
+    A.close()
+    B.close()
+
+
+@pytest.mark.parametrize("quant,mla,level", [("f8e5m2", False, 2), ("q2_k", True, 1), ("q2_k", False, 1), ("q3_k", False, 2)])
 def test_models_that_do_not_qualify_run_the_loop(ctx, quant, mla, level):
-    """float weights, MLA, the default plane layout, Q3_K: dsk_hydrate IS the loop there (and says why)"""
+    """float weights, the default plane layout (MHA and MLA), Q3_K: dsk_hydrate IS the loop there (and says why)"""
     import dsk
     c = synth.preset("tiny_v3", quant, mla)
     T = synth.synth_model(c, seed=47)
