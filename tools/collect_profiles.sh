@@ -23,10 +23,12 @@ $T python tools/prof_summary.py --trace gpurun_out/trace_mla --out gpurun_out/${
 $T python tools/kbench.py < /dev/null 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_kbench.txt
 $T python tools/timeline.py < /dev/null 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_timeline_mha.txt
 $T python tools/moe_timeline.py < /dev/null 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_timeline_moe.txt
-timeout 400 bash tools/pmc_sq.sh ${R}_final < /dev/null > /dev/null 2>&1
 # round 5: the floor of a five-launch block on this box; the prompt phase (dsk_hydrate) on the full model and its kernel trace
 timeout 120 tools/_build/block_floor 58 < /dev/null > gpurun_out/${R}_block_floor.txt 2>&1
 $T python tools/hydrate_bench.py --P 16,64,128,256,512 < /dev/null 2>&1 | grep '^{' | tail -1 > gpurun_out/${R}_hydrate.json
+$T python tools/hydrate_bench.py --P 16,64,128,256,512 --opt hydrate_route_seed=7 < /dev/null 2>&1 | grep '^{' | tail -1 > gpurun_out/${R}_hydrate_uniform.json
+$T python tools/hydrate_bench.py --attn mla --P 16,64,128,256 < /dev/null 2>&1 | grep '^{' | tail -1 > gpurun_out/${R}_hydrate_mla.json
+$T python tools/hydrate_bench.py --attn mla --P 64,128 --opt hydrate_route_seed=7 < /dev/null 2>&1 | grep '^{' | tail -1 > gpurun_out/${R}_hydrate_mla_uniform.json
 cd /tmp
 timeout 240 rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/trace_hyd -- python $ROOT/tools/hydrate_bench.py --P 64 --layers 8 --reps 1 --no-loop < /dev/null > $ROOT/gpurun_out/trace_hyd.log 2>&1
 cd $ROOT
@@ -35,6 +37,8 @@ rm -rf gpurun_out/trace_hyd
 # DeepSeek-V2-Lite (BASELINE configs C3) in both Q2_K layouts; the Q8_K hand-over of the fused expert launch against f32 hidden vectors
 $T python bench.py --model v2lite --steps 32 --warmup 4 --no-cpu-baseline --no-extras < /dev/null 2>&1 | grep '^{' | tail -1 > gpurun_out/${R}_bench_v2lite.json
 $T python bench.py --model v2lite --steps 32 --warmup 4 --no-cpu-baseline --no-extras --opt q2k_tiles=0 < /dev/null 2>&1 | grep '^{' | tail -1 > gpurun_out/${R}_bench_v2lite_planes.json
-( timeout 120 python tools/moe_ab.py < /dev/null; timeout 120 python tools/moe_ab.py --opt moe_q8_handoff=0 < /dev/null; timeout 120 python tools/moe_ab.py --opt q2k_tiles=0 < /dev/null ) 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_ab_options.txt
 rm -rf gpurun_out/trace_mha gpurun_out/trace_mla gpurun_out/pmc gpurun_out/pmc_sq
+# the whole GPU test-suite and the smoke entry point on the same sources, same box
+( timeout 900 python -m pytest tests -q -m gpu < /dev/null; timeout 300 python __graft_entry__.py smoke < /dev/null ) > gpurun_out/${R}_gputests.log 2>&1
+tail -3 gpurun_out/${R}_gputests.log
 ls gpurun_out | grep "^${R}_" | head -40

@@ -71,8 +71,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=128)
     ap.add_argument("--opt", action="append", default=[])
     ap.add_argument("--no-loop", action="store_true", help="skip the per-token loop (a kernel trace of the batched path only)")
+    ap.add_argument("--attn", default="mha", choices=["mha", "mla"])
     a = ap.parse_args()
-    c = synth.preset("v3", "q2_k", False)
+    c = synth.preset("v3", "q2_k", a.attn == "mla")
     if a.layers:
         c.n_layers = a.layers
         c.first_k_dense_replace = min(c.first_k_dense_replace, a.layers)
