@@ -102,8 +102,18 @@ static const char* hyd_why_not(const dsk_model* m) {
   return nullptr;
 }
 
+static int hyd_ensure_alloc(dsk_model* m);
 static int hyd_ensure(dsk_model* m) {
   if (m->hyd) return DSK_OK;
+  const int r = hyd_ensure_alloc(m);
+  if (r != DSK_OK) {  // (a half-allocated state must not survive: the next call would take it for complete)
+    const std::string keep = dsk_last_error();
+    hydrate_free(m);
+    DSK_FAIL(r, "%s", keep.c_str());
+  }
+  return DSK_OK;
+}
+static int hyd_ensure_alloc(dsk_model* m) {
   const dsk_config& c = m->c;
   HydState* h = new HydState();
   m->hyd = h;

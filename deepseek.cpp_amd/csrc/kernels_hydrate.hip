@@ -162,7 +162,8 @@ __global__ __launch_bounds__(SPREAD && !GLU ? 512 : 256) void hyd_gemm_kernel(co
   const bool lane_ok = (g4l >> 1) == (kg >> 1);
   const int jbase = 16 * (8 * (kg >> 1) + (kg & 1));  // byte offset of sub-block j(kg, 0) in a block's codes
   const int qd = lane >> 4, rown = lane & 15;         // result side: token qd of the quad, row rown of the strip
-  const int first = SPREAD ? wave * 4 * NQ : 0, step = SPREAD ? nwaves * 4 * NQ : 4 * NQ;
+  // (SPREAD: blockIdx.y deals the token chunks of a strip over several workgroups when the matrix has few strips)
+  const int first = SPREAD ? ((int)blockIdx.y * nwaves + wave) * 4 * NQ : 0, step = SPREAD ? (int)gridDim.y * nwaves * 4 * NQ : 4 * NQ;
   bool first_pass = true;
   for (int base = first; base < cnt; base += step) {
     int off0[NQ], off1[NQ], boff[NQ], doff[NQ], outv[NQ];
@@ -250,10 +251,15 @@ static void hyd_gemm_launch(hipStream_t st, const HydGemmArgs& A) {
   const long long units = (long long)(A.n_experts > 0 ? A.n_experts : 1) * ((A.rows + 15) >> 4);
   // plain matrices with more rows of activations than one wave takes per pass: the waves of a workgroup share a strip
   if (A.n_experts == 0 && A.m > 4 * NQ) {
-    int nw = (A.m + 4 * NQ - 1) / (4 * NQ);
+    const int chunks = (A.m + 4 * NQ - 1) / (4 * NQ);
+    int nw = chunks;
     const int maxw = GLU ? 4 : 8;  // (a GLU pair holds two matrices' tiles: 4 waves keep 512 registers per lane in reach)
     if (nw > maxw) nw = maxw;
-    hipLaunchKernelGGL((hyd_gemm_kernel<GLU, NQ, true>), dim3((unsigned)units), dim3(64 * nw), 0, st, A);
+    // a matrix of few strips (the first-stage projections: 96 + 36) would occupy a fraction of the chip with 8-wave workgroups:
+    // its chunks are dealt over several smaller workgroups per strip instead (they still stream the strip at about the same time)
+    int ny = 1;
+    while (units * ny < 256 && nw > 1) { nw = (nw + 1) / 2; ny = (chunks + nw - 1) / nw; }
+    hipLaunchKernelGGL((hyd_gemm_kernel<GLU, NQ, true>), dim3((unsigned)units, (unsigned)ny), dim3(64 * nw), 0, st, A);
   } else {
     hipLaunchKernelGGL((hyd_gemm_kernel<GLU, NQ, false>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st, A);
   }
