@@ -281,6 +281,41 @@ ADEV float attn_mha_body(const AttnMhaArgs& a, const float* q, int t_lo, int t_h
     if (g < TG && g + k * TG < kv_len)
       vpre[k] = *reinterpret_cast<const f16x4*>(vc + ((size_t)(g + k * TG) * H + h) * vd + i4 * 4);
   __syncthreads();
+  if (!ml && kv_len <= 64 && TG >= 32) {  // (TG >= 32: the two prefetched value rows per thread are all of a 64-position context)
+    // Short contexts (every position lives in wave 0's lanes): the block-wide max / sum below reduce to wave 0's own DPP trees -
+    // the other waves contribute -inf and exact zeros - so every wave can take them from the scores itself, redundantly: the
+    // SAME bits as the general path with five workgroup barriers and two scratch walks less, and the partial sums of the value mix
+    // are added over the position groups that exist (the others hold exact zeros).  attn tail 2.9 -> ~1.9 us at kv_len <= 24.
+    const float a0 = lane < kv_len ? att[lane] : -INFINITY;
+    const float mx0 = wave_max_dpp(a0);
+    const float e0 = lane < kv_len ? expf(a0 - mx0) : 0.f;
+    const float sum0 = wave_sum_dpp(e0);
+    const float w0 = e0 / sum0;  // softmax weight of position `lane`
+    float acc0[4] = {0.f, 0.f, 0.f, 0.f};
+    float wk[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) wk[k] = __shfl(w0, g + k * TG < 64 ? g + k * TG : 0);  // (every lane takes part in the exchange)
+    if (g < TG) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int t = g + k * TG;
+        const float w = wk[k];
+        if (t < kv_len) {
+          acc0[0] = fmaf(w, (float)vpre[k].x, acc0[0]);
+          acc0[1] = fmaf(w, (float)vpre[k].y, acc0[1]);
+          acc0[2] = fmaf(w, (float)vpre[k].z, acc0[2]);
+          acc0[3] = fmaf(w, (float)vpre[k].w, acc0[3]);
+        }
+      }
+      if (g < kv_len) *reinterpret_cast<f32x4*>(part + (size_t)g * vd + i4 * 4) = f32x4{acc0[0], acc0[1], acc0[2], acc0[3]};
+    }
+    __syncthreads();
+    float o0 = 0.f;
+    const int ng = TG < kv_len ? TG : kv_len;
+    if (tid < vd)
+      for (int gg = 0; gg < ng; ++gg) o0 += part[gg * vd + tid];
+    return o0;
+  }
   // softmax, src/infer.cpp:472-487
   float mx = -INFINITY;
   for (int t = tid; t < kv_len; t += NT) mx = fmaxf(mx, att[t]);

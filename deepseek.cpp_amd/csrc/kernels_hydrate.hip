@@ -526,6 +526,18 @@ __global__ __launch_bounds__(1024) void hyd_mla_attn_kernel(const AttnMlaArgs a,
   }
   __syncthreads();
   // ---- softmax (src/infer.cpp:472-487) ----
+  if (kv_len <= 64) {
+    // short contexts: every position lives in wave 0's lanes, so the block-wide max / sum of the general path below ARE wave 0's
+    // DPP trees (the other waves contribute -inf and exact zeros): same bits, one barrier instead of five
+    if (wave == 0) {
+      const float a0 = lane < kv_len ? att[lane] : -INFINITY;
+      const float mx0 = ad::wave_max_dpp(a0);
+      const float e0 = lane < kv_len ? expf(a0 - mx0) : 0.f;
+      const float sum0 = ad::wave_sum_dpp(e0);
+      if (lane < kv_len) att[lane] = e0 / sum0;
+    }
+    __syncthreads();
+  } else {
   float mx = -INFINITY;
   for (int t = tid; t < kv_len; t += NT) mx = fmaxf(mx, att[t]);
   mx = ad::block_max(mx, scratch, tid, NT);
@@ -538,6 +550,7 @@ __global__ __launch_bounds__(1024) void hyd_mla_attn_kernel(const AttnMlaArgs a,
   sum = ad::block_sum(sum, scratch, tid, NT);
   for (int t = tid; t < kv_len; t += NT) att[t] = att[t] / sum;
   __syncthreads();
+  }
   // ---- latent values: lora / 4 threads per position, NT / (lora / 4) positions in flight, 4 rows per thread ----
   {
     const int tpp = lora >> 2, TG = NT / tpp;
