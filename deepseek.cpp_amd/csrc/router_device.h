@@ -35,6 +35,13 @@ RDEV float block_max(float v, float* scratch, int tid, int nthreads) {
   return t;
 }
 
+// sum over the four lanes of a quad (DPP quad_perm [1,0,3,2] then [2,3,0,1]); every lane of the quad must execute it
+RDEV int quad_sum(int x) {
+  x += __builtin_amdgcn_mov_dpp(x, 0xB1, 0xf, 0xf, true);
+  x += __builtin_amdgcn_mov_dpp(x, 0x4E, 0xf, 0xf, true);
+  return x;
+}
+
 // ------------------------------------------------------------------------------------
 // MoE router + gate in ONE launch.
 // Router: F32 GEMV (src/infer.cpp:847, 121-157) over the FFN-normed x (the rmsnorm of
@@ -76,10 +83,34 @@ RDEV void gate_body(int e, float v, const float* __restrict__ bias, int E, int K
   // candidates, compacted: a wave64 VALU op takes 4 cycles, so the serial compare loops below are the
   // critical path of the whole launch -- they must run over the candidates only, not over all E
   int ncand = E;
+  // With 1024 threads four of them share a candidate: each compares it with a quarter of its rivals (two 16-byte LDS reads in
+  // flight instead of a chain of eight round trips) and the quad adds the counts up - ranks are integers: the same result.
+  const bool quads = nthreads >= 1024;
   if (topk_method == DSK_TOPK_GROUP_LIMITED_GREEDY) {
     const int gs = E / n_group, tg = topk_group < gs ? topk_group : gs;
     ncand = n_group * tg;
-    if (e < E) {
+    if (quads && (gs & 15) == 0) {
+      const int e2 = e >> 2, p = e & 3, q = gs >> 2;
+      const bool live = e2 < E;
+      const float v2 = live ? s[e2] : 0.f;
+      const int g = live ? e2 / gs : 0;
+      int rank = 0;
+      if (live) {
+        const int j0 = g * gs + p * q;
+        for (int j = j0; j < j0 + q; j += 4) {
+          const f32x4 sv = *reinterpret_cast<const f32x4*>(s + j);
+          rank += (sv.x > v2 || (sv.x == v2 && j + 0 < e2)) ? 1 : 0;
+          rank += (sv.y > v2 || (sv.y == v2 && j + 1 < e2)) ? 1 : 0;
+          rank += (sv.z > v2 || (sv.z == v2 && j + 2 < e2)) ? 1 : 0;
+          rank += (sv.w > v2 || (sv.w == v2 && j + 3 < e2)) ? 1 : 0;
+        }
+      }
+      rank = quad_sum(rank);
+      if (live && p == 0 && rank < tg) {
+        cs[g * tg + rank] = v2;
+        ci[g * tg + rank] = e2;
+      }
+    } else if (e < E) {
       const int g = e / gs, g0 = g * gs;
       int rank = 0;
       if ((gs & 3) == 0) {  // group starts are multiples of 4: 16-byte LDS reads
@@ -106,7 +137,25 @@ RDEV void gate_body(int e, float v, const float* __restrict__ bias, int E, int K
     ci[e] = e;
   }
   __syncthreads();
-  if (e < ncand) {
+  if (quads && (ncand & 15) == 0) {
+    const int c = e >> 2, p = e & 3, q = ncand >> 2;
+    const bool live = c < ncand;
+    const float v2 = live ? cs[c] : 0.f;
+    const int i2 = live ? ci[c] : 0;
+    int rank = 0;
+    if (live) {
+      for (int j0 = p * q; j0 < (p + 1) * q; j0 += 4) {
+        const f32x4 sv = *reinterpret_cast<const f32x4*>(cs + j0);
+        const u32x4 iv = *reinterpret_cast<const u32x4*>(ci + j0);
+        rank += (sv.x > v2 || (sv.x == v2 && (int)iv.x < i2)) ? 1 : 0;
+        rank += (sv.y > v2 || (sv.y == v2 && (int)iv.y < i2)) ? 1 : 0;
+        rank += (sv.z > v2 || (sv.z == v2 && (int)iv.z < i2)) ? 1 : 0;
+        rank += (sv.w > v2 || (sv.w == v2 && (int)iv.w < i2)) ? 1 : 0;
+      }
+    }
+    rank = quad_sum(rank);
+    if (live && p == 0 && rank < K && i2 < E) sel[rank] = i2;
+  } else if (e < ncand) {
     const float v2 = cs[e];
     const int i2 = ci[e];
     int rank = 0;
