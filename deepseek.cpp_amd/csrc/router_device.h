@@ -58,7 +58,7 @@ RDEV int quad_sum(int x) {
 RDEV void gate_body(int e, float v, const float* __restrict__ bias, int E, int K, int norm_topk_prob, float scaling, int scoring,
                    int topk_method, int n_group, int topk_group, int* __restrict__ active_experts,
                    float* __restrict__ active_weights, float* __restrict__ scores_out, float* s, int* ci, int* sel, float* scratch,
-                   int nthreads = 256) {
+                   int nthreads = 256, bool have_bv = false, float bv = 0.f) {
   // s[256]: scores; cs (aliases scratch area passed as `s + 256`) / ci[256]: compacted candidates.
   // Called by every thread of the workgroup (barriers inside); threads >= 256 only take part in those.
   float* cs = s + 256;
@@ -71,7 +71,7 @@ RDEV void gate_body(int e, float v, const float* __restrict__ bias, int E, int K
   } else {
     v = 1.0f / (1.0f + expf(-v));  // sigmoid, src/infer.cpp:489-491
   }
-  if (bias && e < E) v += bias[e];
+  if (bias && e < E) v += have_bv ? bv : bias[e];  // (have_bv: the caller loaded bias[e] ahead of time)
   if (e >= E) v = -INFINITY;
   if (e < 256) {
     s[e] = v;
@@ -245,6 +245,11 @@ RDEV void router_body(const RouterArgs& a, int bid, int nblocks) {
   const int dim = a.dim, E = a.n_routed;
   unsigned long long* tl = a.timeline && bid < DSK_TL_WGS ? a.timeline + (size_t)bid * 8 : nullptr;
   if (tl && tid == 0) tl[0] = wall_clock64();
+  // the gate's bias, requested now by every workgroup: the last arriver would otherwise wait for it (a cold line) behind the scores
+  const float bias_v = a.bias && tid < E ? a.bias[tid] : 0.f;
+  // (Measured and rejected: this wave's weight rows - and its slices of x and of the norm weights - requested before the norm
+  // instead of behind it.  128 KB of requests per CU stall the waves in issue until the first of them are back: the norm scale is
+  // known at 3.5 us instead of 1.25, rows done 4.1 -> 4.5, the launch 10.2 -> 10.5 us.)
   const float scale = a.norm_w && !(a.dbg & 4) ? router_norm_scale(a, tid, scratch) : 1.0f;
   if (tl && tid == 0) tl[1] = wall_clock64();
   float acc = 0.f;
@@ -313,7 +318,7 @@ RDEV void router_body(const RouterArgs& a, int bid, int nblocks) {
   float v = 0.f;
   if (tid < E) v = __hip_atomic_load(a.partial + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   gate_body(tid, v, a.bias, E, a.n_active, a.norm_topk_prob, a.scaling, a.scoring, a.topk_method, a.n_group, a.topk_group,
-            a.active_experts, a.active_weights, a.scores_out, s, surv, sel, scratch, 1024);
+            a.active_experts, a.active_weights, a.scores_out, s, surv, sel, scratch, 1024, true, bias_v);
   if (tl && tid == 0) tl[4] = wall_clock64();
 }
 // MLA model path, the work of ONE small workgroup: rmsnorm of the latent (src/infer.cpp:1089), f16 cache entries of
