@@ -655,20 +655,22 @@ int launch_embed(hipStream_t st, const DTensor& t, const StepParams* sp, int tok
 }
 
 // gate_body / router_body live in router_device.h (shared with kernels_gemv.hip)
-__global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ partial, int ksplit, const float* __restrict__ bias,
+// (1024 threads like the router launch's last workgroup, so that the op-level entry point runs - and its tests with exact ties
+// cover - the same four-lanes-per-candidate rank loops)
+__global__ __launch_bounds__(1024) void gate_kernel(const float* __restrict__ partial, int ksplit, const float* __restrict__ bias,
                                                    int E, int K, int norm_topk_prob, float scaling, int scoring, int topk_method,
                                                    int n_group, int topk_group, int* __restrict__ active_experts,
                                                    float* __restrict__ active_weights, float* __restrict__ scores_out) {
   __shared__ __attribute__((aligned(16))) float s[512];
   __shared__ __attribute__((aligned(16))) int surv[256];
-  __shared__ float scratch[4];
+  __shared__ float scratch[16];
   __shared__ int sel[256];
   const int e = threadIdx.x;
   float v = 0.f;
   if (e < E)
     for (int c = 0; c < ksplit; ++c) v += partial[(size_t)c * E + e];
   rd::gate_body(e, v, bias, E, K, norm_topk_prob, scaling, scoring, topk_method, n_group, topk_group, active_experts, active_weights,
-            scores_out, s, surv, sel, scratch);
+            scores_out, s, surv, sel, scratch, 1024);
 }
 int launch_gate(hipStream_t st, const float* partial, int ksplit, const float* bias, int n_routed, int n_active,
                 int norm_topk_prob, float scaling, int scoring, int topk_method, int n_group, int topk_group,
@@ -677,7 +679,7 @@ int launch_gate(hipStream_t st, const float* partial, int ksplit, const float* b
   if (n_active > n_routed) DSK_FAIL(DSK_ERR_INVALID, "moe_gate: n_active > n_routed");
   if (topk_method == DSK_TOPK_GROUP_LIMITED_GREEDY && (n_group <= 0 || n_routed % n_group || topk_group * n_group < n_active))
     DSK_FAIL(DSK_ERR_INVALID, "moe_gate: bad group config (E=%d, n_group=%d, topk_group=%d, k=%d)", n_routed, n_group, topk_group, n_active);
-  hipLaunchKernelGGL(gate_kernel, dim3(1), dim3(256), 0, st, partial, ksplit, bias, n_routed, n_active, norm_topk_prob, scaling,
+  hipLaunchKernelGGL(gate_kernel, dim3(1), dim3(1024), 0, st, partial, ksplit, bias, n_routed, n_active, norm_topk_prob, scaling,
                      scoring, topk_method, n_group, topk_group, active_experts, active_weights, scores_out);
   return DSK_OK;
 }

@@ -184,6 +184,17 @@ def test_moe_gate_indices_bitexact(ctx, oracle, ops_gold):
         if v3 or len(set(np.exp(s - s.max()).astype(np.float32))) == E:  # softmax may merge near-equal scores
             assert np.array_equal(eg, eo), (trial, eg, eo)
             assert rel_inf(wg, wo) < 1e-5
+    # shapes whose groups / candidate lists are not multiples of 16: the one-lane-per-candidate rank loops (the shapes above take
+    # the four-lanes-per-candidate form of router_device.h gate_body), with exact ties
+    for trial, (E, K, args) in enumerate([(96, 6, (6, True, 1.5, 1, 1, 4, 2)), (40, 6, (6, True, 1.0, 1, 0, 1, 1)), (200, 8, (8, True, 2.5, 1, 1, 8, 4))] * 4):
+        s = rng.standard_normal(E).astype(np.float32)
+        if trial % 2 == 0:
+            s[rng.integers(0, E, 8)] = s[1]
+        b = (0.1 * rng.standard_normal(E)).astype(np.float32)
+        eg, wg = ctx.moe_gate(s, b, *args)
+        eo, wo, _ = oracle.moe_gate(s, b, *args)
+        assert np.array_equal(eg, eo), (E, trial, eg, eo)
+        assert rel_inf(wg, wo) < 1e-5
 
 
 def test_rope(ctx, oracle, ops_gold):
