@@ -26,7 +26,10 @@
 // loads return in order: the staging of x (an L2 hit, 1.2 us) then waits behind the 43 KB of HBM reads - staged x 1.2 -> 3.0 us,
 // phase A done 15.3 -> 17.6, exit 31.9 -> 33.0, the launch 34.0 -> 35.2 us.)
 
-template <int DUMMY>
+// LEAN: the instantiation for the shapes the model path runs at DeepSeek-V3 width - rows of x longer than 8 blocks (4-block items),
+// Q8_K hand-over, every wave's phase-B steps inside its registers + park slots, no parity tap - without the code of the other cases
+// (the launch is sensitive to its own size: EXPERIMENTS 5.4).  The host picks it (moe_tile_lean).
+template <int LEAN>
 __global__ __launch_bounds__(1024) void moe_ffn_tile_kernel(const MoeFfnArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ float scratch[16];
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(1024) void moe_ffn_tile_kernel(const MoeFfnArgs a) 
         soff0 = (tb + (m3 ? sidx - nt : sidx)) * nb * TILE_B;
         act = actA;
       };
-      if (nb > 8) tile_items<4>(i0, i1, ips, nb, red, TL, lane, strip_of, [](int, int) {});
+      if (LEAN || nb > 8) tile_items<4>(i0, i1, ips, nb, red, TL, lane, strip_of, [](int, int) {});
       else tile_items<1>(i0, i1, ips, nb, red, TL, lane, strip_of, [](int, int) {});
       __syncthreads();
       if (wave < nt) {  // src/infer.cpp:859-872; write-through: the consumers sit on other CUs
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(1024) void moe_ffn_tile_kernel(const MoeFfnArgs a) 
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the arrival
       __syncthreads();
-      if (!a.hq_qs) {
+      if (!LEAN && !a.hq_qs) {
         if (tid == 0) __hip_atomic_fetch_add(a.slot_ctr + s * MOE_CTR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else if (wave == NW - 1) {
         // Q8_K hand-over (kernels_moe.hip): the 4 units of a 256-block of h_k arrive on the block's counter; the LAST one
@@ -196,9 +199,9 @@ __global__ __launch_bounds__(1024) void moe_ffn_tile_kernel(const MoeFfnArgs a) 
         q8k_block_lds<LAY_TILE>(v, lane, actB + (size_t)K * a.lds_b + (size_t)b * TREC);
       }
     };
-    if (a.hq_qs && slots > K) stage_shared();
+    if ((LEAN || a.hq_qs) && slots > K) stage_shared();
     // wait until every phase-A unit of every slot has published (lane k of wave 0 watches slot k; bounded)
-    const unsigned slot_target = a.hq_qs ? (unsigned)(a.mi >> 8) : (unsigned)a.UA;
+    const unsigned slot_target = (LEAN || a.hq_qs) ? (unsigned)(a.mi >> 8) : (unsigned)a.UA;
     if (wave == 0) {
       unsigned spins = 0;
       // (an earlier launch of this token already gave up - a DEVICE word next to the counters says so; the host-visible word lives
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(1024) void moe_ffn_tile_kernel(const MoeFfnArgs a) 
     }
     __syncthreads();
     if (tl && tid == 0) tl[3] = wall_clock64();
-    if (a.hq_qs) {  // routed slots: copies of the Q8_K blocks their producers left (sc1 loads: written during THIS launch)
+    if (LEAN || a.hq_qs) {  // routed slots: copies of the Q8_K blocks their producers left (sc1 loads: written during THIS launch)
       const rsrc_t qr = make_rsrc(a.hq_qs), br = make_rsrc(a.hq_bsums), dr = make_rsrc(a.hq_d);
       const int runs_per_slot = a.mi >> 4, nruns = K * runs_per_slot;
       for (int i = tid; i < nruns; i += NW * 64) {
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(1024) void moe_ffn_tile_kernel(const MoeFfnArgs a) 
     }
     __syncthreads();
     if (tl && tid == 0) tl[4] = wall_clock64();
-    if (a.tap_qs && bid == 0)  // parity tap: what the slots staged
+    if (!LEAN && a.tap_qs && bid == 0)  // parity tap: what the slots staged
       for (int s = 0; s < slots; ++s)
         dump_staged_q8<LAY_TILE>(actB + (size_t)s * a.lds_b, s < K ? a.mi : a.shared_n, a.tap_qs + (size_t)s * a.tap_stride,
                                  a.tap_d + (size_t)s * (a.tap_stride >> 8), tid, 1024);
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(1024) void moe_ffn_tile_kernel(const MoeFfnArgs a) 
         tstep_mac(P, recv[MOE_T_PRE + p], TL, accd, accm);
         red[(size_t)(j0 + MOE_T_PRE + p) * 64 + lane] = titem_value(accd, accm, TL);
       }
-    for (int jb = j0 + NPRE; jb < j1; jb += MOE_T_PRE) {
+    if (!LEAN) for (int jb = j0 + NPRE; jb < j1; jb += MOE_T_PRE) {
 #pragma unroll
       for (int u = 0; u < MOE_T_PRE; ++u)
         if (jb + u < j1) {
@@ -359,9 +362,16 @@ int moe_ffn_plan_tile(MoeFfnArgs& a, int n_cus) {
   return DSK_OK;
 }
 
+// the lean instantiation applies when none of the cases it leaves out can occur
+static bool moe_tile_lean(const MoeFfnArgs& a) {
+  const int nbR = a.mi >> 8, nbS = a.shared_n >> 8, slots_sh = a.shared_n > 0 ? 1 : 0;
+  const int ntile_max = a.rows_wg / 16;
+  const int J = ntile_max * (a.K * nbR + slots_sh * nbS);   // the largest step list of a workgroup
+  return (a.dim >> 8) > 8 && a.hq_qs != nullptr && a.tap_qs == nullptr && (J + 15) / 16 <= MOE_T_PRE + MOE_T_PARK;
+}
 int launch_moe_ffn_tile(hipStream_t st, const MoeFfnArgs& a, hipEvent_t ev_start, hipEvent_t ev_stop) {
   const size_t lds = moe_tile_lds(a);
-  auto k = moe_ffn_tile_kernel<0>;
+  auto k = moe_tile_lean(a) ? moe_ffn_tile_kernel<1> : moe_ffn_tile_kernel<0>;
   if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (ev_start && ev_stop) hipExtLaunchKernelGGL(k, dim3(a.grid + (a.pf_wgs > 0 ? a.pf_wgs : 0)), dim3(1024), (uint32_t)lds, st, ev_start, ev_stop, 0u, a);
   else hipLaunchKernelGGL(k, dim3(a.grid + (a.pf_wgs > 0 ? a.pf_wgs : 0)), dim3(1024), lds, st, a);
