@@ -381,7 +381,9 @@ __global__ __launch_bounds__(256) void hyd_kv_write_kernel(const AttnMhaArgs a, 
 }
 // MHA: rope of the query + attention over positions [0, kv_len) of the cache, per (head, token): head_attn_kernel's second half
 // (same attn_mha_body<1024>: same score / softmax / value-mix trees)
-__global__ __launch_bounds__(1024) void hyd_attn_kernel(const AttnMhaArgs a, const StepParams* __restrict__ sps, const float* __restrict__ q, int q_stride,
+// (64 VGPRs - 12 dwords of scratch - so that TWO workgroups share a CU: the launch is a chain of dependent round trips per (head,
+// token), 8192 of them at P = 64: 115 -> 87 us per block.  The MLA kernel below measured slower with the same cap: 30 dwords spilled.)
+__global__ __launch_bounds__(1024, 8) void hyd_attn_kernel(const AttnMhaArgs a, const StepParams* __restrict__ sps, const float* __restrict__ q, int q_stride,
                                                         float* __restrict__ out, int out_stride) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ float scratch[16];
