@@ -25,6 +25,9 @@
 #include <algorithm>
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+#ifndef HYD16_MIN_TOKENS
+#define HYD16_MIN_TOKENS 12  // plain matrices: from this many tokens on, 16 tokens per wave (hyd_gemm16_kernel)
+#endif
 #define HYD_OOB 0x40000000  // a buffer offset beyond any activation array (all far below 1 GiB): the load returns zeros and touches no memory
 
 DEV rsrc_t make_rsrc_n(const void* p, u32 bytes) {
@@ -246,9 +249,213 @@ __global__ __launch_bounds__(SPREAD && !GLU ? 512 : 256) void hyd_gemm_kernel(co
   }
 }
 
+// ------------------------------------------------------------------------------------
+// Plain matrices times MANY tokens: 16 tokens per wave and pass, the matrix instruction's whole N side.
+// The K side of one instruction is one sub-block GROUP g (sub-blocks 4 g .. 4 g + 3: what the float stage keeps apart), so
+// D_g[token][row] is the exact group sum with no zero padding: K-group kg' of lane (row n, kg') carries sub-block 4 g + kg' =
+// field 2 (g & 1) + (kg' >> 1) of the qs bytes of K-group 2 (g >> 1) + (kg' & 1) - the lane's own 16 bytes or those of the lane
+// 32 away (one v_permlane32_swap per dword gives both) - scaled as in hyd_expand; the activation operand of lane (token t, kg') is
+// the token's 16 codes of that sub-block in natural order: four plain 16-byte loads per block, no selector rows.
+// The min term rides the matrix pipe too: a sub-block sum b (|b| <= 2032) is split b = 8 (v1 + v2) + v0 with all three in int8 range,
+// and K slot (sub-block j, {v0, v1, v2, 0}) meets the weight side's {m_j, 8 m_j, 8 m_j, 0} (8 m_j <= 120): the instruction returns
+// sum_j m_j b_j exactly; one instruction per group (the activation side masked to the group's lanes).
+// In the C/D layout lane (n, q) holds tokens 4 q .. 4 q + 3 of its row: the float stage (hyd_block's, per token) is lane-local.
+// Same integers, same float chains as hyd_gemm_kernel: same bits.
+// ------------------------------------------------------------------------------------
+typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
+struct Hyd16Acc { float S[4][4], ad[4][4], am[4][4]; };  // [token of the lane's four][group]
+DEV void hyd16_acc_zero(Hyd16Acc& a) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) a.S[r][g] = a.ad[r][g] = a.am[r][g] = 0.f;
+}
+struct Hyd16Act {
+  i32x4 a[4];     // the token's codes of sub-block 4 g + kg'
+  u32x2_t bs;     // the token's sums of sub-blocks 4 kg' .. 4 kg' + 3 (int16)
+  float dx[4];    // result side: the scales of tokens 4 q .. 4 q + 3
+};
+DEV void hyd16_act_load(Hyd16Act& X, const rsrc_t& RA, const rsrc_t& RB, const rsrc_t& RD, int offA, int offB, const int (&offD)[4], int b) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) X.a[g] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(RA, offA + 64 * g, b * 256, 0));
+  X.bs = __builtin_amdgcn_raw_buffer_load_b64(RB, offB, b * 32, 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) X.dx[r] = u2f(__builtin_amdgcn_raw_buffer_load_b32(RD, offD[r], b * 4, 0));
+}
+// the weight side of a tile: four scaled group operands and the min operand
+DEV void hyd16_expand(const HydTile& T, int kgp, i32x4 (&B)[4], i32x4& Bm) {
+  const u32 w[4] = {T.w.x, T.w.y, T.w.z, T.w.w};
+  u32 lo[4], hi[4];  // lo: lanes 0-31 their own dword, lanes 32-63 that of lane - 32 (groups 0, 1); hi: lanes 0-31 that of lane + 32 (groups 2, 3)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const auto sw = __builtin_amdgcn_permlane32_swap(w[i], w[i], false, false);
+    lo[i] = sw[0];
+    hi[i] = sw[1];
+  }
+  const int fs = kgp >> 1;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int sh = 2 * (2 * (g & 1) + fs);
+    const u32 sc = (T.sc[g] >> (8 * kgp)) & 0xFu;
+    const u32 pair = sc | (sc << 16);
+    const u32* src = (g >> 1) ? hi : lo;
+    B[g].x = (int)pkmul16((src[0] >> sh) & 0x03030303u, pair);
+    B[g].y = (int)pkmul16((src[1] >> sh) & 0x03030303u, pair);
+    B[g].z = (int)pkmul16((src[2] >> sh) & 0x03030303u, pair);
+    B[g].w = (int)pkmul16((src[3] >> sh) & 0x03030303u, pair);
+  }
+  const u32 scm = kgp == 0 ? T.sc[0] : kgp == 1 ? T.sc[1] : kgp == 2 ? T.sc[2] : T.sc[3];  // the lane's own group's scale | min bytes
+  Bm.x = (int)(((scm >> 4) & 0xFu) * 0x00080801u);
+  Bm.y = (int)(((scm >> 12) & 0xFu) * 0x00080801u);
+  Bm.z = (int)(((scm >> 20) & 0xFu) * 0x00080801u);
+  Bm.w = (int)(((scm >> 28) & 0xFu) * 0x00080801u);
+}
+DEV u32 hyd16_split(int b) {  // b = 8 (v1 + v2) + v0: bytes {v0, v1, v2, 0}
+  const int v0 = b & 7, q = b >> 3, v1 = q >> 1, v2 = q - v1;
+  return (u32)v0 | (((u32)v1 & 0xFFu) << 8) | (((u32)v2 & 0xFFu) << 16);
+}
+DEV void hyd16_block(const HydTile& T, const i32x4 (&B)[4], const i32x4& Bm, const Hyd16Act& X, int kgp, Hyd16Acc& acc) {
+  i32x4 am4;  // the min term's activation operand of this lane: sub-blocks 4 kg' + i
+  am4.x = (int)hyd16_split((int)(short)(X.bs.x & 0xFFFFu));
+  am4.y = (int)hyd16_split((int)(short)(X.bs.x >> 16));
+  am4.z = (int)hyd16_split((int)(short)(X.bs.y & 0xFFFFu));
+  am4.w = (int)hyd16_split((int)(short)(X.bs.y >> 16));
+  const float d = h2f(T.dm & 0xffff), dmin = h2f(T.dm >> 16);
+  float dd[4], dmn[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { dd[r] = X.dx[r] * d; dmn[r] = X.dx[r] * dmin; }
+  // all eight matrix instructions first (independent: they pipeline back to back), then the float stage
+  const i32x4 z = {0, 0, 0, 0};
+  i32x4 D[4], M[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) D[g] = __builtin_amdgcn_mfma_i32_16x16x64_i8(X.a[g], B[g], z, 0, 0, 0);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) M[g] = __builtin_amdgcn_mfma_i32_16x16x64_i8(kgp == g ? am4 : z, Bm, z, 0, 0, 0);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int Dr[4] = {D[g].x, D[g].y, D[g].z, D[g].w}, Mr[4] = {M[g].x, M[g].y, M[g].z, M[g].w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      acc.ad[r][g] = fmaf(dd[r], (float)Dr[r], acc.ad[r][g]);
+      acc.am[r][g] = fmaf(dmn[r], (float)Mr[r], acc.am[r][g]);
+    }
+  }
+}
+DEV void hyd16_item_end(Hyd16Acc& acc) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      acc.S[r][g] += acc.ad[r][g] - acc.am[r][g];
+      acc.ad[r][g] = acc.am[r][g] = 0.f;
+    }
+}
+DEV float hyd16_value(const Hyd16Acc& acc, int r) { return (acc.S[r][0] + acc.S[r][1]) + (acc.S[r][2] + acc.S[r][3]); }
+
+template <bool GLU>
+__global__ __launch_bounds__(GLU ? 256 : 512) void hyd_gemm16_kernel(const HydGemmArgs A) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int nwaves = (int)blockDim.x >> 6;
+  const int strip = (int)blockIdx.x;
+  const int n = A.n, nb = n >> 8;
+  const size_t woff = (size_t)strip * nb * TILE_B;
+  const rsrc_t W1 = make_rsrc(A.W + woff);
+  const rsrc_t W3 = make_rsrc(GLU ? A.W3 + woff : A.W + woff);
+  HydTile T1, T3, N1, N3;
+  hyd_tile_load(T1, W1, lane, 0);
+  if (GLU) hyd_tile_load(T3, W3, lane, 0);
+  if (nb > 1) {
+    hyd_tile_load(N1, W1, lane, TILE_B);
+    if (GLU) hyd_tile_load(N3, W3, lane, TILE_B);
+  }
+  const int cnt = A.m;
+  const bool seg4 = nb > 8;  // tile_seg
+  const rsrc_t RA = make_rsrc_n(A.a_qs, (u32)((size_t)A.a_rows * n));
+  const rsrc_t RB = make_rsrc_n(A.a_bsums, (u32)((size_t)A.a_rows * (n >> 4) * 2));
+  const rsrc_t RD = make_rsrc_n(A.a_d, (u32)((size_t)A.a_rows * nb * 4));
+  const int kgp = lane >> 4, tl = lane & 15;   // operand side: token tl of the chunk, K-group kg'
+  const int q = lane >> 4, rown = lane & 15;   // result side: tokens 4 q .. 4 q + 3, row rown of the strip
+  const int first = ((int)blockIdx.y * nwaves + wave) * 16, step = (int)gridDim.y * nwaves * 16;
+  bool first_pass = true;
+  for (int base = first; base < cnt; base += step) {
+    const int eA = base + tl;
+    const bool okA = eA < cnt;
+    const int arow = okA ? eA / A.a_div : 0;
+    const int offA = okA ? arow * n + 16 * kgp : HYD_OOB;
+    const int offB = okA ? arow * (n >> 4) * 2 + 8 * kgp : HYD_OOB;
+    int offD[4], outv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int eD = base + 4 * q + r;
+      const bool okD = eD < cnt;
+      offD[r] = okD ? (eD / A.a_div) * nb * 4 : HYD_OOB;
+      outv[r] = okD ? eD : -1;
+    }
+    Hyd16Act X, Y;
+    hyd16_act_load(X, RA, RB, RD, offA, offB, offD, 0);
+    if (!first_pass) {  // a further pass over the same strip (L2 hits)
+      hyd_tile_load(T1, W1, lane, 0);
+      if (GLU) hyd_tile_load(T3, W3, lane, 0);
+      if (nb > 1) {
+        hyd_tile_load(N1, W1, lane, TILE_B);
+        if (GLU) hyd_tile_load(N3, W3, lane, TILE_B);
+      }
+    }
+    first_pass = false;
+    Hyd16Acc acc1, acc3;
+    hyd16_acc_zero(acc1);
+    if (GLU) hyd16_acc_zero(acc3);
+    for (int b = 0; b < nb; ++b) {
+      HydTile M1, M3;
+      if (b + 2 < nb) {
+        hyd_tile_load(M1, W1, lane, (b + 2) * TILE_B);
+        if (GLU) hyd_tile_load(M3, W3, lane, (b + 2) * TILE_B);
+      }
+      if (b + 1 < nb) hyd16_act_load(Y, RA, RB, RD, offA, offB, offD, b + 1);
+      const bool item_end = !seg4 || (b & 3) == 3 || b == nb - 1;
+      {
+        i32x4 B[4], Bm;
+        hyd16_expand(T1, kgp, B, Bm);
+        hyd16_block(T1, B, Bm, X, kgp, acc1);
+        if (item_end) hyd16_item_end(acc1);
+        if (GLU) {
+          hyd16_expand(T3, kgp, B, Bm);
+          hyd16_block(T3, B, Bm, X, kgp, acc3);
+          if (item_end) hyd16_item_end(acc3);
+        }
+      }
+      T1 = N1; N1 = M1;
+      if (GLU) { T3 = N3; N3 = M3; }
+      X = Y;
+    }
+    const int row = strip * 16 + rown;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (outv[r] >= 0 && row < A.rows) {
+        float* o = A.out + (size_t)outv[r] * A.out_stride + row;
+        const float v = hyd16_value(acc1, r);
+        if (GLU) *o = act_fn(v, A.act) * hyd16_value(acc3, r);   // src/infer.cpp:859-872
+        else if (A.epilogue == EPI_ADD) *o += v;                  // src/infer.cpp:832-834, 928-930
+        else *o = v;
+      }
+    }
+  }
+}
+
 template <bool GLU, int NQ>
 static void hyd_gemm_launch(hipStream_t st, const HydGemmArgs& A) {
   const long long units = (long long)(A.n_experts > 0 ? A.n_experts : 1) * ((A.rows + 15) >> 4);
+  // plain matrices times many tokens: 16 tokens per wave (hyd_gemm16_kernel), the waves of a workgroup on consecutive chunks of one strip
+  if (A.n_experts == 0 && A.list == nullptr && A.m >= HYD16_MIN_TOKENS) {
+    const int chunks = (A.m + 15) / 16;
+    int nw = chunks;
+    const int maxw = GLU ? 4 : 8;
+    if (nw > maxw) nw = maxw;
+    int ny = 1;
+    while (units * ny < 256 && nw > 1) { nw = (nw + 1) / 2; ny = (chunks + nw - 1) / nw; }
+    hipLaunchKernelGGL((hyd_gemm16_kernel<GLU>), dim3((unsigned)units, (unsigned)ny), dim3(64 * nw), 0, st, A);
+    return;
+  }
   // plain matrices with more rows of activations than one wave takes per pass: the waves of a workgroup share a strip
   if (A.n_experts == 0 && A.m > 4 * NQ) {
     const int chunks = (A.m + 4 * NQ - 1) / (4 * NQ);
