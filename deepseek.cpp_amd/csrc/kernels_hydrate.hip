@@ -491,12 +491,118 @@ __global__ __launch_bounds__(64 * NW) void hyd_gemm16_kernel(const HydGemmArgs A
   }
 }
 
+// Long rows, few strips (the first-stage projections: 96 + 36 strips of 28 blocks; the shared expert's w1 / w3): a strip's row is a
+// chain of 28 dependent block steps whatever the grid - 25 us per launch at P = 64 with most of the chip idle.  The association of
+// tile_device.h is made for this: a row's value is the in-order sum of its ITEM partials (4 blocks each), so the items of one
+// strip x 16 tokens go to the WAVES of a workgroup (wave w = item w), every wave leaves ad - am of its item in LDS and wave 0 adds
+// them in item order - the additions hyd16_item_end performs, in the same order: same bits.  Operands straight from L2 (each wave
+// reads other blocks: nothing to share).
+template <bool GLU>
+__global__ __launch_bounds__(512) void hyd_gemm16k_kernel(const HydGemmArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];  // partials [matrix][item][value 0..15][lane]
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int nitems = (int)blockDim.x >> 6;
+  const int strip = (int)blockIdx.x;
+  const int n = A.n, nb = n >> 8;
+  const int b_lo = wave * 4, b_hi = b_lo + 4 < nb ? b_lo + 4 : nb;
+  const size_t woff = (size_t)strip * nb * TILE_B;
+  const rsrc_t W1 = make_rsrc(A.W + woff);
+  const rsrc_t W3 = make_rsrc(GLU ? A.W3 + woff : A.W + woff);
+  HydTile T1, T3, N1, N3;
+  hyd_tile_load(T1, W1, lane, b_lo * TILE_B);
+  if (GLU) hyd_tile_load(T3, W3, lane, b_lo * TILE_B);
+  if (b_lo + 1 < b_hi) {
+    hyd_tile_load(N1, W1, lane, (b_lo + 1) * TILE_B);
+    if (GLU) hyd_tile_load(N3, W3, lane, (b_lo + 1) * TILE_B);
+  }
+  const int cnt = A.m;
+  const rsrc_t RA = make_rsrc_n(A.a_qs, (u32)((size_t)A.a_rows * n));
+  const rsrc_t RB = make_rsrc_n(A.a_bsums, (u32)((size_t)A.a_rows * (n >> 4) * 2));
+  const rsrc_t RD = make_rsrc_n(A.a_d, (u32)((size_t)A.a_rows * nb * 4));
+  const int kgp = lane >> 4, tl = lane & 15, q = lane >> 4, rown = lane & 15;
+  const int base = (int)blockIdx.y * 16;
+  const int eA = base + tl;
+  const bool okA = eA < cnt;
+  const int arow = okA ? eA / A.a_div : 0;
+  const int offA = okA ? arow * n + 16 * kgp : HYD_OOB;
+  const int offB = okA ? arow * (n >> 4) * 2 + 8 * kgp : HYD_OOB;
+  int offD[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int eD = base + 4 * q + r;
+    offD[r] = eD < cnt ? (eD / A.a_div) * nb * 4 : HYD_OOB;
+  }
+  Hyd16Act X, Y;
+  hyd16_act_load(X, RA, RB, RD, offA, offB, offD, b_lo);
+  Hyd16Acc acc1, acc3;
+  hyd16_acc_zero(acc1);
+  if (GLU) hyd16_acc_zero(acc3);
+  for (int b = b_lo; b < b_hi; ++b) {
+    HydTile M1, M3;
+    if (b + 2 < b_hi) {
+      hyd_tile_load(M1, W1, lane, (b + 2) * TILE_B);
+      if (GLU) hyd_tile_load(M3, W3, lane, (b + 2) * TILE_B);
+    }
+    if (b + 1 < b_hi) hyd16_act_load(Y, RA, RB, RD, offA, offB, offD, b + 1);
+    i32x4 B[4], Bm;
+    hyd16_expand(T1, kgp, B, Bm);
+    hyd16_block(T1, B, Bm, X, kgp, acc1);
+    if (GLU) {
+      hyd16_expand(T3, kgp, B, Bm);
+      hyd16_block(T3, B, Bm, X, kgp, acc3);
+    }
+    T1 = N1; N1 = M1;
+    if (GLU) { T3 = N3; N3 = M3; }
+    X = Y;
+  }
+  float* part = reinterpret_cast<float*>(lds);
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      part[((size_t)wave * 16 + r * 4 + g) * 64 + lane] = acc1.ad[r][g] - acc1.am[r][g];
+      if (GLU) part[((size_t)(nitems + wave) * 16 + r * 4 + g) * 64 + lane] = acc3.ad[r][g] - acc3.am[r][g];
+    }
+  __syncthreads();
+  if (wave != 0) return;
+  float S1[4][4], S3[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { S1[r][g] = 0.f; S3[r][g] = 0.f; }
+  for (int it = 0; it < nitems; ++it)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        S1[r][g] += part[((size_t)it * 16 + r * 4 + g) * 64 + lane];
+        if (GLU) S3[r][g] += part[((size_t)(nitems + it) * 16 + r * 4 + g) * 64 + lane];
+      }
+  const int row = strip * 16 + rown;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int eD = base + 4 * q + r;
+    if (eD < cnt && row < A.rows) {
+      float* o = A.out + (size_t)eD * A.out_stride + row;
+      const float v = (S1[r][0] + S1[r][1]) + (S1[r][2] + S1[r][3]);
+      if (GLU) *o = act_fn(v, A.act) * ((S3[r][0] + S3[r][1]) + (S3[r][2] + S3[r][3]));   // src/infer.cpp:859-872
+      else if (A.epilogue == EPI_ADD) *o += v;                                              // src/infer.cpp:832-834, 928-930
+      else *o = v;
+    }
+  }
+}
+
 template <bool GLU, int NQ>
 static void hyd_gemm_launch(hipStream_t st, const HydGemmArgs& A) {
   const long long units = (long long)(A.n_experts > 0 ? A.n_experts : 1) * ((A.rows + 15) >> 4);
   // plain matrices times many tokens: 16 tokens per wave (hyd_gemm16_kernel), the waves of a workgroup on consecutive chunks of one strip
   if (A.n_experts == 0 && A.list == nullptr && A.m >= HYD16_MIN_TOKENS) {
     const int chunks = (A.m + 15) / 16;
+    const int nb_ = A.n >> 8, ips_ = tile_ips(nb_);
+    if (nb_ > 8 && ips_ <= 8 && units * chunks <= 768) {  // long rows, few strips: the items of a strip to the waves of a workgroup
+      hipLaunchKernelGGL((hyd_gemm16k_kernel<GLU>), dim3((unsigned)units, (unsigned)chunks), dim3(64 * ips_), (GLU ? 2 : 1) * ips_ * 16 * 64 * 4, st, A);
+      return;
+    }
     // strips per workgroup: as many as still give most CUs a workgroup (the staging is paid once per workgroup, and every choice
     // puts the same number of waves on the chip); at least 2 (the staging indices assume >= 128 threads)
     int nw = GLU ? 4 : 8;
