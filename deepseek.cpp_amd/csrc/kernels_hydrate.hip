@@ -28,6 +28,9 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 #ifndef HYD16_MIN_TOKENS
 #define HYD16_MIN_TOKENS 12  // plain matrices: from this many tokens on, 16 tokens per wave (hyd_gemm16_kernel)
 #endif
+#ifndef HYD16_EXPERT_MIN
+#define HYD16_EXPERT_MIN 6   // expert stacks: tasks with at least this many rows take the 16-token form (0: never)
+#endif
 #define HYD_OOB 0x40000000  // a buffer offset beyond any activation array (all far below 1 GiB): the load returns zeros and touches no memory
 
 DEV rsrc_t make_rsrc_n(const void* p, u32 bytes) {
@@ -361,6 +364,9 @@ DEV float hyd16_value(const Hyd16Acc& acc, int r) { return (acc.S[r][0] + acc.S[
 #define HYD16_TOK_B 272     // LDS bytes of a token's codes of one block (256 + 16: the 16 tokens of an operand read spread over the banks)
 #define HYD16_STAGE_B (HYD16_SB * (16 * HYD16_TOK_B + 16 * 32 + 16 * 4))   // codes | sub-block sums | scales, per block
 template <int R> struct Hyd16Stage { u32x4 c[R]; u32x4 bs; u32x4 d; };
+// Plain matrices: blockIdx.x = strip group, blockIdx.y = the chunk of 16 tokens.  Expert stacks (A.n_experts > 0: the task's rows come
+// through its list, src/infer.cpp:853-878): blockIdx.x = task x strip groups, the workgroup walks the task's rows 16 at a time (a
+// launch may be restricted to tasks with a row count in [cnt_min, cnt_max]: the few-row tasks stay with hyd_gemm_kernel's quads).
 template <bool GLU, int NW>
 __global__ __launch_bounds__(64 * NW) void hyd_gemm16_kernel(const HydGemmArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];  // 2 x HYD16_STAGE_B
@@ -368,125 +374,133 @@ __global__ __launch_bounds__(64 * NW) void hyd_gemm16_kernel(const HydGemmArgs A
   constexpr int nwaves = NW, nthreads = 64 * NW;
   constexpr int R = HYD16_SB * 256 / nthreads;  // 16-byte pieces of a stage's codes per thread
   const int strips = (A.rows + 15) >> 4;
-  const int strip = (int)blockIdx.x * nwaves + wave;
+  const int groups = (strips + nwaves - 1) / nwaves;
+  const int task = A.n_experts > 0 ? (int)blockIdx.x / groups : 0;
+  const int group = (int)blockIdx.x - task * groups;
+  const int cnt = A.count ? __builtin_amdgcn_readfirstlane(A.count[task]) : A.m;
+  if (cnt <= 0 || cnt < A.cnt_min || (A.cnt_max > 0 && cnt > A.cnt_max)) return;
+  const int* list = A.list ? A.list + (size_t)task * A.list_stride : nullptr;
+  const int strip = group * nwaves + wave;
   const bool live = strip < strips;  // (a wave without a strip still stages and keeps the barriers)
   const int n = A.n, nb = n >> 8;
-  const size_t woff = (size_t)(live ? strip : 0) * nb * TILE_B;
+  const size_t woff = (size_t)task * A.e_bytes + (size_t)(live ? strip : 0) * nb * TILE_B;
   const rsrc_t W1 = make_rsrc(A.W + woff);
   const rsrc_t W3 = make_rsrc(GLU ? A.W3 + woff : A.W + woff);
-  HydTile T1, T3, N1, N3;
-  if (live) {
-    hyd_tile_load(T1, W1, lane, 0);
-    if (GLU) hyd_tile_load(T3, W3, lane, 0);
-    if (nb > 1) {
-      hyd_tile_load(N1, W1, lane, TILE_B);
-      if (GLU) hyd_tile_load(N3, W3, lane, TILE_B);
-    }
-  }
-  const int cnt = A.m;
   const bool seg4 = nb > 8;  // tile_seg
   const rsrc_t RA = make_rsrc_n(A.a_qs, (u32)((size_t)A.a_rows * n));
   const rsrc_t RB = make_rsrc_n(A.a_bsums, (u32)((size_t)A.a_rows * (n >> 4) * 2));
   const rsrc_t RD = make_rsrc_n(A.a_d, (u32)((size_t)A.a_rows * nb * 4));
   const int kgp = lane >> 4, tl = lane & 15;   // operand side: token tl of the chunk, K-group kg'
   const int q = lane >> 4, rown = lane & 15;   // result side: tokens 4 q .. 4 q + 3, row rown of the strip
-  const int base = (int)blockIdx.y * 16;
-  // ---- staging: thread -> its pieces of a stage (wave-uniform loop bounds; a token past the count reads zeros) ----
-  // codes: HYD16_SB x 16 tokens x 16 pieces of 16 bytes; sums: HYD16_SB x 16 x 2 pieces; scales: 16 tokens x (HYD16_SB floats = 16 bytes)
-  int c_off[R];
-#pragma unroll
-  for (int k = 0; k < R; ++k) {
-    const int idx = tid + k * nthreads;
-    const int t = (idx >> 4) & 15, piece = idx & 15;
-    const int e = base + t;
-    c_off[k] = e < cnt ? (e / A.a_div) * n + piece * 16 : HYD_OOB;
-  }
   auto c_sb = [&](int k) { return (tid + k * nthreads) >> 8; };
   auto c_lds = [&](int k) { const int idx = tid + k * nthreads; return ((idx >> 8) * 16 + ((idx >> 4) & 15)) * HYD16_TOK_B + (idx & 15) * 16; };
   const int b_sb = tid >> 5, b_t = (tid >> 1) & 15, b_piece = tid & 1;
-  const int b_off = (base + b_t < cnt) ? ((base + b_t) / A.a_div) * (n >> 4) * 2 + b_piece * 16 : HYD_OOB;
   const int b_lds = HYD16_SB * 16 * HYD16_TOK_B + (b_sb * 16 + b_t) * 32 + b_piece * 16;
-  const int d_off = (tid < 16 && base + tid < cnt) ? ((base + tid) / A.a_div) * nb * 4 : HYD_OOB;
   const int d_lds = HYD16_SB * (16 * HYD16_TOK_B + 16 * 32);
-  auto stage_request = [&](Hyd16Stage<R>& G, int b0) {
+  auto arow_of = [&](int e) { return (list ? list[e] : e) / A.a_div; };  // (e < cnt)
+  for (int base = (int)blockIdx.y * 16; base < cnt; base += (int)gridDim.y * 16) {
+    // ---- staging: thread -> its pieces of a stage (wave-uniform loop bounds; a row past the count reads zeros) ----
+    // codes: HYD16_SB x 16 tokens x 16 pieces of 16 bytes; sums: HYD16_SB x 16 x 2 pieces; scales: 16 tokens x (HYD16_SB floats = 16 bytes)
+    int c_off[R];
 #pragma unroll
-    for (int k = 0; k < R; ++k) G.c[k] = __builtin_amdgcn_raw_buffer_load_b128(RA, c_off[k], (b0 + c_sb(k)) * 256, 0);
-    if (tid < HYD16_SB * 32) G.bs = __builtin_amdgcn_raw_buffer_load_b128(RB, b_off, (b0 + b_sb) * 32, 0);
-    if (tid < 16) {  // the token's scales of blocks b0 .. b0 + 3 (the last stage of a row may reach past it: the offsets stay inside the array
-                     // or beyond it - zeros - and those blocks are never multiplied)
-      G.d.x = __builtin_amdgcn_raw_buffer_load_b32(RD, d_off, (b0 + 0) * 4, 0);
-      G.d.y = b0 + 1 < nb ? __builtin_amdgcn_raw_buffer_load_b32(RD, d_off, (b0 + 1) * 4, 0) : 0u;
-      G.d.z = b0 + 2 < nb ? __builtin_amdgcn_raw_buffer_load_b32(RD, d_off, (b0 + 2) * 4, 0) : 0u;
-      G.d.w = b0 + 3 < nb ? __builtin_amdgcn_raw_buffer_load_b32(RD, d_off, (b0 + 3) * 4, 0) : 0u;
+    for (int k = 0; k < R; ++k) {
+      const int idx = tid + k * nthreads;
+      const int t = (idx >> 4) & 15, piece = idx & 15;
+      const int e = base + t;
+      c_off[k] = e < cnt ? arow_of(e) * n + piece * 16 : HYD_OOB;
     }
-  };
-  auto stage_write = [&](const Hyd16Stage<R>& G, uint8_t* buf) {
+    const int b_off = (base + b_t < cnt) ? arow_of(base + b_t) * (n >> 4) * 2 + b_piece * 16 : HYD_OOB;
+    const int d_off = (tid < 16 && base + tid < cnt) ? arow_of(base + tid) * nb * 4 : HYD_OOB;
+    auto stage_request = [&](Hyd16Stage<R>& G, int b0) {
 #pragma unroll
-    for (int k = 0; k < R; ++k) *reinterpret_cast<u32x4*>(buf + c_lds(k)) = G.c[k];
-    if (tid < HYD16_SB * 32) *reinterpret_cast<u32x4*>(buf + b_lds) = G.bs;
-    if (tid < 16) {
-      float* dl = reinterpret_cast<float*>(buf + d_lds);
-      dl[0 * 16 + tid] = u2f(G.d.x); dl[1 * 16 + tid] = u2f(G.d.y); dl[2 * 16 + tid] = u2f(G.d.z); dl[3 * 16 + tid] = u2f(G.d.w);
-    }
-  };
-  Hyd16Stage<R> G;
-  stage_request(G, 0);
-  stage_write(G, lds);
-  __syncthreads();
-  Hyd16Acc acc1, acc3;
-  hyd16_acc_zero(acc1);
-  if (GLU) hyd16_acc_zero(acc3);
-  for (int b0 = 0; b0 < nb; b0 += HYD16_SB) {
-    uint8_t* cur = lds + ((b0 / HYD16_SB) & 1) * HYD16_STAGE_B;
-    uint8_t* nxt = lds + (((b0 / HYD16_SB) & 1) ^ 1) * HYD16_STAGE_B;
-    const bool more = b0 + HYD16_SB < nb;
-    if (more) stage_request(G, b0 + HYD16_SB);
-    if (live) {
+      for (int k = 0; k < R; ++k) G.c[k] = __builtin_amdgcn_raw_buffer_load_b128(RA, c_off[k], (b0 + c_sb(k)) * 256, 0);
+      if (tid < HYD16_SB * 32) G.bs = __builtin_amdgcn_raw_buffer_load_b128(RB, b_off, (b0 + b_sb) * 32, 0);
+      if (tid < 16) {  // the token's scales of blocks b0 .. b0 + 3 (past the row's end: never multiplied)
+        G.d.x = __builtin_amdgcn_raw_buffer_load_b32(RD, d_off, (b0 + 0) * 4, 0);
+        G.d.y = b0 + 1 < nb ? __builtin_amdgcn_raw_buffer_load_b32(RD, d_off, (b0 + 1) * 4, 0) : 0u;
+        G.d.z = b0 + 2 < nb ? __builtin_amdgcn_raw_buffer_load_b32(RD, d_off, (b0 + 2) * 4, 0) : 0u;
+        G.d.w = b0 + 3 < nb ? __builtin_amdgcn_raw_buffer_load_b32(RD, d_off, (b0 + 3) * 4, 0) : 0u;
+      }
+    };
+    auto stage_write = [&](const Hyd16Stage<R>& G, uint8_t* buf) {
 #pragma unroll
-      for (int u = 0; u < HYD16_SB; ++u) {
-        const int b = b0 + u;
-        if (b < nb) {
-          HydTile M1, M3;
-          if (b + 2 < nb) {
-            hyd_tile_load(M1, W1, lane, (b + 2) * TILE_B);
-            if (GLU) hyd_tile_load(M3, W3, lane, (b + 2) * TILE_B);
-          }
-          Hyd16Act X;
-          const uint8_t* cb = cur + (u * 16 + tl) * HYD16_TOK_B + 16 * kgp;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) X.a[g] = *reinterpret_cast<const i32x4*>(cb + 64 * g);
-          X.bs = *reinterpret_cast<const u32x2_t*>(cur + HYD16_SB * 16 * HYD16_TOK_B + (u * 16 + tl) * 32 + 8 * kgp);
-          const f32x4 dq = *reinterpret_cast<const f32x4*>(cur + d_lds + (u * 16 + 4 * q) * 4);
-          X.dx[0] = dq.x; X.dx[1] = dq.y; X.dx[2] = dq.z; X.dx[3] = dq.w;
-          const bool item_end = !seg4 || (b & 3) == 3 || b == nb - 1;
-          i32x4 B[4], Bm;
-          hyd16_expand(T1, kgp, B, Bm);
-          hyd16_block(T1, B, Bm, X, kgp, acc1);
-          if (item_end) hyd16_item_end(acc1);
-          if (GLU) {
-            hyd16_expand(T3, kgp, B, Bm);
-            hyd16_block(T3, B, Bm, X, kgp, acc3);
-            if (item_end) hyd16_item_end(acc3);
-          }
-          T1 = N1; N1 = M1;
-          if (GLU) { T3 = N3; N3 = M3; }
-        }
+      for (int k = 0; k < R; ++k) *reinterpret_cast<u32x4*>(buf + c_lds(k)) = G.c[k];
+      if (tid < HYD16_SB * 32) *reinterpret_cast<u32x4*>(buf + b_lds) = G.bs;
+      if (tid < 16) {
+        float* dl = reinterpret_cast<float*>(buf + d_lds);
+        dl[0 * 16 + tid] = u2f(G.d.x); dl[1 * 16 + tid] = u2f(G.d.y); dl[2 * 16 + tid] = u2f(G.d.z); dl[3 * 16 + tid] = u2f(G.d.w);
+      }
+    };
+    HydTile T1, T3, N1, N3;
+    if (live) {  // (a further pass over the same strip: L2 hits)
+      hyd_tile_load(T1, W1, lane, 0);
+      if (GLU) hyd_tile_load(T3, W3, lane, 0);
+      if (nb > 1) {
+        hyd_tile_load(N1, W1, lane, TILE_B);
+        if (GLU) hyd_tile_load(N3, W3, lane, TILE_B);
       }
     }
-    if (more) stage_write(G, nxt);
+    Hyd16Stage<R> G;
+    stage_request(G, 0);
+    stage_write(G, lds);
     __syncthreads();
-  }
-  if (!live) return;
-  const int row = strip * 16 + rown;
+    Hyd16Acc acc1, acc3;
+    hyd16_acc_zero(acc1);
+    if (GLU) hyd16_acc_zero(acc3);
+    for (int b0 = 0; b0 < nb; b0 += HYD16_SB) {
+      uint8_t* cur = lds + ((b0 / HYD16_SB) & 1) * HYD16_STAGE_B;
+      uint8_t* nxt = lds + (((b0 / HYD16_SB) & 1) ^ 1) * HYD16_STAGE_B;
+      const bool more = b0 + HYD16_SB < nb;
+      if (more) stage_request(G, b0 + HYD16_SB);
+      if (live) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int eD = base + 4 * q + r;
-    if (eD < cnt && row < A.rows) {
-      float* o = A.out + (size_t)eD * A.out_stride + row;
-      const float v = hyd16_value(acc1, r);
-      if (GLU) *o = act_fn(v, A.act) * hyd16_value(acc3, r);   // src/infer.cpp:859-872
-      else if (A.epilogue == EPI_ADD) *o += v;                  // src/infer.cpp:832-834, 928-930
-      else *o = v;
+        for (int u = 0; u < HYD16_SB; ++u) {
+          const int b = b0 + u;
+          if (b < nb) {
+            HydTile M1, M3;
+            if (b + 2 < nb) {
+              hyd_tile_load(M1, W1, lane, (b + 2) * TILE_B);
+              if (GLU) hyd_tile_load(M3, W3, lane, (b + 2) * TILE_B);
+            }
+            Hyd16Act X;
+            const uint8_t* cb = cur + (u * 16 + tl) * HYD16_TOK_B + 16 * kgp;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) X.a[g] = *reinterpret_cast<const i32x4*>(cb + 64 * g);
+            X.bs = *reinterpret_cast<const u32x2_t*>(cur + HYD16_SB * 16 * HYD16_TOK_B + (u * 16 + tl) * 32 + 8 * kgp);
+            const f32x4 dq = *reinterpret_cast<const f32x4*>(cur + d_lds + (u * 16 + 4 * q) * 4);
+            X.dx[0] = dq.x; X.dx[1] = dq.y; X.dx[2] = dq.z; X.dx[3] = dq.w;
+            const bool item_end = !seg4 || (b & 3) == 3 || b == nb - 1;
+            i32x4 B[4], Bm;
+            hyd16_expand(T1, kgp, B, Bm);
+            hyd16_block(T1, B, Bm, X, kgp, acc1);
+            if (item_end) hyd16_item_end(acc1);
+            if (GLU) {
+              hyd16_expand(T3, kgp, B, Bm);
+              hyd16_block(T3, B, Bm, X, kgp, acc3);
+              if (item_end) hyd16_item_end(acc3);
+            }
+            T1 = N1; N1 = M1;
+            if (GLU) { T3 = N3; N3 = M3; }
+          }
+        }
+      }
+      if (more) stage_write(G, nxt);
+      __syncthreads();  // (also in front of the next chunk's first stage: every wave is done with both buffers)
+    }
+    if (live) {
+      const int row = strip * 16 + rown;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int eD = base + 4 * q + r;
+        if (eD < cnt && row < A.rows) {
+          const int vD = list ? list[eD] : eD;
+          float* o = A.out + (size_t)vD * A.out_stride + row;
+          const float v = hyd16_value(acc1, r);
+          if (GLU) *o = act_fn(v, A.act) * hyd16_value(acc3, r);   // src/infer.cpp:859-872
+          else if (A.epilogue == EPI_ADD) *o += v;                  // src/infer.cpp:832-834, 928-930
+          else *o = v;
+        }
+      }
     }
   }
 }
@@ -595,6 +609,20 @@ __global__ __launch_bounds__(512) void hyd_gemm16k_kernel(const HydGemmArgs A) {
 template <bool GLU, int NQ>
 static void hyd_gemm_launch(hipStream_t st, const HydGemmArgs& A) {
   const long long units = (long long)(A.n_experts > 0 ? A.n_experts : 1) * ((A.rows + 15) >> 4);
+  // expert stacks: the tasks with HYD16_EXPERT_MIN rows or more go through the 16-token form (their rows share the expanded tile 16 at
+  // a time instead of 4), the others stay with the quads below
+  if (A.n_experts > 0 && A.count && A.list && HYD16_EXPERT_MIN > 0 && A.cnt_min == 0 && A.cnt_max == 0) {
+    HydGemmArgs B = A;
+    B.cnt_min = HYD16_EXPERT_MIN;
+    const int strips = (A.rows + 15) >> 4;
+    constexpr int NW = GLU ? 4 : 8;
+    const int groups = (strips + NW - 1) / NW;
+    hipLaunchKernelGGL((hyd_gemm16_kernel<GLU, NW>), dim3((unsigned)(A.n_experts * groups), 1u), dim3(64 * NW), 2 * HYD16_STAGE_B, st, B);
+    HydGemmArgs C = A;
+    C.cnt_max = HYD16_EXPERT_MIN - 1;
+    hipLaunchKernelGGL((hyd_gemm_kernel<GLU, NQ, false>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st, C);
+    return;
+  }
   // plain matrices times many tokens: 16 tokens per wave (hyd_gemm16_kernel), the waves of a workgroup on consecutive chunks of one strip
   if (A.n_experts == 0 && A.list == nullptr && A.m >= HYD16_MIN_TOKENS) {
     const int chunks = (A.m + 15) / 16;
