@@ -317,12 +317,8 @@ DEV u32 hyd16_split(int b) {  // b = 8 (v1 + v2) + v0: bytes {v0, v1, v2, 0}
   const int v0 = b & 7, q = b >> 3, v1 = q >> 1, v2 = q - v1;
   return (u32)v0 | (((u32)v1 & 0xFFu) << 8) | (((u32)v2 & 0xFFu) << 16);
 }
-DEV void hyd16_block(const HydTile& T, const i32x4 (&B)[4], const i32x4& Bm, const Hyd16Act& X, int kgp, Hyd16Acc& acc) {
-  i32x4 am4;  // the min term's activation operand of this lane: sub-blocks 4 kg' + i
-  am4.x = (int)hyd16_split((int)(short)(X.bs.x & 0xFFFFu));
-  am4.y = (int)hyd16_split((int)(short)(X.bs.x >> 16));
-  am4.z = (int)hyd16_split((int)(short)(X.bs.y & 0xFFFFu));
-  am4.w = (int)hyd16_split((int)(short)(X.bs.y >> 16));
+// am4: the min term's activation operand of this lane: the digit words of sub-blocks 4 kg' + i of its token
+DEV void hyd16_block_d(const HydTile& T, const i32x4 (&B)[4], const i32x4& Bm, const Hyd16Act& X, const i32x4& am4, int kgp, Hyd16Acc& acc) {
   const float d = h2f(T.dm & 0xffff), dmin = h2f(T.dm >> 16);
   float dd[4], dmn[4];
 #pragma unroll
@@ -344,6 +340,14 @@ DEV void hyd16_block(const HydTile& T, const i32x4 (&B)[4], const i32x4& Bm, con
     }
   }
 }
+DEV void hyd16_block(const HydTile& T, const i32x4 (&B)[4], const i32x4& Bm, const Hyd16Act& X, int kgp, Hyd16Acc& acc) {
+  i32x4 am4;
+  am4.x = (int)hyd16_split((int)(short)(X.bs.x & 0xFFFFu));
+  am4.y = (int)hyd16_split((int)(short)(X.bs.x >> 16));
+  am4.z = (int)hyd16_split((int)(short)(X.bs.y & 0xFFFFu));
+  am4.w = (int)hyd16_split((int)(short)(X.bs.y >> 16));
+  hyd16_block_d(T, B, Bm, X, am4, kgp, acc);
+}
 DEV void hyd16_item_end(Hyd16Acc& acc) {
 #pragma unroll
   for (int r = 0; r < 4; ++r)
@@ -362,7 +366,7 @@ DEV float hyd16_value(const Hyd16Acc& acc, int r) { return (acc.S[r][0] + acc.S[
 // parked on s_waitcnt, VALU 32 %: 46 KB per CU and block through a memory path that carries ~27 GB/s per CU; wo 108 us at P = 64.)
 #define HYD16_SB 4          // blocks per stage
 #define HYD16_TOK_B 272     // LDS bytes of a token's codes of one block (256 + 16: the 16 tokens of an operand read spread over the banks)
-#define HYD16_STAGE_B (HYD16_SB * (16 * HYD16_TOK_B + 16 * 32 + 16 * 4))   // codes | sub-block sums | scales, per block
+#define HYD16_STAGE_B (HYD16_SB * (16 * HYD16_TOK_B + 16 * 64 + 16 * 4))   // codes | sub-block sums as digit words (hyd16_split) | scales, per block
 template <int R> struct Hyd16Stage { u32x4 c[R]; u32x4 bs; u32x4 d; };
 // Plain matrices: blockIdx.x = strip group, blockIdx.y = the chunk of 16 tokens.  Expert stacks (A.n_experts > 0: the task's rows come
 // through its list, src/infer.cpp:853-878): blockIdx.x = task x strip groups, the workgroup walks the task's rows 16 at a time (a
@@ -395,8 +399,8 @@ __global__ __launch_bounds__(64 * NW) void hyd_gemm16_kernel(const HydGemmArgs A
   auto c_sb = [&](int k) { return (tid + k * nthreads) >> 8; };
   auto c_lds = [&](int k) { const int idx = tid + k * nthreads; return ((idx >> 8) * 16 + ((idx >> 4) & 15)) * HYD16_TOK_B + (idx & 15) * 16; };
   const int b_sb = tid >> 5, b_t = (tid >> 1) & 15, b_piece = tid & 1;
-  const int b_lds = HYD16_SB * 16 * HYD16_TOK_B + (b_sb * 16 + b_t) * 32 + b_piece * 16;
-  const int d_lds = HYD16_SB * (16 * HYD16_TOK_B + 16 * 32);
+  const int b_lds = HYD16_SB * 16 * HYD16_TOK_B + (b_sb * 16 + b_t) * 64 + b_piece * 32;   // (8 sums -> 8 digit words)
+  const int d_lds = HYD16_SB * (16 * HYD16_TOK_B + 16 * 64);
   auto arow_of = [&](int e) { return (list ? list[e] : e) / A.a_div; };  // (e < cnt)
   for (int base = (int)blockIdx.y * 16; base < cnt; base += (int)gridDim.y * 16) {
     // ---- staging: thread -> its pieces of a stage (wave-uniform loop bounds; a row past the count reads zeros) ----
@@ -425,7 +429,16 @@ __global__ __launch_bounds__(64 * NW) void hyd_gemm16_kernel(const HydGemmArgs A
     auto stage_write = [&](const Hyd16Stage<R>& G, uint8_t* buf) {
 #pragma unroll
       for (int k = 0; k < R; ++k) *reinterpret_cast<u32x4*>(buf + c_lds(k)) = G.c[k];
-      if (tid < HYD16_SB * 32) *reinterpret_cast<u32x4*>(buf + b_lds) = G.bs;
+      if (tid < HYD16_SB * 32) {  // the sums go to LDS as the min term's operand words: split ONCE per workgroup, not per wave and block
+        const u32 w[4] = {G.bs.x, G.bs.y, G.bs.z, G.bs.w};
+        u32x4 lo, hi;
+        lo.x = hyd16_split((int)(short)(w[0] & 0xFFFFu)); lo.y = hyd16_split((int)(short)(w[0] >> 16));
+        lo.z = hyd16_split((int)(short)(w[1] & 0xFFFFu)); lo.w = hyd16_split((int)(short)(w[1] >> 16));
+        hi.x = hyd16_split((int)(short)(w[2] & 0xFFFFu)); hi.y = hyd16_split((int)(short)(w[2] >> 16));
+        hi.z = hyd16_split((int)(short)(w[3] & 0xFFFFu)); hi.w = hyd16_split((int)(short)(w[3] >> 16));
+        *reinterpret_cast<u32x4*>(buf + b_lds) = lo;
+        *reinterpret_cast<u32x4*>(buf + b_lds + 16) = hi;
+      }
       if (tid < 16) {
         float* dl = reinterpret_cast<float*>(buf + d_lds);
         dl[0 * 16 + tid] = u2f(G.d.x); dl[1 * 16 + tid] = u2f(G.d.y); dl[2 * 16 + tid] = u2f(G.d.z); dl[3 * 16 + tid] = u2f(G.d.w);
@@ -466,17 +479,17 @@ __global__ __launch_bounds__(64 * NW) void hyd_gemm16_kernel(const HydGemmArgs A
             const uint8_t* cb = cur + (u * 16 + tl) * HYD16_TOK_B + 16 * kgp;
 #pragma unroll
             for (int g = 0; g < 4; ++g) X.a[g] = *reinterpret_cast<const i32x4*>(cb + 64 * g);
-            X.bs = *reinterpret_cast<const u32x2_t*>(cur + HYD16_SB * 16 * HYD16_TOK_B + (u * 16 + tl) * 32 + 8 * kgp);
+            const i32x4 am4 = *reinterpret_cast<const i32x4*>(cur + HYD16_SB * 16 * HYD16_TOK_B + (u * 16 + tl) * 64 + 16 * kgp);
             const f32x4 dq = *reinterpret_cast<const f32x4*>(cur + d_lds + (u * 16 + 4 * q) * 4);
             X.dx[0] = dq.x; X.dx[1] = dq.y; X.dx[2] = dq.z; X.dx[3] = dq.w;
             const bool item_end = !seg4 || (b & 3) == 3 || b == nb - 1;
             i32x4 B[4], Bm;
             hyd16_expand(T1, kgp, B, Bm);
-            hyd16_block(T1, B, Bm, X, kgp, acc1);
+            hyd16_block_d(T1, B, Bm, X, am4, kgp, acc1);
             if (item_end) hyd16_item_end(acc1);
             if (GLU) {
               hyd16_expand(T3, kgp, B, Bm);
-              hyd16_block(T3, B, Bm, X, kgp, acc3);
+              hyd16_block_d(T3, B, Bm, X, am4, kgp, acc3);
               if (item_end) hyd16_item_end(acc3);
             }
             T1 = N1; N1 = M1;

@@ -97,10 +97,11 @@ def _assert_identical(res, P, pos0):
 
 
 @pytest.mark.parametrize("mla", [False, True], ids=["mha", "mla"])
-@pytest.mark.parametrize("P,pos0,chunk", [(1, 0, None), (2, 0, None), (5, 3, None), (16, 0, None), (17, 0, None), (37, 5, None), (37, 0, 16), (48, 9, 7)])
+@pytest.mark.parametrize("P,pos0,chunk", [(1, 0, None), (2, 0, None), (5, 3, None), (13, 2, None), (16, 0, None), (17, 0, None), (37, 5, None), (37, 0, 16), (48, 9, 7)])
 def test_hydrate_equals_the_loop_tiny(ctx, P, pos0, chunk, mla):
     """tiny DeepSeek-V3 Q2_K model, MHA and MLA (1 dense + 2 MoE blocks, 16 experts top-4, rows of <= 8 blocks: single-block items):
-    token quads that are full, ragged and single; chunks that split the prompt (attention over rows an earlier chunk wrote)"""
+    token quads that are full, ragged and single; 13 - 48 tokens: the 16-token GEMM forms (plain matrices from 12 tokens on, expert
+    tasks from 6 rows on) with ragged last chunks; chunks that split the prompt (attention over rows an earlier chunk wrote)"""
     c = synth.preset("tiny_v3", "q2_k", mla)
     T = synth.synth_model(c, seed=41)
     rng = np.random.default_rng(P * 31 + pos0)
