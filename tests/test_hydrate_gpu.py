@@ -62,7 +62,7 @@ def compare_hydrate(ctx, c, T=None, seed=None, tokens=(), pos0=0, chunk=None, re
         lb = B.hydrate(tokens, pos0, dsk.MODE_OUTPUT_LOGITS)
         P = len(tokens)
         res = {"batched": B.info("hydrate_batched_tokens"), "looped": B.info("hydrate_looped_tokens")}
-        cap = chunk or 128
+        cap = chunk or 512  # (the engine's default chunk)
         first_of_last_chunk = ((P - 1) // cap) * cap
         bad_x = []
         for i in range(first_of_last_chunk, P):  # the batched trace holds the last chunk

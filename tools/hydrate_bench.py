@@ -18,9 +18,11 @@ for p in (ROOT, os.path.join(ROOT, "deepseek.cpp_amd")):
         sys.path.insert(0, p)
 
 
-def measure(ctx, c, Ps, reps=2, seed=0, chunk=128, opts=None, loop=True):
+def measure(ctx, c, Ps, reps=2, seed=0, chunk=0, opts=None, loop=True):
     import dsk
-    o = {"q2k_tiles": 2, "hydrate_chunk": chunk}
+    o = {"q2k_tiles": 2}
+    if chunk:
+        o["hydrate_chunk"] = chunk  # (0: the engine's default)
     o.update(opts or {})
     M = dsk.Model(ctx, c, None, synth_seed=seed, options=o)
     why = M.hydrate_why_not()
@@ -50,7 +52,7 @@ def measure(ctx, c, Ps, reps=2, seed=0, chunk=128, opts=None, loop=True):
     out["hydrate"] = res
     # distinct experts the LAST chunk's last MoE block touched (the bytes a chunk streams are proportional to it)
     try:
-        cap = chunk
+        cap = chunk or 512
         re = M.hydrate_buffer("route_e", (cap, max(1, c.n_active_routed)), np.int32)[:min(Ps[-1], cap)]
         cnt = np.bincount(re.reshape(-1), minlength=c.n_routed_experts)
         out["last_chunk_experts"] = {"distinct": int((cnt > 0).sum()), "max_tokens": int(cnt.max())}
@@ -68,7 +70,7 @@ def main():
     ap.add_argument("--P", default="16,64,128")
     ap.add_argument("--layers", type=int, default=0)
     ap.add_argument("--reps", type=int, default=2)
-    ap.add_argument("--chunk", type=int, default=128)
+    ap.add_argument("--chunk", type=int, default=0, help="hydrate_chunk (0: the engine's default)")
     ap.add_argument("--opt", action="append", default=[])
     ap.add_argument("--no-loop", action="store_true", help="skip the per-token loop (a kernel trace of the batched path only)")
     ap.add_argument("--attn", default="mha", choices=["mha", "mla"])
