@@ -252,8 +252,8 @@ int dsk_forward(dsk_model* m, int token, int pos, int mode, float* host_logits);
  *     for i < n_tokens - 1:  dsk_forward(m, tokens[i], pos0 + i, DSK_MODE_HYDRATE_KV_CACHE, NULL)
  *     dsk_forward(m, tokens[n_tokens - 1], pos0 + n_tokens - 1, mode, host_logits)
  * and runs it as batched launches - every weight matrix read once per chunk of up to "hydrate_chunk" tokens (option,
- * default 128), the Q2_K row products as i8 GEMMs on the matrix pipe - when the model qualifies: Q2_K weights stored as tile
- * records (option "q2k_tiles" = 2 before binding), MHA attention with a q latent, one GPU, and positions below the ring
+ * default 512), the Q2_K row products as i8 GEMMs on the matrix pipe - when the model qualifies: Q2_K weights stored as tile
+ * records (option "q2k_tiles" = 2 before binding), MHA or MLA attention with a q latent (MLA: positions below 319), one GPU, and positions below the ring
  * wrap (rs_original_max_position_embeddings).  KV-cache rows, routing and logits are then BIT-identical to the loop
  * (tests/test_hydrate_gpu.py).  Anything else - other models, the tokens at and past the wrap - runs the loop itself, so
  * the call is always valid.  dsk_hydrate_why_not: "" when the batched path applies to this model, else the reason.
