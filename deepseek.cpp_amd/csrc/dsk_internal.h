@@ -484,8 +484,10 @@ struct HydGemmArgs {
   float* out;
   int out_stride;
   int epilogue, act;      // EPI_STORE / EPI_ADD (ignored for GLU pairs); DSK_ACT_*
+  const unsigned* a_dig;  // optional: the sub-block sums as digit words (launch_hyd_digits): the quads' min term then rides the matrix pipe
 };
 int launch_hyd_gemm(hipStream_t st, const HydGemmArgs& A, int nq);
+int launch_hyd_digits(hipStream_t st, const int16_t* bsums, unsigned* dig, size_t count);
 int launch_hyd_norm_q8(hipStream_t st, int NW, const float* X, int P, int n, const float* norm_w, float eps, int8_t* qs, float* d, int16_t* bsums);
 struct HydLatentArgs {
   const float *q_a, *kv_a, *q_norm, *kv_norm;

@@ -34,6 +34,7 @@ struct HydQ8 {
   int8_t* qs = nullptr;
   float* d = nullptr;
   int16_t* bsums = nullptr;
+  unsigned* dig = nullptr;  // the sums as digit words (the inputs of the grouped expert GEMMs only)
 };
 struct HydState {
   int cap = 0;
@@ -152,6 +153,8 @@ static int hyd_ensure_alloc(dsk_model* m) {
   DSK_TRY(hyd_alloc(h, (void**)&h->list, E * P * 4, &tot));
   DSK_TRY(hyd_alloc(h, (void**)&h->count, E * 4, &tot));
   DSK_TRY(hyd_alloc_q8(h, h->a_x, P, dim, &tot));
+  DSK_TRY(hyd_alloc(h, (void**)&h->a_x.dig, P * (dim / 16) * 4, &tot));
+  DSK_TRY(hyd_alloc(h, (void**)&h->a_hb.dig, P * K * (mi / 16) * 4, &tot));
   DSK_TRY(hyd_alloc_q8(h, h->a_qa, P, c.q_lora_rank, &tot));
   DSK_TRY(hyd_alloc_q8(h, h->a_kva, P, c.kv_lora_rank, &tot));
   DSK_TRY(hyd_alloc_q8(h, h->a_att, P, H * vd, &tot));
@@ -272,16 +275,20 @@ static int hyd_layer(dsk_model* m, int l, int P, int max_kv) {
     memset(&A, 0, sizeof A);
     A.W = w1.qs; A.W3 = w3.qs; A.e_bytes = w1.e_qs; A.n_experts = E; A.rows = mi; A.n = dim;
     A.a_qs = h.a_x.qs; A.a_d = h.a_x.d; A.a_bsums = h.a_x.bsums; A.a_rows = P; A.a_div = K;
+    DSK_TRY(launch_hyd_digits(st, h.a_x.bsums, h.a_x.dig, (size_t)P * (dim / 16)));
+    A.a_dig = h.a_x.dig;
     A.list = h.list; A.count = h.count; A.list_stride = h.cap;
     A.out = h.hb; A.out_stride = mi; A.act = c.act;
     DSK_TRY(launch_hyd_gemm(st, A, nq_e));
   }
   DSK_TRY(launch_quantize_q8k(st, h.hb, P * K * mi, h.a_hb.qs, h.a_hb.d, h.a_hb.bsums));
+  DSK_TRY(launch_hyd_digits(st, h.a_hb.bsums, h.a_hb.dig, (size_t)P * K * (mi / 16)));
   {
     HydGemmArgs A;
     memset(&A, 0, sizeof A);
     A.W = w2.qs; A.e_bytes = w2.e_qs; A.n_experts = E; A.rows = dim; A.n = mi;
     A.a_qs = h.a_hb.qs; A.a_d = h.a_hb.d; A.a_bsums = h.a_hb.bsums; A.a_rows = P * K; A.a_div = 1;
+    A.a_dig = h.a_hb.dig;
     A.list = h.list; A.count = h.count; A.list_stride = h.cap;
     A.out = h.eout; A.out_stride = dim; A.epilogue = EPI_STORE; A.act = c.act;
     DSK_TRY(launch_hyd_gemm(st, A, nq_e));

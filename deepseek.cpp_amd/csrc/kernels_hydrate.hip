@@ -78,28 +78,58 @@ DEV void hyd_acc_zero(HydAcc& a) {
 // the activation side of one block for one token quad: the four selector-row operands, the tokens' sub-block sums and scale
 struct HydAct {
   i32x4 a[4];
-  u32x4 bs0, bs1;
+  u32x4 bs0, bs1;  // the token's 16 sub-block sums (result side; DIG: bs0 = the digit words of ONE group, operand side)
   float dx;
 };
+// DIG: the sums come as digit words (hyd16_split, launch_hyd_digits) and the min term rides the matrix pipe: row (t, g4) of the
+// operand holds token t's four words of group g4 in K-group kg == g4 (goff: out of range for the other lanes)
+template <bool DIG>
 DEV void hyd_act_load(HydAct& X, const rsrc_t& RA, const rsrc_t& RB, const rsrc_t& RD, int off0, int off1, int boff, int doff, int b) {
   X.a[0] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(RA, off0, b * 256, 0));
   X.a[1] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(RA, off0 + 32, b * 256, 0));
   X.a[2] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(RA, off1, b * 256, 0));
   X.a[3] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(RA, off1 + 32, b * 256, 0));
-  X.bs0 = __builtin_amdgcn_raw_buffer_load_b128(RB, boff, b * 32, 0);
-  X.bs1 = __builtin_amdgcn_raw_buffer_load_b128(RB, boff + 16, b * 32, 0);
+  if (DIG) {
+    X.bs0 = __builtin_amdgcn_raw_buffer_load_b128(RB, boff, b * 64, 0);
+  } else {
+    X.bs0 = __builtin_amdgcn_raw_buffer_load_b128(RB, boff, b * 32, 0);
+    X.bs1 = __builtin_amdgcn_raw_buffer_load_b128(RB, boff + 16, b * 32, 0);
+  }
   X.dx = u2f(__builtin_amdgcn_raw_buffer_load_b32(RD, doff, b * 4, 0));
 }
 // one block of one tile for one token quad: D = the four exact group sums of this lane's (token, row)
-DEV void hyd_block(const HydTile& T, const i32x4 (&B)[4], const HydAct& X, HydAcc& acc) {
+// the min operand of a tile's weight side: K-group kg carries sub-blocks 4 kg + i as {m, 8 m, 8 m, 0} (against the digit words)
+DEV i32x4 hyd_bm(const HydTile& T, int kg) {
+  const u32 scm = kg == 0 ? T.sc[0] : kg == 1 ? T.sc[1] : kg == 2 ? T.sc[2] : T.sc[3];
+  i32x4 Bm;
+  Bm.x = (int)(((scm >> 4) & 0xFu) * 0x00080801u);
+  Bm.y = (int)(((scm >> 12) & 0xFu) * 0x00080801u);
+  Bm.z = (int)(((scm >> 20) & 0xFu) * 0x00080801u);
+  Bm.w = (int)(((scm >> 28) & 0xFu) * 0x00080801u);
+  return Bm;
+}
+template <bool DIG>
+DEV void hyd_block(const HydTile& T, const i32x4 (&B)[4], const i32x4& Bm, const HydAct& X, HydAcc& acc) {
   i32x4 D = {0, 0, 0, 0};
   D = __builtin_amdgcn_mfma_i32_16x16x64_i8(X.a[0], B[0], D, 0, 0, 0);
   D = __builtin_amdgcn_mfma_i32_16x16x64_i8(X.a[1], B[1], D, 0, 0, 0);
   D = __builtin_amdgcn_mfma_i32_16x16x64_i8(X.a[2], B[2], D, 0, 0, 0);
   D = __builtin_amdgcn_mfma_i32_16x16x64_i8(X.a[3], B[3], D, 0, 0, 0);
-  const u32 bw[8] = {X.bs0.x, X.bs0.y, X.bs0.z, X.bs0.w, X.bs1.x, X.bs1.y, X.bs1.z, X.bs1.w};  // 16 int16 sub-block sums of the token
   const int Dg[4] = {D.x, D.y, D.z, D.w};
   const float dd = X.dx * h2f(T.dm & 0xffff), dmn = X.dx * h2f(T.dm >> 16);
+  if (DIG) {
+    // row (t, g4) x K-group g4 against the mins: lane (n, t) gets the four groups' sum_j m_j b_j - exact (hyd16_split)
+    const i32x4 z = {0, 0, 0, 0};
+    const i32x4 M = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, X.bs0), Bm, z, 0, 0, 0);
+    const int Mg[4] = {M.x, M.y, M.z, M.w};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      acc.ad[g] = fmaf(dd, (float)Dg[g], acc.ad[g]);
+      acc.am[g] = fmaf(dmn, (float)Mg[g], acc.am[g]);
+    }
+    return;
+  }
+  const u32 bw[8] = {X.bs0.x, X.bs0.y, X.bs0.z, X.bs0.w, X.bs1.x, X.bs1.y, X.bs1.z, X.bs1.w};  // 16 int16 sub-block sums of the token
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const u32 m4 = (T.sc[g] >> 4) & 0x0F0F0F0Fu;                                   // the group's four 4-bit mins
@@ -129,7 +159,7 @@ DEV float hyd_value(const HydAcc& acc) { return (acc.S[0] + acc.S[1]) + (acc.S[2
 // Software pipeline of a pass: the tiles of blocks b + 1 and b + 2 and the activation operands of block b + 1 are in flight
 // while block b is multiplied (a wave is a chain of dependent memory round trips otherwise: measured 3 - 15x the streaming time).
 // Quads past the task's rows read zeros (out-of-range buffer offsets) and are not stored.
-template <bool GLU, int NQ, bool SPREAD>
+template <bool GLU, int NQ, bool SPREAD, bool DIG = false>
 __global__ __launch_bounds__(SPREAD && !GLU ? 512 : 256) void hyd_gemm_kernel(const HydGemmArgs A) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int nwaves = (int)blockDim.x >> 6;
@@ -160,7 +190,7 @@ __global__ __launch_bounds__(SPREAD && !GLU ? 512 : 256) void hyd_gemm_kernel(co
   const int* list = A.list ? A.list + (size_t)task * A.list_stride : nullptr;
   const bool seg4 = nb > 8;  // tile_seg
   const rsrc_t RA = make_rsrc_n(A.a_qs, (u32)((size_t)A.a_rows * n));
-  const rsrc_t RB = make_rsrc_n(A.a_bsums, (u32)((size_t)A.a_rows * (n >> 4) * 2));
+  const rsrc_t RB = DIG ? make_rsrc_n(A.a_dig, (u32)((size_t)A.a_rows * (n >> 4) * 4)) : make_rsrc_n(A.a_bsums, (u32)((size_t)A.a_rows * (n >> 4) * 2));
   const rsrc_t RD = make_rsrc_n(A.a_d, (u32)((size_t)A.a_rows * nb * 4));
   // activation operand: this lane is row (tl, g4l) of K-group kg; it holds data for fields 2c, 2c + 1 (c = g4l & 1) when its
   // group's K half is its own
@@ -186,13 +216,14 @@ __global__ __launch_bounds__(SPREAD && !GLU ? 512 : 256) void hyd_gemm_kernel(co
       const bool okD = eD < cnt;
       const int vD = okD ? (list ? list[eD] : eD) : 0;
       const int arowD = vD / A.a_div;
-      boff[q] = okD ? arowD * (n >> 4) * 2 : HYD_OOB;
+      // (DIG: the digit words sit on the OPERAND side - row (tl, g4l), K-group g4l - like the codes)
+      boff[q] = DIG ? (okA && kg == g4l ? (arow * (n >> 4) + 4 * g4l) * 4 : HYD_OOB) : (okD ? arowD * (n >> 4) * 2 : HYD_OOB);
       doff[q] = okD ? arowD * nb * 4 : HYD_OOB;
       outv[q] = okD ? vD : -1;
     }
     HydAct X[NQ], Y[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) hyd_act_load(X[q], RA, RB, RD, off0[q], off1[q], boff[q], doff[q], 0);
+    for (int q = 0; q < NQ; ++q) hyd_act_load<DIG>(X[q], RA, RB, RD, off0[q], off1[q], boff[q], doff[q], 0);
     if (!first_pass) {  // a further pass over the same strip (L2 hits)
       hyd_tile_load(T1, W1, lane, 0);
       if (GLU) hyd_tile_load(T3, W3, lane, 0);
@@ -213,22 +244,24 @@ __global__ __launch_bounds__(SPREAD && !GLU ? 512 : 256) void hyd_gemm_kernel(co
       }
       if (b + 1 < nb) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) hyd_act_load(Y[q], RA, RB, RD, off0[q], off1[q], boff[q], doff[q], b + 1);
+        for (int q = 0; q < NQ; ++q) hyd_act_load<DIG>(Y[q], RA, RB, RD, off0[q], off1[q], boff[q], doff[q], b + 1);
       }
       const bool item_end = !seg4 || (b & 3) == 3 || b == nb - 1;  // tile_device.h: items of 4 blocks, or 1 for rows of <= 8
       {
-        i32x4 B[4];
+        i32x4 B[4], Bm = {0, 0, 0, 0};
         hyd_expand(T1, kg, B);
+        if (DIG) Bm = hyd_bm(T1, kg);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-          hyd_block(T1, B, X[q], acc1[q]);
+          hyd_block<DIG>(T1, B, Bm, X[q], acc1[q]);
           if (item_end) hyd_item_end(acc1[q]);
         }
         if (GLU) {
           hyd_expand(T3, kg, B);
+          if (DIG) Bm = hyd_bm(T3, kg);
 #pragma unroll
           for (int q = 0; q < NQ; ++q) {
-            hyd_block(T3, B, X[q], acc3[q]);
+            hyd_block<DIG>(T3, B, Bm, X[q], acc3[q]);
             if (item_end) hyd_item_end(acc3[q]);
           }
         }
@@ -633,7 +666,8 @@ static void hyd_gemm_launch(hipStream_t st, const HydGemmArgs& A) {
     hipLaunchKernelGGL((hyd_gemm16_kernel<GLU, NW>), dim3((unsigned)(A.n_experts * groups), 1u), dim3(64 * NW), 2 * HYD16_STAGE_B, st, B);
     HydGemmArgs C = A;
     C.cnt_max = HYD16_EXPERT_MIN - 1;
-    hipLaunchKernelGGL((hyd_gemm_kernel<GLU, NQ, false>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st, C);
+    if (C.a_dig) hipLaunchKernelGGL((hyd_gemm_kernel<GLU, NQ, false, true>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st, C);
+    else hipLaunchKernelGGL((hyd_gemm_kernel<GLU, NQ, false>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st, C);
     return;
   }
   // plain matrices times many tokens: 16 tokens per wave (hyd_gemm16_kernel), the waves of a workgroup on consecutive chunks of one strip
@@ -668,6 +702,15 @@ static void hyd_gemm_launch(hipStream_t st, const HydGemmArgs& A) {
   } else {
     hipLaunchKernelGGL((hyd_gemm_kernel<GLU, NQ, false>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st, A);
   }
+}
+// sub-block sums -> digit words (hyd16_split): the operand of the quads' min-term matrix instruction
+__global__ __launch_bounds__(256) void hyd_digits_kernel(const int16_t* __restrict__ bsums, u32* __restrict__ dig, size_t count) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < count) dig[i] = hyd16_split((int)bsums[i]);
+}
+int launch_hyd_digits(hipStream_t st, const int16_t* bsums, unsigned* dig, size_t count) {
+  hipLaunchKernelGGL(hyd_digits_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, bsums, dig, count);
+  return DSK_OK;
 }
 int launch_hyd_gemm(hipStream_t st, const HydGemmArgs& A, int nq) {
   if (A.n % 256 || A.rows < 1 || A.a_rows < 1 || A.a_div < 1) DSK_FAIL(DSK_ERR_INVALID, "hyd_gemm: bad shape");
