@@ -269,7 +269,7 @@ static int hyd_layer(dsk_model* m, int l, int P, int max_kv) {
   const DTensor &w1 = L.t[DSK_ROLE_W1], &w2 = L.t[DSK_ROLE_W2], &w3 = L.t[DSK_ROLE_W3];
   // 4 tokens per wave and pass unless the experts are crowded: 8 tokens cost the GLU pair half of its waves (260 registers), while a
   // second pass over a strip re-reads 75 KB that the first pass just pulled through L2
-  const int nq_e = (double)P * K / E > 6.0 ? 2 : 1;
+  const int nq_e = 1;  // (tasks of 6 rows and more go through the 16-token form: what is left for the quads fits one or two passes)
   {
     HydGemmArgs A;
     memset(&A, 0, sizeof A);
