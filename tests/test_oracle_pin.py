@@ -193,6 +193,54 @@ def test_scaled_int8_expansion_of_q2k_reproduces_the_reference_block_sums(oracle
     assert np.array_equal(got.astype(np.float32), want)
 
 
+def test_group_operands_and_digit_words_of_the_16_token_gemm_reproduce_the_reference_block_sums(oracle):
+    """DESIGN.md 4.9, second GEMM form, modelled lane by lane on the CPU: one 16x16x64 matrix instruction per sub-block GROUP g,
+    lane (row n, K-group kg') supplying sub-block 4 g + kg' = field 2 (g & 1) + (kg' >> 1) of the qs bytes of K-group
+    2 (g >> 1) + (kg' & 1) (its own 16 bytes or those of the lane 32 away), times its 4-bit scale; the token's 16 codes of that
+    sub-block in natural order on the other side; and the min term as ONE more instruction per group: the sub-block sums split
+    b = 8 (v1 + v2) + v0 into int8 digits against {m, 8 m, 8 m, 0}.  The sums must be the isum / summs of ggml_vec_dot_q2_K_q8_K
+    (src/quant.cpp:666-783) exactly."""
+    rng = np.random.default_rng(78)
+    # the digit split over the whole range of a Q8_K sub-block sum
+    for b in range(-2032, 2033):
+        v0, q = b & 7, b >> 3
+        v1 = q >> 1
+        v2 = q - v1
+        assert 0 <= v0 <= 7 and -128 <= v1 <= 127 and -128 <= v2 <= 127 and 8 * (v1 + v2) + v0 == b
+    rows, n, T = 16, 512, 5
+    w = synth.encode_q2k((rng.standard_normal((rows, n)) / np.sqrt(n)).astype(np.float32)).reshape(rows, n // 256, 84).copy()
+    w[:, :, 80:84] = np.frombuffer(np.array([1.0, 1.0], np.float16).tobytes(), np.uint8)
+    acts = rng.integers(-127, 128, (T, n)).astype(np.int8)
+    for t in range(T):
+        want = oracle.gemv_q8(3, np.ascontiguousarray(w.reshape(rows, -1)), rows, n, acts[t], np.ones(n // 256, np.float32))
+        got = np.zeros(rows, np.float64)
+        for b in range(n // 256):
+            a = acts[t, b * 256:(b + 1) * 256].astype(np.int64)
+            bsum = [int(a[16 * j:16 * j + 16].sum()) for j in range(16)]
+            for r in range(rows):
+                blk = w[r, b]
+                sc, qs = blk[:16].astype(np.int64), blk[16:80].astype(np.int64)
+                lane_bytes = [qs[16 * kg:16 * kg + 16] for kg in range(4)]      # the tile record: lane (n, kg) holds qs bytes [16 kg, 16 kg + 16)
+                for g in range(4):
+                    D = M = 0
+                    for kgp in range(4):                                        # K-group kg' of the instruction for group g
+                        kg_src = 2 * (g >> 1) + (kgp & 1)                       # own lane iff kg_src == kgp, else the lane 32 away
+                        assert kg_src == kgp or abs(kg_src - kgp) == 2
+                        field = 2 * (g & 1) + (kgp >> 1)
+                        j = 4 * g + kgp
+                        assert j == 8 * (kg_src >> 1) + 2 * field + (kg_src & 1)   # the sub-block those bytes' field belongs to
+                        wk = ((lane_bytes[kg_src] >> (2 * field)) & 3) * (sc[j] & 0xF)
+                        assert wk.max() <= 45
+                        D += int((wk * a[16 * j:16 * j + 16]).sum())            # the token's codes of sub-block j, natural order
+                        v0, q = bsum[j] & 7, bsum[j] >> 3
+                        v1 = q >> 1
+                        m = int(sc[j] >> 4)
+                        assert 8 * m <= 120
+                        M += v0 * m + v1 * 8 * m + (q - v1) * 8 * m
+                    got[r] += D - M
+        assert np.array_equal(got.astype(np.float32), want), t
+
+
 def test_live_router_gate_exact(oracle, ref):
     rng = np.random.default_rng(4)
     for _ in range(20):
