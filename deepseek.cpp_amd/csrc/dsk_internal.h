@@ -299,6 +299,7 @@ int launch_planes_to_tiles_q2k(hipStream_t st, const uint8_t* qs, const uint8_t*
                                size_t e_bytes, uint8_t* tiles);
 int launch_repack_q3k(hipStream_t st, const uint8_t* aos, size_t n_blocks, uint8_t* qs, uint8_t* hm, uint8_t* sc, uint8_t* dm);
 int launch_embed(hipStream_t st, const DTensor& t, const StepParams* sp, int token_override, int b0, int b1, float* x);
+int launch_embed_rows(hipStream_t st, const DTensor& t, const StepParams* sps, int P, int b0, int b1, float* x);  // P rows, tokens from the step rows
 struct RouterArgs {       // F32 router GEMV (+ optional rmsnorm prologue) + moe_gate in the last workgroup
   const float* w;         // (E, dim)
   const float* x;         // input vector (f32)

@@ -239,6 +239,7 @@ extern "C" int dsk_model_create(dsk_ctx* ctx, const dsk_config* cfg, dsk_model**
   if (getenv("DSK_NO_MOE_Q8_HANDOFF")) m->moe_q8_handoff = false;
   if (getenv("DSK_TAIL_PF")) m->tail_prefetch = atoi(getenv("DSK_TAIL_PF"));
   if (getenv("DSK_NO_FUSE_MOE_FLOAT")) m->fuse_moe_float = false;
+  m->hydrate_route_seed = std::max(0, env_i("DSK_HYD_ROUTE_SEED", 0));  // measurement only: uniform routing in the batched prompt path
 #endif
   *out = m;
   return DSK_OK;
@@ -268,8 +269,7 @@ extern "C" int dsk_model_set_option(dsk_model* m, const char* key, int value) {
   else if (k == "exchange_allgather") m->exchange_allgather = value != 0;
   else if (k == "hydrate_chunk") { if (value < 1 || value > 1024) DSK_FAIL(DSK_ERR_INVALID, "set_option: hydrate_chunk %d (1 .. 1024)", value); m->hydrate_chunk = value; }
   else if (k == "hydrate_batched") m->hydrate_batched = value != 0;
-  else if (k == "hydrate_stop_layer") m->hydrate_stop_layer = value;
-  else if (k == "hydrate_route_seed") m->hydrate_route_seed = value;
+  else if (k == "hydrate_tap_layer") { if (value < -1 || value >= m->c.n_layers) DSK_FAIL(DSK_ERR_INVALID, "set_option: hydrate_tap_layer %d", value); m->hydrate_tap_layer = value; }
   else if (k == "q2k_tiles") {
     if (m->any_bound) DSK_FAIL(DSK_ERR_STATE, "set_option: q2k_tiles must be set before the first tensor is bound");
     if (value < 0 || value > 2) DSK_FAIL(DSK_ERR_INVALID, "set_option: q2k_tiles %d (0 none, 1 experts, 2 every converted role)", value);

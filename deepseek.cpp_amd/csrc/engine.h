@@ -144,8 +144,10 @@ struct dsk_model {
   struct HydState* hyd = nullptr;
   int hydrate_chunk = 512;          // option "hydrate_chunk": tokens per batched chunk (every weight matrix is read once per chunk: a 512-token prompt
                                     // takes 424 ms in chunks of 128, 379 in chunks of 256, 333 in one; ~0.6 GB of chunk buffers at DeepSeek-V3 width)
-  int hydrate_route_seed = 0;       // option "hydrate_route_seed" (measurement only): > 0 = the batched path routes every token to K uniformly drawn experts
-  int hydrate_stop_layer = 0;       // option "hydrate_stop_layer" (debug): > 0: a batched chunk stops after block value - 1 (dsk_hydrate_get_buffer)
+  int hydrate_route_seed = 0;       // -DDSK_AB builds only (env DSK_HYD_ROUTE_SEED, tools/ab_build.sh): > 0 = the batched path routes every token to K
+                                    // uniformly drawn experts - a measurement of balanced routing; the shipped library has no way to set it
+  int hydrate_tap_layer = -1;       // option "hydrate_tap_layer" (parity harness): the block whose intermediates a batched chunk copies aside for
+                                    // dsk_hydrate_get_buffer; the chunk itself runs unchanged
   bool hydrate_batched = true;      // option "hydrate_batched": 0 = dsk_hydrate always runs the per-token loop
   long long hydrate_batched_tokens = 0, hydrate_looped_tokens = 0;  // dsk_model_get_info
   const char* hydrate_why = nullptr;  // why the last dsk_hydrate call looped (nullptr: it did not)

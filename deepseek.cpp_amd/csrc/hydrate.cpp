@@ -25,6 +25,7 @@
 #include <math.h>
 #include <string.h>
 #include <algorithm>
+#include <map>
 #include <string>
 
 int fill_step_params_at(dsk_model* m, int token, int pos, StepParams* sp);  // forward.cpp
@@ -43,9 +44,14 @@ struct HydState {
   HydQ8 a_x, a_qa, a_kva, a_att, a_hd, a_hb, a_hsh, a_lat;
   float *q_rope = nullptr, *q_c = nullptr, *latent = nullptr;  // MLA: (P, H * rope), (P, H * lora), (P, H * lora)
   int *head_list = nullptr, *head_count = nullptr;              // MLA: wv_b as one GEMM task per head
-  StepParams *sp = nullptr, *sp_host = nullptr;
+  StepParams *sp = nullptr, *sp_host = nullptr;  // the chunk's step rows; the pinned side is two halves used in turn (sp_done)
+  hipEvent_t sp_done[2] = {nullptr, nullptr};     // the upload that last read half k
+  int sp_turn = 0;
   unsigned* router_counter = nullptr;
   int *route_e = nullptr, *list = nullptr, *count = nullptr;
+  int last_P = 0;                                 // tokens of the last batched chunk (what the accessors may hand out)
+  // parity harness (option "hydrate_tap_layer"): copies of ONE block's intermediates, taken while the chunk runs on
+  std::map<std::string, std::pair<void*, size_t>> taps;  // name -> (device copy of `cap` rows, bytes per row)
   std::vector<void*> allocs;
 };
 
@@ -67,6 +73,7 @@ void hydrate_free(dsk_model* m) {
   if (!m->hyd) return;
   for (void* p : m->hyd->allocs) hipFree(p);
   if (m->hyd->sp_host) hipHostFree(m->hyd->sp_host);
+  for (hipEvent_t e : m->hyd->sp_done) if (e) hipEventDestroy(e);
   delete m->hyd;
   m->hyd = nullptr;
 }
@@ -99,6 +106,10 @@ static const char* hyd_why_not(const dsk_model* m) {
       for (int role : {DSK_ROLE_SHARED_W1, DSK_ROLE_SHARED_W2, DSK_ROLE_SHARED_W3})
         if (!tiled(L, role)) return "the shared expert is not stored as tile records";
     if (L.is_moe && c.moe_intermediate_size % 256) return "moe_intermediate_size";
+    // the norm + Q8_K launches reproduce the sum-of-squares tree of the decode launch that consumes the vector: built for 4 / 8 / 16 waves
+    for (int lp : {m->lp_qkv_a[l], c.use_mla ? m->lp_qkv_b[l] : -1, L.is_moe ? -1 : m->lp_w13[l]})
+      if (lp >= 0 && m->plans[lp].NW != 4 && m->plans[lp].NW != 8 && m->plans[lp].NW != 16) return "a decode launch stages its vector with a workgroup size the batched path has no twin for";
+    if (m->lp_qkv_a[l] < 0 || (c.use_mla && m->lp_qkv_b[l] < 0) || (!L.is_moe && m->lp_w13[l] < 0)) return "a decode launch plan is missing";
   }
   return nullptr;
 }
@@ -162,13 +173,37 @@ static int hyd_ensure_alloc(dsk_model* m) {
   DSK_TRY(hyd_alloc_q8(h, h->a_hb, P * K, mi, &tot));
   DSK_TRY(hyd_alloc_q8(h, h->a_hsh, P, shn, &tot));
   DSK_TRY(hyd_alloc(h, (void**)&h->sp, P * sizeof(StepParams), &tot));
-  HIP_TRY(hipHostMalloc((void**)&h->sp_host, P * sizeof(StepParams), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&h->sp_host, 2 * P * sizeof(StepParams), hipHostMallocDefault));
+  for (hipEvent_t& e : h->sp_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   if (m->trace) DSK_TRY(hyd_alloc(h, (void**)&h->trace, (size_t)c.n_layers * P * dim * 4, &tot));
   m->scratch_bytes += tot;
   return DSK_OK;
 }
 
-// tokens per pass of a GEMM wave: 4 * nq (kernels_hydrate.hip NQ) for a task of `rows_per_task` activation rows on average
+// Parity harness (option "hydrate_tap_layer" = l): while block l of a chunk runs, its intermediates are COPIED aside - the chunk
+// itself is untouched (nothing is skipped, nothing is replaced), so a tapped call leaves the same caches and logits as any other.
+// `rows` rows of `row_bytes` each; the copy holds `cap` rows (dsk_hydrate_get_buffer reads the last chunk's).
+static int hyd_tap(dsk_model* m, int l, const char* name, const void* src, size_t rows, size_t row_bytes) {
+  if (l != m->hydrate_tap_layer || !src) return DSK_OK;
+  HydState& h = *m->hyd;
+  auto it = h.taps.find(name);
+  if (it == h.taps.end()) {
+    void* p = nullptr;
+    double tot = 0;
+    DSK_TRY(hyd_alloc(&h, &p, (size_t)h.cap * row_bytes, &tot));
+    m->scratch_bytes += tot;
+    it = h.taps.emplace(name, std::make_pair(p, row_bytes)).first;
+  }
+  if (it->second.second != row_bytes) DSK_FAIL(DSK_ERR_STATE, "hydrate tap '%s': row size changed", name);
+  HIP_TRY(hipMemcpyAsync(it->second.first, src, rows * row_bytes, hipMemcpyDeviceToDevice, m->ctx->stream));
+  return DSK_OK;
+}
+static int hyd_tap_q8(dsk_model* m, int l, const std::string& point, const HydQ8& q, size_t rows, size_t n) {
+  if (l != m->hydrate_tap_layer) return DSK_OK;
+  DSK_TRY(hyd_tap(m, l, ("q8." + point + ".qs").c_str(), q.qs, rows, n));
+  DSK_TRY(hyd_tap(m, l, ("q8." + point + ".d").c_str(), q.d, rows, (n / 256) * 4));
+  return DSK_OK;
+}
 
 static int hyd_gemm(dsk_model* m, const DTensor& w, const DTensor* w3, const HydQ8& a, int a_rows, int P, float* out, int out_stride, int epilogue) {
   HydGemmArgs A;
@@ -194,6 +229,9 @@ static int hyd_layer(dsk_model* m, int l, int P, int max_kv) {
   DSK_TRY(launch_hyd_norm_q8(st, m->plans[m->lp_qkv_a[l]].NW, h.X, P, dim, f32w(L.t[DSK_ROLE_ATTN_NORM]), c.norm_eps, h.a_x.qs, h.a_x.d, h.a_x.bsums));
   DSK_TRY(hyd_gemm(m, L.t[DSK_ROLE_WQ_A], nullptr, h.a_x, P, P, h.q_a, qlr, EPI_STORE));
   DSK_TRY(hyd_gemm(m, L.t[DSK_ROLE_WKV_A], nullptr, h.a_x, P, P, h.kv_a, kvl + rope, EPI_STORE));
+  DSK_TRY(hyd_tap_q8(m, l, "x_attn", h.a_x, P, dim));
+  DSK_TRY(hyd_tap(m, l, "q_a", h.q_a, P, (size_t)qlr * 4));
+  DSK_TRY(hyd_tap(m, l, "kv_a", h.kv_a, P, (size_t)(kvl + rope) * 4));
   if (c.use_mla) {
     // second stage on norm(q_a): wq_rope_b, wc (the prologue of gemv_kvwrite_tile_kernel: stage_q8 at that plan's workgroup size)
     DSK_TRY(launch_hyd_norm_q8(st, m->plans[m->lp_qkv_b[l]].NW, h.q_a, P, qlr, f32w(L.t[DSK_ROLE_Q_A_NORM]), c.norm_eps, h.a_qa.qs, h.a_qa.d, h.a_qa.bsums));
@@ -217,6 +255,12 @@ static int hyd_layer(dsk_model* m, int l, int P, int max_kv) {
       A.out = h.att; A.out_stride = vd; A.epilogue = EPI_STORE; A.act = c.act;
       DSK_TRY(launch_hyd_gemm(st, A, P <= 4 ? 1 : 2));
     }
+    DSK_TRY(hyd_tap_q8(m, l, "q_a", h.a_qa, P, qlr));
+    DSK_TRY(hyd_tap(m, l, "q_rope", h.q_rope, P, (size_t)H * rope * 4));
+    DSK_TRY(hyd_tap(m, l, "q_c", h.q_c, P, (size_t)H * kvl * 4));
+    DSK_TRY(hyd_tap(m, l, "latent_out", h.latent, P, (size_t)H * kvl * 4));
+    DSK_TRY(hyd_tap_q8(m, l, "latent", h.a_lat, P, (size_t)H * kvl));
+    DSK_TRY(hyd_tap(m, l, "vb_out", h.att, P, (size_t)H * vd * 4));
   } else {
     HydLatentArgs A;
     memset(&A, 0, sizeof A);
@@ -230,15 +274,25 @@ static int hyd_layer(dsk_model* m, int l, int P, int max_kv) {
     const AttnMhaArgs& a = m->head_attn[l].a;
     DSK_TRY(launch_hyd_kv_write(st, a, h.sp, P, h.kv_b, H * nv, h.kv_a, kvl + rope));
     DSK_TRY(launch_hyd_attn(st, a, h.sp, P, max_kv, h.q, H * hd, h.att, H * vd));
+    DSK_TRY(hyd_tap_q8(m, l, "q_a", h.a_qa, P, qlr));
+    DSK_TRY(hyd_tap_q8(m, l, "kv_a", h.a_kva, P, kvl));
+    DSK_TRY(hyd_tap(m, l, "q", h.q, P, (size_t)H * hd * 4));
+    DSK_TRY(hyd_tap(m, l, "kv_b", h.kv_b, P, (size_t)H * nv * 4));
+    DSK_TRY(hyd_tap(m, l, "att_out", h.att, P, (size_t)H * vd * 4));
   }
   DSK_TRY(launch_quantize_q8k(st, h.att, P * H * vd, h.a_att.qs, h.a_att.d, h.a_att.bsums));
   DSK_TRY(hyd_gemm(m, L.t[DSK_ROLE_WO], nullptr, h.a_att, P, P, h.X, dim, EPI_ADD));
+  DSK_TRY(hyd_tap_q8(m, l, "att", h.a_att, P, (size_t)H * vd));
+  DSK_TRY(hyd_tap(m, l, "x_mid", h.X, P, (size_t)dim * 4));
   // ---- FFN half (src/infer.cpp:836-931) ----
   if (!L.is_moe) {
     DSK_TRY(launch_hyd_norm_q8(st, m->plans[m->lp_w13[l]].NW, h.X, P, dim, f32w(L.t[DSK_ROLE_FFN_NORM]), c.norm_eps, h.a_x.qs, h.a_x.d, h.a_x.bsums));
     DSK_TRY(hyd_gemm(m, L.t[DSK_ROLE_W1], &L.t[DSK_ROLE_W3], h.a_x, P, P, h.hbd, c.hidden_dim, EPI_STORE));
     DSK_TRY(launch_quantize_q8k(st, h.hbd, P * c.hidden_dim, h.a_hd.qs, h.a_hd.d, h.a_hd.bsums));
     DSK_TRY(hyd_gemm(m, L.t[DSK_ROLE_W2], nullptr, h.a_hd, P, P, h.X, dim, EPI_ADD));
+    DSK_TRY(hyd_tap_q8(m, l, "x_ffn", h.a_x, P, dim));
+    DSK_TRY(hyd_tap(m, l, "hb", h.hbd, P, (size_t)c.hidden_dim * 4));
+    DSK_TRY(hyd_tap_q8(m, l, "hb", h.a_hd, P, c.hidden_dim));
     return DSK_OK;
   }
   const int K = c.n_active_routed, E = c.n_routed_experts, mi = c.moe_intermediate_size, shn = c.n_shared_experts * mi;
@@ -258,8 +312,9 @@ static int hyd_layer(dsk_model* m, int l, int P, int max_kv) {
     r.q_qs = h.a_x.qs; r.q_d = h.a_x.d; r.q_bsums = h.a_x.bsums;
     DSK_TRY(launch_hyd_router(st, r, P, h.hbd));  // (the dense FFN's hidden buffer holds the normed vectors: P x dim <= P x hidden_dim)
   }
-  if (m->hydrate_route_seed > 0)  // measurement only: uniform routing instead of the synthetic model's skewed one
-    DSK_TRY(launch_hyd_route_override(st, h.route_e, P, K, E, (unsigned)m->hydrate_route_seed * 1000003u + (unsigned)l));
+#ifdef DSK_AB  // measurement builds only (tools/ab_build.sh): uniform routing instead of the synthetic model's skewed one
+  if (m->hydrate_route_seed > 0) DSK_TRY(launch_hyd_route_override(st, h.route_e, P, K, E, (unsigned)m->hydrate_route_seed * 1000003u + (unsigned)l));
+#endif
   DSK_TRY(launch_hyd_group(st, h.route_e, P * K, E, h.list, h.cap, h.count));
   if (shn > 0) {
     DSK_TRY(hyd_gemm(m, L.t[DSK_ROLE_SHARED_W1], &L.t[DSK_ROLE_SHARED_W3], h.a_x, P, P, h.hb_sh, shn, EPI_STORE));
@@ -294,6 +349,20 @@ static int hyd_layer(dsk_model* m, int l, int P, int max_kv) {
     DSK_TRY(launch_hyd_gemm(st, A, nq_e));
   }
   DSK_TRY(launch_hyd_combine(st, h.X, h.eout, h.route_w, shn > 0 ? h.eout_sh : nullptr, P, K, dim));
+  if (l == m->hydrate_tap_layer) {
+    DSK_TRY(hyd_tap_q8(m, l, "x_ffn", h.a_x, P, dim));
+    DSK_TRY(hyd_tap(m, l, "router_logits", h.router_partial, P, (size_t)E * 4));  // (the row-resident router form: launch_hyd_router)
+    DSK_TRY(hyd_tap(m, l, "route_e", h.route_e, P, (size_t)K * 4));
+    DSK_TRY(hyd_tap(m, l, "route_w", h.route_w, P, (size_t)K * 4));
+    DSK_TRY(hyd_tap(m, l, "hb", h.hb, P, (size_t)K * mi * 4));
+    DSK_TRY(hyd_tap_q8(m, l, "hb", h.a_hb, P, (size_t)K * mi));
+    DSK_TRY(hyd_tap(m, l, "eout", h.eout, P, (size_t)K * dim * 4));
+    if (shn > 0) {
+      DSK_TRY(hyd_tap(m, l, "hb_sh", h.hb_sh, P, (size_t)shn * 4));
+      DSK_TRY(hyd_tap_q8(m, l, "hb_sh", h.a_hsh, P, shn));
+      DSK_TRY(hyd_tap(m, l, "eout_sh", h.eout_sh, P, (size_t)dim * 4));
+    }
+  }
   return DSK_OK;
 }
 
@@ -302,19 +371,38 @@ static int hyd_chunk(dsk_model* m, const int32_t* tokens, int P, int pos0) {
   const dsk_config& c = m->c;
   HydState& h = *m->hyd;
   hipStream_t st = m->ctx->stream;
-  // (the pinned step-parameter rows are re-used by every chunk: the previous chunk's asynchronous copy must have read them)
-  HIP_TRY(hipStreamSynchronize(st));
-  for (int p = 0; p < P; ++p) DSK_TRY(fill_step_params_at(m, tokens[p], pos0 + p, h.sp_host + p));
-  HIP_TRY(hipMemcpyAsync(h.sp, h.sp_host, (size_t)P * sizeof(StepParams), hipMemcpyHostToDevice, st));
-  for (int p = 0; p < P; ++p)  // Model::_copy_embedding, src/infer.cpp:1217-1263
-    DSK_TRY(launch_embed(st, m->g[DSK_ROLE_EMBED], nullptr, tokens[p], std::max(1, c.block_size[0]), std::max(1, c.block_size[1]), h.X + (size_t)p * c.dim));
+  // the pinned step-parameter rows: two halves used in turn, so that the host fills the next chunk's rows while the device still
+  // runs this one (only the upload that last read THIS half must have finished - the chunk before the previous one's)
+  const int half = h.sp_turn;
+  h.sp_turn ^= 1;
+  StepParams* rows = h.sp_host + (size_t)half * h.cap;
+  HIP_TRY(hipEventSynchronize(h.sp_done[half]));
+  for (int p = 0; p < P; ++p) DSK_TRY(fill_step_params_at(m, tokens[p], pos0 + p, rows + p));
+  HIP_TRY(hipMemcpyAsync(h.sp, rows, (size_t)P * sizeof(StepParams), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipEventRecord(h.sp_done[half], st));
+  // Model::_copy_embedding, src/infer.cpp:1217-1263: the P rows in one launch (the tokens come from the step rows)
+  DSK_TRY(launch_embed_rows(st, m->g[DSK_ROLE_EMBED], h.sp, P, std::max(1, c.block_size[0]), std::max(1, c.block_size[1]), h.X));
   const int max_kv = pos0 + P;
   for (int l = 0; l < c.n_layers; ++l) {
     DSK_TRY(hyd_layer(m, l, P, max_kv));
     if (h.trace) HIP_TRY(hipMemcpyAsync(h.trace + (size_t)l * h.cap * c.dim, h.X, (size_t)P * c.dim * 4, hipMemcpyDeviceToDevice, st));
-    if (m->hydrate_stop_layer > 0 && l + 1 >= m->hydrate_stop_layer) break;  // debug: leave this block's intermediates in the buffers
   }
   return DSK_OK;
+}
+
+// the first position the batched path must leave to the loop (the per-token decode step changes its float association there)
+static int hyd_position_limit(const dsk_model* m) {
+  // positions before the ring wraps (src/infer.cpp:1271-1277: from pos >= W on the sink keys are rotated in place, token by token)
+  int limit = std::min(m->c.max_seq_len, std::max(1, m->c.rs_original_max_position_embeddings));
+  // MLA: from mla_flash_min_kv cached positions on the decode path scores on the matrix cores (mla_flash_kernel: its own
+  // association); the batched path reproduces the short-context kernel only
+  if (m->c.use_mla && m->fl_part_o) limit = std::min(limit, std::max(1, m->mla_flash_min_kv - 1));
+  // MHA: from mha_split_min cached positions on decode runs mha_split workgroups per head over pieces of the context and merges
+  // un-normalised partials (head_attn_kernel) - another association than the whole-context softmax hyd_attn_kernel reproduces
+  if (!m->c.use_mla && m->mha_split > 1) limit = std::min(limit, std::max(1, m->mha_split_min - 1));
+  // the attention launches keep one float per cached position in LDS
+  limit = std::min(limit, 24 * 1024);
+  return limit;
 }
 
 extern "C" int dsk_hydrate(dsk_model* m, const int32_t* tokens, int n_tokens, int pos0, int mode, float* host_logits) {
@@ -330,21 +418,23 @@ extern "C" int dsk_hydrate(dsk_model* m, const int32_t* tokens, int n_tokens, in
   int done = 0;
   bool last_batched = false;
   const char* why = m->hydrate_batched ? hyd_why_not(m) : "option hydrate_batched is off";
+  if (!why && hyd_ensure(m) != DSK_OK) {  // no room for the chunk buffers: the call is still valid - it IS the loop
+    (void)hipGetLastError();
+    dsk_clear_error();
+    why = "the chunk buffers do not fit the device's free memory";
+  }
   m->hydrate_why = why;
   if (!why) {
-    DSK_TRY(hyd_ensure(m));
-    // positions before the ring wraps (src/infer.cpp:1271-1277: from pos >= W on the sink keys are rotated in place, token by token)
-    int limit = std::min(m->c.max_seq_len, std::max(1, m->c.rs_original_max_position_embeddings));
-    // MLA: from mla_flash_min_kv cached positions on the decode path scores on the matrix cores (mla_flash_kernel: its own
-    // association); the batched path reproduces the short-context kernel only
-    if (m->c.use_mla && m->fl_part_o) limit = std::min(limit, std::max(1, m->mla_flash_min_kv - 1));
+    const int limit = hyd_position_limit(m);
     int last_P = 0;
     while (done < n_tokens) {
       const int P = std::min(std::min(m->hyd->cap, n_tokens - done), limit - (pos0 + done));
       if (P < 1) break;
       DSK_TRY(hyd_chunk(m, tokens + done, P, pos0 + done));
+      HIP_TRY(hipGetLastError());  // a launch the runtime refused surfaces here, before the next chunk builds on its cache rows
       done += P;
       last_P = P;
+      m->hyd->last_P = P;
       m->hydrate_batched_tokens += P;
       last_batched = done == n_tokens;
     }
@@ -368,7 +458,8 @@ extern "C" int dsk_hydrate(dsk_model* m, const int32_t* tokens, int n_tokens, in
 // dsk_hydrate call): the batched counterpart of dsk_model_get_trace_x
 extern "C" int dsk_hydrate_get_trace_x(dsk_model* m, int layer, int index, float* x_out) {
   if (!m || !m->hyd || !m->hyd->trace || !x_out) DSK_FAIL(DSK_ERR_STATE, "hydrate_get_trace_x: no batched trace (dsk_model_set_trace(1) before the first dsk_hydrate)");
-  if (layer < 0 || layer >= m->c.n_layers || index < 0 || index >= m->hyd->cap) DSK_FAIL(DSK_ERR_INVALID, "hydrate_get_trace_x: layer %d index %d", layer, index);
+  if (layer < 0 || layer >= m->c.n_layers || index < 0 || index >= m->hyd->last_P)
+    DSK_FAIL(DSK_ERR_INVALID, "hydrate_get_trace_x: layer %d index %d (the last batched chunk held %d tokens)", layer, index, m->hyd->last_P);
   HIP_TRY(hipSetDevice(m->ctx->device));
   HIP_TRY(hipMemcpy(x_out, m->hyd->trace + ((size_t)layer * m->hyd->cap + index) * m->c.dim, (size_t)m->c.dim * 4, hipMemcpyDeviceToHost));
   return DSK_OK;
@@ -380,40 +471,29 @@ extern "C" const char* dsk_hydrate_why_not(dsk_model* m) {
   return why ? why : "";
 }
 
-// Parity harness / debugging: one of the batched path's intermediate buffers as the last chunk left it (rows = tokens, or
-// (token, slot) pairs for "hb" / "eout").  With option "hydrate_stop_layer" = l + 1 the chunk stops after block l, so the
-// buffers hold THAT block's intermediates.
-extern "C" int dsk_hydrate_get_buffer(dsk_model* m, const char* name, void* out, size_t bytes) {
+// Parity harness: rows [row0, row0 + rows) of a named intermediate of the LAST batched chunk.
+//   With option "hydrate_tap_layer" = l the names are block l's stages, copied aside while the chunk ran (hyd_tap above; the
+//   names tests/teacher.py uses for dsk_model_get_stage): "q8.x_attn.qs" / ".d", "q_a", "kv_a", "q8.q_a.*", "q8.kv_a.*" (MHA),
+//   "q", "kv_b", "att_out" (MHA), "q_rope", "q_c", "latent_out", "q8.latent.*", "vb_out" (MLA), "q8.att.*", "x_mid",
+//   "q8.x_ffn.*", "hb", "q8.hb.*", and for MoE blocks "router_logits", "route_e", "route_w", "eout", "hb_sh", "q8.hb_sh.*",
+//   "eout_sh".  A row is one token (for "hb" / "eout": the token's K slots).
+//   Without a tap: "x" (the residual stream after the last block) and "route_e" of the last MoE block.
+// `bytes` must be rows x the row size of that name.
+extern "C" int dsk_hydrate_get_buffer(dsk_model* m, const char* name, int row0, int rows, void* out, size_t bytes) {
   if (!m || !m->hyd || !name || !out) DSK_FAIL(DSK_ERR_STATE, "hydrate_get_buffer: no batched chunk has run");
-  const dsk_config& c = m->c;
   const HydState& h = *m->hyd;
-  const size_t P = h.cap, K = std::max(1, c.n_active_routed), H = c.n_heads;
-  const std::string s(name);
   const void* src = nullptr;
-  size_t avail = 0;
-  auto f32 = [&](const float* p, size_t n) { src = p; avail = n * 4; };
-  if (s == "x") f32(h.X, P * c.dim);
-  else if (s == "q_a") f32(h.q_a, P * c.q_lora_rank);
-  else if (s == "kv_a") f32(h.kv_a, P * (c.kv_lora_rank + c.qk_rope_head_dim));
-  else if (s == "q") f32(h.q, P * H * m->head_dim);
-  else if (s == "kv_b") f32(h.kv_b, P * H * (c.qk_nope_head_dim + c.v_head_dim));
-  else if (s == "att") f32(h.att, P * H * c.v_head_dim);
-  else if (s == "hbd") f32(h.hbd, P * c.hidden_dim);
-  else if (s == "hb") f32(h.hb, P * K * std::max(256, c.moe_intermediate_size));
-  else if (s == "hb_sh") f32(h.hb_sh, P * std::max(256, c.n_shared_experts * c.moe_intermediate_size));
-  else if (s == "eout") f32(h.eout, P * K * c.dim);
-  else if (s == "eout_sh") f32(h.eout_sh, P * c.dim);
-  else if (s == "route_w") f32(h.route_w, P * K);
-  else if (s == "route_e") { src = h.route_e; avail = P * K * 4; }
-  else if (s == "q8.x.qs") { src = h.a_x.qs; avail = P * c.dim; }
-  else if (s == "q8.x.d") { src = h.a_x.d; avail = P * (c.dim / 256) * 4; }
-  else if (s == "q8.qa.qs") { src = h.a_qa.qs; avail = P * c.q_lora_rank; }
-  else if (s == "q8.kva.qs") { src = h.a_kva.qs; avail = P * c.kv_lora_rank; }
-  else if (s == "q8.att.qs") { src = h.a_att.qs; avail = P * H * c.v_head_dim; }
-  else DSK_FAIL(DSK_ERR_INVALID, "hydrate_get_buffer: unknown buffer '%s'", name);
-  if (bytes > avail) DSK_FAIL(DSK_ERR_INVALID, "hydrate_get_buffer: '%s' holds %zu bytes, %zu requested", name, avail, bytes);
+  size_t row_bytes = 0;
+  const auto it = h.taps.find(name);
+  if (it != h.taps.end()) { src = it->second.first; row_bytes = it->second.second; }
+  else if (!strcmp(name, "x")) { src = h.X; row_bytes = (size_t)m->c.dim * 4; }
+  else if (!strcmp(name, "route_e") && m->c.n_active_routed > 0) { src = h.route_e; row_bytes = (size_t)m->c.n_active_routed * 4; }
+  if (!src) DSK_FAIL(DSK_ERR_INVALID, "hydrate_get_buffer: no buffer '%s' (option hydrate_tap_layer = %d)", name, m->hydrate_tap_layer);
+  if (row0 < 0 || rows < 1 || row0 + rows > h.last_P)
+    DSK_FAIL(DSK_ERR_INVALID, "hydrate_get_buffer: rows [%d, %d) of '%s': the last batched chunk held %d tokens", row0, row0 + rows, name, h.last_P);
+  if (bytes != (size_t)rows * row_bytes) DSK_FAIL(DSK_ERR_INVALID, "hydrate_get_buffer: '%s' has %zu bytes per row, %zu bytes given for %d rows", name, row_bytes, bytes, rows);
   HIP_TRY(hipSetDevice(m->ctx->device));
   HIP_TRY(hipStreamSynchronize(m->ctx->stream));
-  HIP_TRY(hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out, static_cast<const uint8_t*>(src) + (size_t)row0 * row_bytes, bytes, hipMemcpyDeviceToHost));
   return DSK_OK;
 }

@@ -675,7 +675,9 @@ static void hyd_gemm_launch(hipStream_t st, const HydGemmArgs& A) {
     const int chunks = (A.m + 15) / 16;
     const int nb_ = A.n >> 8, ips_ = tile_ips(nb_);
     if (nb_ > 8 && ips_ <= 8 && units * chunks <= 768) {  // long rows, few strips: the items of a strip to the waves of a workgroup
-      hipLaunchKernelGGL((hyd_gemm16k_kernel<GLU>), dim3((unsigned)units, (unsigned)chunks), dim3(64 * ips_), (GLU ? 2 : 1) * ips_ * 16 * 64 * 4, st, A);
+      const int lds_k = (GLU ? 2 : 1) * ips_ * 16 * 64 * 4;  // (64 KB for a GLU pair of 8 items: above the default dynamic limit's comfort)
+      if (lds_k > 48 * 1024) hipFuncSetAttribute((const void*)hyd_gemm16k_kernel<GLU>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_k);
+      hipLaunchKernelGGL((hyd_gemm16k_kernel<GLU>), dim3((unsigned)units, (unsigned)chunks), dim3(64 * ips_), lds_k, st, A);
       return;
     }
     // strips per workgroup: as many as still give most CUs a workgroup (the staging is paid once per workgroup, and every choice
@@ -1177,7 +1179,8 @@ int launch_hyd_router(hipStream_t st, const RouterArgs& a, int P, float* Y) {
   return DSK_OK;
 }
 
-// MEASUREMENT ONLY (option "hydrate_route_seed"): replace the gate's choice by K distinct experts per token drawn uniformly by a
+#ifdef DSK_AB
+// MEASUREMENT ONLY, -DDSK_AB builds (tools/ab_build.sh, env DSK_HYD_ROUTE_SEED): replace the gate's choice by K distinct experts per token drawn uniformly by a
 // hash of (seed, layer, token, slot).  The synthetic benchmark model routes most tokens of a chunk to the same ~125 experts (its
 // random router sees strongly correlated inputs), which flatters a batched prompt: a trained model balances its experts, and the
 // bytes a chunk touches are what the prompt phase is made of.  Never used by the parity tests.
@@ -1201,6 +1204,7 @@ int launch_hyd_route_override(hipStream_t st, int* route_e, int P, int K, int E,
   hipLaunchKernelGGL(hyd_route_override_kernel, dim3((P + 63) / 64), dim3(64), 0, st, route_e, P, K, E, seed);
   return DSK_OK;
 }
+#endif
 
 // tokens grouped by expert: list[e] = the (token, slot) pairs p * K + k routed to expert e, in pair order; count[e].
 // One workgroup per expert scans the pairs 256 at a time (ballot + prefix counts: the order is the pair order, deterministic).

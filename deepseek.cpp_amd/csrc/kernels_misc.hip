@@ -599,11 +599,13 @@ DEV int q3k_scale_b(const uint8_t* S, int j) {  // src/quant.cpp:402-407
   return (low4 | (hi2 << 4)) - 32;
 }
 
+// blockIdx.y = the row of a batch (dsk_hydrate: the tokens of a chunk come from its step rows, x holds gridDim.y rows of dim floats)
 __global__ void embed_kernel(DTensor t, const StepParams* __restrict__ sp, int token_override, int b0, int b1, float* __restrict__ x) {
-  const int token = token_override >= 0 ? token_override : sp->token;
+  const int token = token_override >= 0 ? token_override : sp[blockIdx.y].token;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int dim = t.n;
   if (i >= dim) return;
+  x += (size_t)blockIdx.y * dim;
   const size_t nb = dim >> 8;
   float y;
   switch (t.quant) {
@@ -651,6 +653,10 @@ __global__ void embed_kernel(DTensor t, const StepParams* __restrict__ sp, int t
 }
 int launch_embed(hipStream_t st, const DTensor& t, const StepParams* sp, int token_override, int b0, int b1, float* x) {
   hipLaunchKernelGGL(embed_kernel, dim3((t.n + 255) / 256), dim3(256), 0, st, t, sp, token_override, b0, b1, x);
+  return DSK_OK;
+}
+int launch_embed_rows(hipStream_t st, const DTensor& t, const StepParams* sps, int P, int b0, int b1, float* x) {
+  hipLaunchKernelGGL(embed_kernel, dim3((t.n + 255) / 256, P), dim3(256), 0, st, t, sps, -1, b0, b1, x);
   return DSK_OK;
 }
 

@@ -439,11 +439,12 @@ class Model:
         f.restype = C.c_char_p
         return f(self.h).decode()
 
-    def hydrate_buffer(self, name: str, shape, dtype=np.float32):
-        out = np.zeros(shape, dtype)
+    def hydrate_buffer(self, name: str, row0: int, rows: int, width: int, dtype=np.float32):
+        """dsk_hydrate_get_buffer: (rows, width) of a named intermediate of the last batched chunk (one row per token)"""
+        out = np.zeros((rows, width), dtype)
         f = lib().dsk_hydrate_get_buffer
-        f.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
-        check(f(self.h, name.encode(), out.ctypes.data, out.nbytes))
+        f.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        check(f(self.h, name.encode(), row0, rows, out.ctypes.data, out.nbytes))
         return out
 
     def hydrate_trace_x(self, layer: int, index: int):

@@ -263,10 +263,13 @@ const char* dsk_hydrate_why_not(dsk_model* m);
 /* Parity harness: residual stream of token `index` of the last batched chunk after block `layer`
  * (dsk_model_set_trace(m, 1) before the first dsk_hydrate call); the per-token counterpart is dsk_model_get_trace_x. */
 int dsk_hydrate_get_trace_x(dsk_model* m, int layer, int index, float* x_out);
-/* Debugging: an intermediate buffer of the batched path as the last chunk left it ("x", "q_a", "kv_a", "q", "kv_b", "att",
- * "hbd", "hb", "hb_sh", "eout", "eout_sh", "route_e", "route_w", "q8.x.qs", ...; rows of hydrate_chunk tokens).  With option
- * "hydrate_stop_layer" = l + 1 a chunk stops after block l and the buffers hold that block's intermediates. */
-int dsk_hydrate_get_buffer(dsk_model* m, const char* name, void* out, size_t bytes);
+/* Parity harness: rows [row0, row0 + rows) - one row per token - of a named intermediate of the LAST batched chunk.  With option
+ * "hydrate_tap_layer" = l, block l's stages are copied aside while a chunk runs (the chunk itself is unchanged) under the names
+ * dsk_model_get_stage uses for the per-token block ("q8.x_attn.qs" / ".d", "q_a", "kv_a", "att_out", "x_mid", "router_logits",
+ * "route_e", "route_w", "hb", "eout", ...: hydrate.cpp lists them); tests/test_hydrate_gpu.py hands them to the oracle-side block
+ * audit.  Without a tap: "x" (the residual stream after the last block), "route_e" (the last MoE block's).  `bytes` must be
+ * rows x the row size of that name. */
+int dsk_hydrate_get_buffer(dsk_model* m, const char* name, int row0, int rows, void* out, size_t bytes);
 /* Enable/disable replaying the token step from a captured hipGraph (default on). */
 /* The engine's own pinned host buffer of vocab_size floats (the D2H target of every OUTPUT_LOGITS step).  Passing it
    as `host_logits` to dsk_forward skips the extra host copy: a host application can make InferenceState::logits()

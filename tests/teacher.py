@@ -339,3 +339,72 @@ def audit_head(orc, c, T, dev, x_in, rows=None):
     ref = orc.gemv_q8(Q, np.ascontiguousarray(cls[rows]), len(rows), c.dim, q, d)
     A.chk("logits", logits[rows], ref, GEMV_TOL)
     return A, logits
+
+
+class HydrateDevice:
+    """Token `index` of the LAST batched chunk of dsk_hydrate as a `Device` of the audit above (include/dsk.h
+    dsk_hydrate_get_buffer with option "hydrate_tap_layer" = layer, dsk_hydrate_get_trace_x, dsk_model_get_cache_rows).
+
+    The batched prompt path (src/main.cpp:312-319 run as GEMMs) has no per-block entry point: the chunk runs every block on
+    its own residual stream.  The audit needs nothing else - it proves each stage on the DEVICE'S OWN inputs - so run_block
+    here only hands back what the chunk computed: x_in must be the chunk's stream in front of the block (the caller takes
+    it from the trace, or the embedding row for block 0) and the return value is the stream after it."""
+
+    def __init__(self, M, c, layer, index):
+        self.M, self.c, self.layer, self.i = M, c, layer, index
+        self.moe = c.n_routed_experts > 0 and layer >= c.first_k_dense_replace
+
+    def _buf(self, name, width, dtype=np.float32):
+        return self.M.hydrate_buffer(name, self.i, 1, width, dtype)[0]
+
+    def run_block(self, l, x_in, pos):
+        assert l == self.layer
+        return self.M.hydrate_trace_x(l, self.i)
+
+    def stage(self, name, n, dtype=np.float32):
+        c, M, l = self.c, self.M, self.layer
+        H = c.n_heads
+        widths = {"k_cache": H * c.head_dim, "v_cache": H * c.v_head_dim, "nope_cache": c.kv_lora_rank, "rope_cache": c.qk_rope_head_dim}
+        if name in widths:
+            w = widths[name]
+            assert n % w == 0
+            return M.get_cache_rows(l, name, 0, n // w, w).reshape(-1)
+        if self.moe and name in ("hb", "eout"):
+            K, mi = c.n_active_routed, c.moe_intermediate_size
+            shn = c.n_shared_experts * mi
+            slots = K + (1 if shn > 0 else 0)
+            if name == "eout":
+                out = np.zeros((slots, c.dim), np.float32)
+                out[:K] = self._buf("eout", K * c.dim).reshape(K, c.dim)
+                if shn > 0:
+                    out[K] = self._buf("eout_sh", c.dim)
+            else:
+                stride = max(mi, shn, 1)
+                out = np.zeros((slots, stride), np.float32)
+                out[:K, :mi] = self._buf("hb", K * mi).reshape(K, mi)
+                if shn > 0:
+                    out[K, :shn] = self._buf("hb_sh", shn)
+            assert out.size == n, (name, out.size, n)
+            return out.reshape(-1)
+        return self._buf(name, n, dtype)
+
+    def stage_q8(self, point, n):
+        c = self.c
+        if point == "x_ffn_shared":
+            raise KeyError(point)  # (the chunk quantises the normed x once: there is no second copy to compare)
+        if point == "x_ffn_tap":
+            point = "x_ffn"
+        if self.moe and point == "hb":
+            K, mi = c.n_active_routed, c.moe_intermediate_size
+            shn = c.n_shared_experts * mi
+            slots, stride = K + (1 if shn > 0 else 0), max(mi, shn, 1)
+            q = np.zeros((slots, stride), np.int8)
+            d = np.zeros((slots, stride // 256), np.float32)
+            q[:K, :mi] = self._buf("q8.hb.qs", K * mi, np.int8).reshape(K, mi)
+            d[:K, :mi // 256] = self._buf("q8.hb.d", K * mi // 256).reshape(K, mi // 256)
+            if shn > 0:
+                q[K, :shn] = self._buf("q8.hb_sh.qs", shn, np.int8)
+                d[K, :shn // 256] = self._buf("q8.hb_sh.d", shn // 256)
+            assert q.size == n
+            return q.reshape(-1), d.reshape(-1)
+        return self._buf(f"q8.{point}.qs", n, np.int8), self._buf(f"q8.{point}.d", n // 256)

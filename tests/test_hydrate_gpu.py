@@ -121,6 +121,79 @@ def test_hydrate_equals_the_loop_v3_width(ctx, P, pos0, mla):
     _assert_identical(compare_hydrate(ctx, c, None, seed=11, tokens=tokens, pos0=pos0), P, pos0)
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("P", [256, 512])
+def test_hydrate_equals_the_loop_v3_width_one_bench_sized_chunk(ctx, P):
+    """the configuration bench.py times: ONE chunk of 256 / 512 tokens at DeepSeek-V3 width (the engine's default chunk is 512; the
+    hottest expert of such a chunk carries hundreds of rows: many 16-row passes per task, every plain matrix at 16 / 32 token chunks)"""
+    c = synth.preset("v3", "q2_k", False, n_layers=2, first_k_dense_replace=1, max_seq_len=P + 8)
+    tokens = np.random.default_rng(P).integers(0, c.vocab_size, P)
+    _assert_identical(compare_hydrate(ctx, c, None, seed=17, tokens=tokens, pos0=0), P, 0)
+
+
+@pytest.mark.timeout(900)
+def test_mha_batches_up_to_the_split_context_regime(ctx):
+    """MHA at DeepSeek-V3 width: from mha_split_min (1024) cached positions on decode runs two workgroups per head over halves of the
+    context and merges un-normalised partials (head_attn_kernel) - another float association than a whole-context softmax - so
+    dsk_hydrate batches positions below it and loops from there: KV rows and logits are the loop's across position 1023"""
+    import dsk
+    c = synth.preset("v3", "q2_k", False, n_layers=2, first_k_dense_replace=1, max_seq_len=1056)
+    pre = [(5 * i + 1) % c.vocab_size for i in range(1000)]
+    tokens = [(17 * i + 3) % c.vocab_size for i in range(40)]
+    A = dsk.Model(ctx, c, None, synth_seed=19, options={"q2k_tiles": 2})
+    B = dsk.Model(ctx, c, None, synth_seed=19, options={"q2k_tiles": 2})
+    assert B.hydrate_why_not() == ""
+    _loop(A, pre, 0)
+    B.hydrate(pre, 0, dsk.MODE_HYDRATE_KV_CACHE)
+    assert B.info("hydrate_batched_tokens") == 1000
+    la, _ = _loop(A, tokens, 1000)
+    lb = B.hydrate(tokens, 1000, dsk.MODE_OUTPUT_LOGITS)
+    assert B.info("hydrate_batched_tokens") == 1023 and B.info("hydrate_looped_tokens") == 17
+    assert np.array_equal(la, lb)
+    for (ka, va), (kb, vb) in zip(_caches(A, c, 1040), _caches(B, c, 1040)):
+        assert np.array_equal(ka, kb) and np.array_equal(va, vb)
+    A.close()
+    B.close()
+
+
+@pytest.mark.parametrize("mla", [False, True], ids=["mha", "mla"])
+def test_hydrate_blocks_audited_on_the_oracle(ctx, oracle, mla):
+    """Not 'batched == own loop' but 'batched == the reference': the golden tiny DeepSeek-V3 Q2_K models (tests/golden, seed 7), a
+    37-token prompt through dsk_hydrate, and EVERY block audited on the oracle for ten of the tokens (tests/teacher.py
+    HydrateDevice + BlockAuditor: Q8_K codes equal to the oracle's except proven ties, every GEMV / float stage on the device's codes
+    within 2e-5 / 1e-4, this position's K / V (latent) cache row against the oracle's arithmetic to the last f16 place, attention over
+    the rows the same chunk wrote, route_e identical on the device's router logits).  The classifier row of the call (the last token's
+    logits) goes through the head audit's arithmetic as well."""
+    import dsk
+    from tests import teacher
+    c = synth.preset("tiny_v3", "q2_k", mla)
+    T = synth.synth_model(c, seed=7)
+    emb = T["model.embed.weight"]
+    tokens = [int(t) for t in np.random.default_rng(37).integers(0, c.vocab_size, 37)]
+    aud = teacher.BlockAuditor(oracle, c, T)
+    worst, flips, logits = 0.0, 0, None
+    for l in range(c.n_layers):
+        M = dsk.Model(ctx, c, T, options={"q2k_tiles": 2, "hydrate_tap_layer": l})
+        M.set_trace(True)
+        lg = M.hydrate(tokens, 0, dsk.MODE_OUTPUT_LOGITS)
+        assert M.info("hydrate_batched_tokens") == len(tokens) and M.info("hydrate_looped_tokens") == 0
+        assert logits is None or np.array_equal(lg, logits)  # a tap changes nothing
+        logits = lg
+        for i in list(range(0, 37, 4)) + [36]:
+            x_in = oracle.embed_row(emb.quant, emb.data, c.dim, tokens[i]) if l == 0 else M.hydrate_trace_x(l - 1, i)
+            A, x_out = aud.run(teacher.HydrateDevice(M, c, l, i), l, x_in, i)
+            flips += A.total_flips()
+            worst = max(worst, max(A.errs.values()))
+        if l == c.n_layers - 1:  # final norm + classifier of the last token on the chunk's own stream (src/infer.cpp:1292-1316)
+            Ah, lg_head = teacher.audit_head(oracle, c, T, M, M.hydrate_trace_x(l, 36))
+            assert np.array_equal(lg_head, lg)  # the call's logits ARE the audited head's on that stream
+            flips += Ah.total_flips()
+            worst = max(worst, max(Ah.errs.values()))
+        M.close()
+    print(f"\n[batched prompt, tiny_v3 q2_k {'mla' if mla else 'mha'}] {c.n_layers} blocks x 11 tokens: worst stage error {worst:.2e}, {flips} proven int8 ties")
+    assert worst < teacher.FLOAT_TOL
+
+
 def test_hydrate_across_the_ring_wrap_takes_the_loop_there(ctx):
     """positions at and past rs_original_max_position_embeddings rotate the sink keys in place, token by token
     (src/infer.cpp:1008-1020): dsk_hydrate batches up to the wrap and loops from there - still the same bits as the loop"""

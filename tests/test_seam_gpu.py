@@ -6,7 +6,11 @@ with deepseek.cpp_amd/libdsk_hip.so.  Tokenizer, sampler, codec, CLI and the per
 reference's in both binaries (src/main.cpp:277-431); only the forward pass changes device.
 
 Both run the same checkpoints: same token count, perplexity within 1e-3 relative (float weights; the W2A8 model within
-the int8 noise floor), identical greedy text.
+the int8 noise floor), identical greedy text for float weights.  For the W2A8 checkpoints - whose prompt goes through dsk_hydrate's
+batched path inside main_hip - the TEXT is tied to the oracle too: the prompt's token ids are read from the binaries' own output,
+the HIP binary's first generated piece must be the argmax of the engine's logits after dsk_hydrate of those ids, the reference
+binary's the argmax of the oracle's, and the two must be the same token whenever the teacher-forced audit of the prompt proves no
+int8 rounding tie (or the oracle's two best logits are a near-tie themselves).
 """
 import os
 import re
@@ -58,13 +62,59 @@ def _completion(out: bytes):
     return out[i:j].strip(b"\n"), int(m.group(1))
 
 
+def _prompt_ids(out: bytes):
+    # encode_prompt prints the encoding as [piece:id][piece:id]... in front of "Encoding stats" (src/main.cpp:257-275)
+    line = [ln for ln in out.split(b"\n") if ln.startswith(b"[<s>:")][-1]
+    return [int(x) for x in re.findall(rb":(\d+)\]", line)]
+
+
+def _kquant_text_against_the_oracle(ctx, oracle, c, T, out_cpu, out_hip, t_cpu, t_hip):
+    """see the module docstring: the first generated token of both binaries, tied to the oracle / the engine and to each other"""
+    import dsk
+    from tests import teacher
+    ids = _prompt_ids(out_cpu)
+    assert ids == _prompt_ids(out_hip) and ids[0] == 0 and len(ids) > 8
+    vocab = synth.synthetic_vocab(c.vocab_size)
+    M, O = dsk.Model(ctx, c, T, options={"q2k_tiles": 2}), oracle.model(c, T)  # (the options the patched main loads with)
+    lg_hip = M.hydrate(ids, 0, dsk.MODE_OUTPUT_LOGITS)
+    assert M.info("hydrate_batched_tokens") == len(ids)
+    lo = None
+    aud = teacher.BlockAuditor(oracle, c, T)
+    emb = T["model.embed.weight"]
+    flips = 0
+    M2 = dsk.Model(ctx, c, T, options={"q2k_tiles": 2})
+    for pos, tok in enumerate(ids):  # the oracle's stream, and the audit of every block of the prompt on it
+        lo = O.forward(tok, pos)
+        x = oracle.embed_row(emb.quant, emb.data, c.dim, tok)
+        for l in range(c.n_layers):
+            A, _ = aud.run(M2, l, x, pos)
+            flips += A.total_flips()
+            x = O.trace_x(l)
+    first_hip, first_cpu = int(np.argmax(lg_hip)), int(np.argmax(lo))
+
+    def piece(tok):  # decode_one (src/tokenizer.cpp:44-56): byte-fallback tokens print their byte, the others the piece as is
+        return bytes([tok - 2]) if 2 <= tok < 258 else vocab[tok].encode("latin-1")
+
+    for text, first in ((t_hip, first_hip), (t_cpu, first_cpu)):
+        if piece(first).strip(b"\n"):  # (_completion strips the newlines around the text)
+            assert text.startswith(piece(first)), (text[:8], first, piece(first))
+    top2 = np.sort(lo)[-2:]
+    near_tie = float(top2[1] - top2[0]) < 1e-3 * float(np.max(np.abs(lo)))
+    print(f"[seam, {c.quant}] prompt of {len(ids)} tokens: {flips} proven int8 ties in the audit; first generated token hip {first_hip} "
+          f"cpu {first_cpu}; logits rel_inf {teacher.rel_inf(lg_hip, lo):.2e}")
+    if flips == 0 and not near_tie:
+        assert first_hip == first_cpu
+    for m in (M, M2, O):
+        m.close()
+
+
 # (the Q2_K MHA case: the patched main loads with "q2k_tiles=2" and hands the whole prompt to dsk_hydrate - the batched path)
 CASES = [("tiny_v3", "fp16", False), ("tiny_v3", "f8e5m2", True), ("tiny_v2lite", "fp32", False), ("tiny_v3", "q2_k", True), ("tiny_v3", "q2_k", False)]
 
 
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("preset,quant,mla", CASES, ids=[f"{p}-{q}-{'mla' if m else 'mha'}" for p, q, m in CASES])
-def test_reference_main_with_device_hip_matches_reference_main(preset, quant, mla):
+def test_reference_main_with_device_hip_matches_reference_main(ctx, oracle, preset, quant, mla):
     _need_binaries()
     c = synth.preset(preset, quant, mla)
     T = synth.synth_model(c, seed=33)
@@ -75,9 +125,12 @@ def test_reference_main_with_device_hip_matches_reference_main(preset, quant, ml
         n_hip, ppl_hip = _perplexity(_run(MAIN_HIP, d, "-m", "perplexity", "-i", TEXT, "-d", "hip"))
         assert n_cpu == n_hip and n_cpu > 20
         rel = abs(ppl_hip - ppl_cpu) / ppl_cpu
-        t_cpu, k_cpu = _completion(_run(MAIN, d, "-m", "completion", "-t", "0", "-n", "32", "-i", TEXT[:40]))
-        t_hip, k_hip = _completion(_run(MAIN_HIP, d, "-m", "completion", "-t", "0", "-n", "32", "-i", TEXT[:40], "-d", "hip"))
+        out_cpu = _run(MAIN, d, "-m", "completion", "-t", "0", "-n", "32", "-i", TEXT[:40])
+        out_hip = _run(MAIN_HIP, d, "-m", "completion", "-t", "0", "-n", "32", "-i", TEXT[:40], "-d", "hip")
+        (t_cpu, k_cpu), (t_hip, k_hip) = _completion(out_cpu), _completion(out_hip)
         assert k_cpu == k_hip
+        if quant in ("q2_k", "q3_k"):
+            _kquant_text_against_the_oracle(ctx, oracle, c, T, out_cpu, out_hip, t_cpu, t_hip)
         print(f"\n[{preset} {quant} {'mla' if mla else 'mha'}] perplexity cpu {ppl_cpu:.6g} hip {ppl_hip:.6g} (rel {rel:.2e}); "
               f"greedy text equal: {t_cpu == t_hip}")
         if quant in ("q2_k", "q3_k"):

@@ -32,15 +32,21 @@ def _free_running_check(A, x_hip, x_orc, what, pos):
 
 
 KQ_CASES = [c for c in MODEL_CASES if is_kquant(c[1])]
+# (case, option q2k_tiles): every K-quant golden model at the default layout, and the Q2_K ones with EVERY converted role as tile
+# records (level 2: the tiled second stage of the MLA launch, wv_b on the matrix pipe inside mla_head_kernel, the tiled first
+# stage / per-head projections / wo / dense FFN / classifier) - the layout dsk_hydrate's batched path and the seam run on
+KQ_TILE_CASES = [(c, None) for c in KQ_CASES] + [(c, 2) for c in KQ_CASES if c[1] == "q2_k" and c[0] == "tiny_v3"]
 
 
-@pytest.mark.parametrize("case", KQ_CASES, ids=[case_id(c) for c in KQ_CASES])
-def test_every_block_teacher_forced_on_the_oracle_stream(ctx, oracle, case):
+@pytest.mark.parametrize("case,tiles", KQ_TILE_CASES, ids=[case_id(c) + ("" if t is None else f"-tiles{t}") for c, t in KQ_TILE_CASES])
+def test_every_block_teacher_forced_on_the_oracle_stream(ctx, oracle, case, tiles):
     import dsk
     preset, quant, mla, seed = case
     c = synth.preset(preset, quant, mla)
     T = synth.synth_model(c, seed=seed)
-    M, O = dsk.Model(ctx, c, T), oracle.model(c, T)
+    M, O = dsk.Model(ctx, c, T, options=None if tiles is None else {"q2k_tiles": tiles}), oracle.model(c, T)
+    if tiles:
+        assert M.info("tiled_tensors") > 0
     aud = teacher.BlockAuditor(oracle, c, T)
     emb = T["model.embed.weight"]
     flips, worst, free = 0, 0.0, []
@@ -79,8 +85,8 @@ def _v3_full_width(mla, seed, quant="q2_k"):
 
 
 @pytest.mark.timeout(1500)
-@pytest.mark.parametrize("mla,quant,tiles", [(False, "q2_k", None), (True, "q2_k", None), (False, "q3_k", None), (False, "q2_k", 2), (False, "q2_k", 0)],
-                         ids=["mha", "mla", "mha-q3_k", "mha-all-tiles", "mha-no-tiles"])
+@pytest.mark.parametrize("mla,quant,tiles", [(False, "q2_k", None), (True, "q2_k", None), (False, "q3_k", None), (False, "q2_k", 2), (False, "q2_k", 0), (True, "q2_k", 2)],
+                         ids=["mha", "mla", "mha-q3_k", "mha-all-tiles", "mha-no-tiles", "mla-all-tiles"])
 def test_v3_full_width_256_experts_teacher_forced(ctx, oracle, mla, quant, tiles):
     """BASELINE.json configs[3] at full width: 256 routed experts, 8 groups / 4 kept, top-8; 1 dense + 1 MoE block.  Q3_K at
     the same width runs the other instantiation of every K-quant kernel (moe_ffn_kernel<Q3_K, 2, 2>, the generic row loops).
@@ -121,6 +127,37 @@ def test_v3_full_width_256_experts_teacher_forced(ctx, oracle, mla, quant, tiles
     assert sum(routes) >= len(routes) - 1, routes
     M.close()
     O.close()
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("mla", [False, True], ids=["mha", "mla"])
+def test_v3_full_width_batched_prompt_audited_on_the_oracle(ctx, oracle, mla):
+    """The batched prompt path (dsk_hydrate, src/main.cpp:312-319 as GEMMs) against the ORACLE at full DeepSeek-V3 width
+    (256 experts, 128 heads, 1 dense + 1 MoE block), not against the engine's own loop: a 37-token prompt in one chunk, then for
+    the first, a middle and the last token every stage of every block goes through the same audit as the per-token block
+    (teacher.HydrateDevice: codes = the oracle's except proven ties, integer GEMVs and float stages on the device's codes within
+    2e-5 / 1e-4, the position's K/V (latent) cache row to the last f16 place, attention over the rows the SAME chunk wrote,
+    expert indices identical on the device's router logits, the k-ordered combine within 2e-6)."""
+    import dsk
+    c, T = _v3_full_width(mla, seed=33)
+    emb = T["model.embed.weight"]
+    tokens = [int(t) for t in np.random.default_rng(3).integers(0, c.vocab_size, 37)]
+    aud = teacher.BlockAuditor(oracle, c, T)
+    worst, flips = 0.0, 0
+    for l in range(c.n_layers):
+        M = dsk.Model(ctx, c, T, options={"q2k_tiles": 2, "hydrate_tap_layer": l})
+        assert M.hydrate_why_not() == ""
+        M.set_trace(True)
+        M.hydrate(tokens, 0, dsk.MODE_HYDRATE_KV_CACHE)
+        assert M.info("hydrate_batched_tokens") == len(tokens) and M.info("hydrate_looped_tokens") == 0
+        for i in (0, 18, 36):
+            x_in = oracle.embed_row(emb.quant, emb.data, c.dim, tokens[i]) if l == 0 else M.hydrate_trace_x(l - 1, i)
+            A, _ = aud.run(teacher.HydrateDevice(M, c, l, i), l, x_in, i)
+            flips += A.total_flips()
+            worst = max(worst, max(A.errs.values()))
+            print(f"\n[v3 {'mla' if mla else 'mha'} batched prompt, block {l}, token {i}] {A.summary()}")
+        M.close()
+    assert worst < teacher.FLOAT_TOL
 
 
 def _f16_bits(a):

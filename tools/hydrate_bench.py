@@ -53,7 +53,8 @@ def measure(ctx, c, Ps, reps=2, seed=0, chunk=0, opts=None, loop=True):
     # distinct experts the LAST chunk's last MoE block touched (the bytes a chunk streams are proportional to it)
     try:
         cap = chunk or 512
-        re = M.hydrate_buffer("route_e", (cap, max(1, c.n_active_routed)), np.int32)[:min(Ps[-1], cap)]
+        last = (Ps[-1] - 1) % cap + 1  # tokens of the last chunk
+        re = M.hydrate_buffer("route_e", 0, last, max(1, c.n_active_routed), np.int32)
         cnt = np.bincount(re.reshape(-1), minlength=c.n_routed_experts)
         out["last_chunk_experts"] = {"distinct": int((cnt > 0).sum()), "max_tokens": int(cnt.max())}
     except Exception as e:  # noqa: BLE001

@@ -2,7 +2,7 @@
 
   python tools/hydrate_debug.py [--preset tiny_v3|v3] [--P 5] [--pos0 0]
 
-For every block l: the batched chunk is re-run with option hydrate_stop_layer = l + 1 and its intermediate buffers are
+For every block l: the batched chunk is re-run with option hydrate_tap_layer = l and the block's tapped intermediates are
 compared with the stages dsk_model_run_block leaves when the SAME block runs on the loop's own residual stream (x of the
 previous block, per token).  Prints the first stage that differs per (block, token) and how far off it is.
 """
@@ -50,27 +50,26 @@ def main():
         xs.append(np.stack([A.trace_x(l) for l in range(c.n_layers)]))
     nbad = 0
     for l in range(c.n_layers):
-        B = dsk.Model(ctx, c, T, synth_seed=seed, options={"q2k_tiles": 2, "hydrate_stop_layer": l + 1, "hydrate_chunk": max(P, 4)})
+        B = dsk.Model(ctx, c, T, synth_seed=seed, options={"q2k_tiles": 2, "hydrate_tap_layer": l, "hydrate_chunk": max(P, 4)})
         B.set_trace(True)
         for i, t in enumerate(pre):  # the context comes from the loop on B itself (the same decode path as A)
             B.forward(t, i, dsk.MODE_HYDRATE_KV_CACHE)
         B.hydrate(tokens, a.pos0, dsk.MODE_HYDRATE_KV_CACHE)
-        cap = max(P, 4)
         moe = l >= c.first_k_dense_replace
-        bufs = {"q_a": (cap, c.q_lora_rank), "kv_a": (cap, c.kv_lora_rank + c.qk_rope_head_dim), "att": (cap, H * vd), "x": (cap, c.dim)}
+        bufs = {"q_a": c.q_lora_rank, "kv_a": c.kv_lora_rank + c.qk_rope_head_dim, "att_out": H * vd}
         if moe:
-            bufs.update({"route_e": (cap, K), "route_w": (cap, K), "hb": (cap * K, max(256, c.moe_intermediate_size)), "eout": (cap * K, c.dim),
-                         "hb_sh": (cap, max(256, c.n_shared_experts * c.moe_intermediate_size)), "eout_sh": (cap, c.dim)})
-        else:
-            bufs.update({"hbd": (cap, c.hidden_dim)})
-        got = {k: B.hydrate_buffer(k, s, np.int32 if k == "route_e" else np.float32) for k, s in bufs.items()}
+            bufs.update({"route_e": K, "route_w": K, "eout": K * c.dim})
+            if c.n_shared_experts:
+                bufs["eout_sh"] = c.dim
+        got = {k: B.hydrate_buffer(k, 0, P, w, np.int32 if k == "route_e" else np.float32) for k, w in bufs.items()}
+        got["x"] = np.stack([B.hydrate_trace_x(l, i) for i in range(P)])
         for i in range(P):
             if l > 0:  # (block 0's input is the embedding row, which has no accessor: only its output is compared)
                 # the loop's own stages: block l on the loop's residual stream at this position (the cache rows of earlier positions
                 # are already there: A decoded the whole prompt; the row of this position is rewritten with the same values)
                 A.run_block(l, xs[i][l - 1], a.pos0 + i)
                 want = {"q_a": A.stage("q_a", c.q_lora_rank), "kv_a": A.stage("kv_a", c.kv_lora_rank + c.qk_rope_head_dim),
-                        "att": A.stage("att_out", H * vd)}
+                        "att_out": A.stage("att_out", H * vd)}
                 if moe:
                     want["route_e"] = A.stage("route_e", K, np.int32)
                     want["route_w"] = A.stage("route_w", K)
@@ -78,10 +77,10 @@ def main():
                     want["eout"] = eo[:K]
                     if c.n_shared_experts:
                         want["eout_sh"] = eo[K]
-                for k in ("q_a", "kv_a", "att", "route_e", "route_w", "eout", "eout_sh"):
+                for k in ("q_a", "kv_a", "att_out", "route_e", "route_w", "eout", "eout_sh"):
                     if k not in want:
                         continue
-                    g = got[k][i * K:(i + 1) * K] if k == "eout" else got[k][i]
+                    g = got[k][i]
                     w = want[k]
                     if not np.array_equal(np.asarray(g).reshape(-1), np.asarray(w).reshape(-1)):
                         gd, wd = np.asarray(g, np.float64).reshape(-1), np.asarray(w, np.float64).reshape(-1)
