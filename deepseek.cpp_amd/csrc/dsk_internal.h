@@ -192,6 +192,7 @@ size_t tile_mat_bytes(size_t rows, size_t n);  // bytes of one (rows, n) Q2_K ma
 #endif
 #define MOE_CTR_WORDS (16 * MOE_CTR_STRIDE + 16)
 #define MOE_GAVE_UP_WORD (16 * MOE_CTR_STRIDE + 8)  // device-side copy of "a hand-off gave up during this token" (cleared with the counters)
+#define MOE_CAND_BYTES 65536  // the pipelined launch's candidate records: 16 strips x (|max|, max) per 256-block of a hidden vector
 #define MOE_BLK_CTRS 1024  // per-block arrival counters of the fused expert launch (K x mi / 256 <= 1024)
 struct MoeFfnArgs {
   int quant;
@@ -233,6 +234,8 @@ struct MoeFfnArgs {
   int UA, rows_wg, lds_a, lds_b, lds_o, grid;  // filled by moe_ffn_plan
   int tiled, lds_red;    // Q2_K weights in the tiled layout (kernels_moe_tile.hip: w*_qs = tile records, e13_qs / e2_qs = bytes of one
                          // padded expert matrix); lds_red = bytes of the partials region
+  float* cand;           // the pipelined form's candidate records (MOE_CAND_BYTES)
+  int pipe;              // option "moe_pipe": the launch pipelined by slot halves where its deals exist (kernels_moe_pipe.hip)
   int spin_limit;        // polls before the hand-off wait gives up (0: 2^20); < 0: fault injection (workgroup 0 reports a give-up)
   // float-weight models (F8E5M2 / F16 / F32; moe_ffn_f_kernel): block scales (F8 only, per-expert strides in floats), the
   // shared expert's w1 / w3 (computed in phase A too: these models have no rider in the router launch), the FFN norm (x is
@@ -253,6 +256,8 @@ struct MoeFfnArgs {
 int moe_ffn_plan(MoeFfnArgs& a, int n_cus);
 int launch_moe_ffn(hipStream_t st, const MoeFfnArgs& a, hipEvent_t ev_start, hipEvent_t ev_stop);
 int moe_ffn_plan_tile(MoeFfnArgs& a, int n_cus);
+bool moe_pipe_applies(const MoeFfnArgs& a);  // kernels_moe_pipe.hip: the same launch pipelined by slot halves (option "moe_pipe")
+int launch_moe_ffn_pipe(hipStream_t st, const MoeFfnArgs& a, hipEvent_t ev_start, hipEvent_t ev_stop);
 int launch_moe_ffn_tile(hipStream_t st, const MoeFfnArgs& a, hipEvent_t ev_start, hipEvent_t ev_stop);
 
 // per-token parameters living in device memory so that a captured graph can be replayed

@@ -262,6 +262,7 @@ extern "C" int dsk_model_set_option(dsk_model* m, const char* key, int value) {
   else if (k == "timeline") m->want_timeline = value != 0;
   else if (k == "moe_spin_limit") m->moe_spin_limit = value;
   else if (k == "moe_q8_handoff") m->moe_q8_handoff = value != 0;
+  else if (k == "moe_pipe") m->moe_pipe = value;
   else if (k == "tail_prefetch") m->tail_prefetch = value;
   else if (k == "fuse_moe_float") m->fuse_moe_float = value != 0;
   else if (k == "force_exchange") m->force_exchange = value != 0;
@@ -864,6 +865,8 @@ extern "C" int dsk_model_finalize(dsk_model* m) {
   HIP_TRY(hipMemset(m->moe_ctr, 0, MOE_CTR_WORDS * 4));
   HIP_TRY(hipMalloc((void**)&m->moe_blk_ctr, MOE_BLK_CTRS * 4));
   HIP_TRY(hipMemset(m->moe_blk_ctr, 0, MOE_BLK_CTRS * 4));
+  HIP_TRY(hipMalloc((void**)&m->moe_cand, MOE_CAND_BYTES));
+  HIP_TRY(hipMemset(m->moe_cand, 0, MOE_CAND_BYTES));
   HIP_TRY(hipHostMalloc((void**)&m->err_host, 64, hipHostMallocDefault));
   memset(m->err_host, 0, 64);
   if (m->want_timeline) {
@@ -915,6 +918,7 @@ extern "C" int dsk_model_destroy(dsk_model* m) {
   if (m->egather) hipFree(m->egather);
   if (m->moe_ctr) hipFree(m->moe_ctr);
   if (m->moe_blk_ctr) hipFree(m->moe_blk_ctr);
+  if (m->moe_cand) hipFree(m->moe_cand);
   if (m->moe_timeline) hipFree(m->moe_timeline);
   if (m->err_host) hipHostFree(m->err_host);
   if (m->router_counter) hipFree(m->router_counter);

@@ -130,9 +130,11 @@ struct dsk_model {
   bool att_q8_in_wo = false;       // DSK_ATT_Q8_IN_WO=1: wo quantises the attention output in its own prologue (no finisher hand-off in the attention launch)
   bool fuse_moe = true;            // DSK_NO_FUSE_MOE at model creation switches it off (A/B, bit-identity tests)
   unsigned* moe_ctr = nullptr;     // slot_ctr[16] | slot_pass[16]
+  float* moe_cand = nullptr;       // candidate records of the pipelined fused expert launch (kernels_moe_pipe.hip)
   unsigned* moe_blk_ctr = nullptr; // per-block arrivals of the fused expert launch (hidden vectors quantised by their producers)
   bool fuse_moe_float = true;      // option "fuse_moe_float": the fused expert launch for F8E5M2 / F16 / F32 weights too
   bool moe_q8_handoff = true;      // option "moe_q8_handoff"
+  int moe_pipe = 0;                // option "moe_pipe": the fused expert launch pipelined by slot halves (kernels_moe_pipe.hip)
   int tail_prefetch = 8;           // option "tail_prefetch": cold-line prefetch workgroups per launch that has room for them (forward.cpp build_plans; 0: off)
   // DSK_TIMELINE=1 (debug): 8 wall-clock stamps per workgroup of the LAST launch of each kind in a token;
   // kind 0 first-stage projections, 1 per-head attention, 2 wo, 3 router + shared expert, 4 fused routed experts

@@ -418,6 +418,8 @@ int build_plans(dsk_model* m) {
       a.tiled = w1.tiled;
       a.err = m->err_host;
       a.spin_limit = m->moe_spin_limit;
+      a.pipe = m->moe_pipe;
+      a.cand = m->moe_cand;
       a.timeline = m->timeline_of(4);
       a.lprA_log2 = m->plans[m->lp_w13[l]].lpr_log2;
       a.lprB_log2 = m->plans[m->lp_w2[l]].lpr_log2;

@@ -47,7 +47,12 @@ __global__ __launch_bounds__(1024) void moe_ffn_tile_kernel(const MoeFfnArgs a) 
   const int K = a.K, slots = K + (a.shared_n > 0 ? 1 : 0);
   unsigned long long* tl = a.timeline && bid < DSK_TL_WGS ? a.timeline + (size_t)bid * 8 : nullptr;
   if (tl && tid == 0) tl[0] = wall_clock64();
+#ifdef TILE_DBG
+  TLane TL = tlane_init(lane);
+  if (tl && (wave == 2 || wave == 15)) { TL.dbg = tl + (wave == 2 ? 7 : 6); if (lane == 0) *TL.dbg = 0; }
+#else
   const TLane TL = tlane_init(lane);
+#endif
 
   // ---- prologue: the router left Q8_K(rmsnorm(x)) behind (previous launch): copy it into block records ----
   {
@@ -370,6 +375,7 @@ static bool moe_tile_lean(const MoeFfnArgs& a) {
   return (a.dim >> 8) > 8 && a.hq_qs != nullptr && a.tap_qs == nullptr && (J + 15) / 16 <= MOE_T_PRE + MOE_T_PARK;
 }
 int launch_moe_ffn_tile(hipStream_t st, const MoeFfnArgs& a, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  if (a.pipe && moe_pipe_applies(a)) return launch_moe_ffn_pipe(st, a, ev_start, ev_stop);
   const size_t lds = moe_tile_lds(a);
   auto k = moe_tile_lean(a) ? moe_ffn_tile_kernel<1> : moe_ffn_tile_kernel<0>;
   if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
