@@ -143,6 +143,270 @@ DEV void mp_wait_ge(unsigned* w, unsigned v) {
   while (mp_peek(w) < v) __builtin_amdgcn_s_sleep(MP_SLEEP);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// moe_ffn_stage_kernel (option "moe_pipe" = 2): the one-phase launch (moe_ffn_tile_kernel<1>: same phase A, same Q8_K hand-over chain,
+// same copies, same multiplies, same bits) with its SECOND HALF re-ordered around what the probes of this round say:
+//   * the hand-over chain runs FIRST, before anybody on this CU requests W2 (2.0 us instead of 5.1 behind the requests, EXPERIMENTS 4.4),
+//     while waves 0..7 quantise the shared expert's hidden vector;
+//   * the W2 steps are requested in TWO stages - (shared expert + slots [0, K/2)), then slots [K/2, K) - with the hand-off wait and the
+//     hidden vectors' copy requests BETWEEN them: the copies (16 KB) queue behind stage 1's tiles only, not behind all of W2;
+//   * the wait polls through the scalar path (s_load_dword glc: not in the CU's in-order queue);
+//   * stage 1 multiplies while stage 2's tiles stream.
+// One workgroup barrier sits between a wave's requests and its multiplies (where the copies meet), none behind stage 2.
+// ------------------------------------------------------------------------------------------------------------------------
+#define MS_NS1 5  // W2 steps of stage 1 / stage 2 a wave holds in registers (DeepSeek-V3: 80 / 16 and 64 / 16)
+#define MS_NS2 4
+#ifndef MS_POLL_NAP
+#define MS_POLL_NAP 12
+#endif
+__global__ __launch_bounds__(1024) void moe_ffn_stage_kernel(const MoeFfnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ float scratch[16];
+  constexpr int NW = 16;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int bid = blockIdx.x, G = a.grid;
+  if (bid >= G) {  // tail prefetch workgroups (MoeFfnArgs::pf_wgs)
+    tail_prefetch(a.pf_p, a.pf_n, tid, 1024);
+    return;
+  }
+  uint8_t* actA = smem;
+  uint8_t* actB = smem + a.lds_a;                                                        // slots x lds_b block records
+  float* o_s = reinterpret_cast<float*>(smem + a.lds_a + (size_t)a.lds_b * (a.K + 1));  // [slot][rows_wg] slot outputs
+  float* red = reinterpret_cast<float*>(smem + a.lds_a + (size_t)a.lds_b * (a.K + 1) + a.lds_o);  // partials [item][64]
+  const int K = a.K, KH = K >> 1, slots = K + (a.shared_n > 0 ? 1 : 0);
+  unsigned long long* tl = a.timeline && bid < DSK_TL_WGS ? a.timeline + (size_t)bid * 8 : nullptr;
+  if (tl && tid == 0) tl[0] = wall_clock64();
+  const TLane TL = tlane_init(lane);
+  {  // the router left Q8_K(rmsnorm(x)) behind (previous launch): copy it into block records
+    ActSrc S;
+    S.act_mode = ACT_Q8; S.n = a.dim; S.a_qs = a.a_qs; S.a_d = a.a_d; S.a_bsums = a.a_bsums;
+    S.a_f32 = nullptr; S.norm_w = nullptr; S.eps = 0.f; S.pre_scale = 0.f;
+    stage_q8<LAY_TILE, NW>(S, actA, tid, scratch);
+  }
+  // the routing into SGPRs once, through the scalar path (every a.route_e[k] below would be a vector load with a full wait behind
+  // whatever this CU has requested by then)
+  const u32x8_t RE = mp_sload8(a.route_e);
+  auto route_of = [&](int k) {
+    u32 r = RE[0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) r = k == j ? RE[j] : r;
+    return (int)r;
+  };
+  const int tiles_x = a.dim >> 4;
+  const int t_lo = (int)((long long)tiles_x * bid / G), t_hi = (int)((long long)tiles_x * (bid + 1) / G);
+  const int ntile = t_hi - t_lo, nrows = ntile * 16, r_lo = t_lo * 16;
+  const int nbR = a.mi >> 8, nbS = a.shared_n >> 8;
+  float xv = 0.f;
+  if (tid < nrows) xv = a.x[r_lo + tid];
+  __syncthreads();
+  if (tl && tid == 0) tl[1] = wall_clock64();
+
+  // ---- phase A: one w1/w3 GLU unit of 4 strips (64 rows), as in moe_ffn_tile_kernel ----
+  {
+    const int nb = a.dim >> 8, ips = tile_ips(nb);
+    const int s = bid / a.UA, u = bid - s * a.UA;
+    const int e = route_of(s);
+    const uint8_t* const W1 = a.w1_qs + (size_t)e * a.e13_qs;
+    const uint8_t* const W3 = a.w3_qs + (size_t)e * a.e13_qs;
+    const int tb = u * 4, nt = 4;
+    const int I = 2 * nt * ips;
+    const int i0 = (int)((long long)I * wave / NW), i1 = (int)((long long)I * (wave + 1) / NW);
+    auto strip_of = [&](int sidx, rsrc_t& W, int& soff0, const uint8_t*& act) {
+      const bool m3 = sidx >= nt;
+      W = make_rsrc(m3 ? W3 : W1);
+      soff0 = (tb + (m3 ? sidx - nt : sidx)) * nb * TILE_B;
+      act = actA;
+    };
+    tile_items<4>(i0, i1, ips, nb, red, TL, lane, strip_of, [](int, int) {});
+    __syncthreads();
+    if (wave < nt) {  // src/infer.cpp:859-872; write-through: the consumers sit on other CUs
+      const float v1 = tile_strip_value(red + (size_t)wave * ips * 64, ips, lane);
+      const float v3 = tile_strip_value(red + (size_t)(nt + wave) * ips * 64, ips, lane);
+      const int rr = (tb + wave) * 16 + lane;
+      if (lane < 16) __hip_atomic_store(a.hb + (size_t)s * a.hb_stride + rr, act_fn(v1, a.act) * v3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the arrival
+    __syncthreads();
+    if (tl && tid == 0) tl[2] = wall_clock64();
+    if (wave == NW - 1) {
+      // Q8_K hand-over (kernels_moe.hip), FIRST: nothing of this CU is in the memory queue in front of its round trips
+      const int blk = (u * 64) >> 8;
+      unsigned old = 0;
+      if (lane == 0) old = __hip_atomic_fetch_add(a.blk_ctr + s * (a.mi >> 8) + blk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      old = __builtin_amdgcn_readfirstlane(old);
+      if (old == 3u) {
+        if (lane == 0) __hip_atomic_store(a.blk_ctr + s * (a.mi >> 8) + blk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+        const u32x4 hv = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(a.hb), (int)(((size_t)s * a.hb_stride + blk * 256 + lane * 4) * 4), 0, 16);
+        const u32 h0 = hv.x, h1 = hv.y, h2 = hv.z, h3 = hv.w;
+        const float v[4] = {u2f(h0), u2f(h1), u2f(h2), u2f(h3)};
+        const size_t e0 = (size_t)s * a.hb_stride + blk * 256;
+        ad::q8k_block_wt(v, lane, a.hq_qs + e0, a.hq_d + (e0 >> 8), a.hq_bsums + (e0 >> 4));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the slot's counter counts blocks; whoever completes a slot counts it on ONE further word (the line of "slot K", which the
+        // router launch re-arms with the others): 256 workgroups poll that word, not eight lines
+        unsigned os = 0;
+        if (lane == 0) os = __hip_atomic_fetch_add(a.slot_ctr + s * MOE_CTR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0 && os == (unsigned)(a.mi >> 8) - 1u) __hip_atomic_fetch_add(a.slot_ctr + K * MOE_CTR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else if (slots > K && wave < nbS) {
+      // meanwhile: the shared expert's f32 hidden vector (ready since the router launch) -> slot K's block records
+      const u32x4 hv = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(a.hb), (K * a.hb_stride + wave * 256 + lane * 4) * 4, 0, 16);
+      const u32 w0 = hv.x, w1 = hv.y, w2 = hv.z, w3 = hv.w;
+      const float v[4] = {u2f(w0), u2f(w1), u2f(w2), u2f(w3)};
+      q8k_block_lds<LAY_TILE>(v, lane, actB + (size_t)K * a.lds_b + (size_t)wave * TREC);
+    }
+    __syncthreads();  // the chain is through (this CU's part of it): now the stream
+  }
+  if (tl && tid == 0) tl[7] = wall_clock64();
+
+  // ---- phase B: this workgroup's tiles [t_lo, t_hi) of x, for all slots, in two stages ----
+  const int R = K * ntile * nbR;  // routed partials: (slot k, tile t, block b) at red[(k ntile + t) nbR + b]; the shared expert's behind them
+  const int nsh = slots > K ? ntile * nbS : 0;
+  const int J1 = nsh + KH * ntile * nbR, J2 = (K - KH) * ntile * nbR;
+  const int j0 = (int)((long long)J1 * wave / NW), j1 = (int)((long long)J1 * (wave + 1) / NW);
+  const int k0 = (int)((long long)J2 * wave / NW), k1 = (int)((long long)J2 * (wave + 1) / NW);
+  const rsrc_t WR = make_rsrc(a.w2_qs), WS = make_rsrc(slots > K ? a.sw2_qs : a.w2_qs);
+  struct Cur { int k, t, b; bool sh; int ebase; };
+  auto cur_routed = [&](int jj, int kbase) {
+    Cur c;
+    c.sh = false;
+    c.k = kbase + jj / (ntile * nbR);
+    const int rem = jj - (c.k - kbase) * ntile * nbR;
+    c.t = rem / nbR; c.b = rem - c.t * nbR;
+    c.ebase = (int)((size_t)route_of(c.k < K ? c.k : 0) * a.e2_qs);  // (the stack is < 2^31 bytes: moe_ffn_plan_tile)
+    return c;
+  };
+  auto cur_next = [&](Cur& c) {
+    ++c.b;
+    if (c.sh) {
+      if (c.b == nbS) {
+        c.b = 0;
+        if (++c.t == ntile) { c.sh = false; c.t = 0; c.k = 0; c.ebase = (int)((size_t)route_of(0) * a.e2_qs); }
+      }
+    } else if (c.b == nbR) {
+      c.b = 0;
+      if (++c.t == ntile) {
+        c.t = 0;
+        ++c.k;
+        c.ebase = (int)((size_t)route_of(c.k < K ? c.k : 0) * a.e2_qs);
+      }
+    }
+  };
+  auto cur_soff = [&](const Cur& c) { return c.ebase + ((t_lo + c.t) * (c.sh ? nbS : nbR) + c.b) * TILE_B; };
+  auto cur_rec = [&](const Cur& c) { return actB + (size_t)(c.sh ? K : c.k) * a.lds_b + (size_t)c.b * TREC; };
+  auto cur_rix = [&](const Cur& c) { return c.sh ? R + c.t * nbS + c.b : (c.k * ntile + c.t) * nbR + c.b; };
+  TStep S1[MS_NS1], S2[MS_NS2];
+  const uint8_t *rec1[MS_NS1], *rec2[MS_NS2];
+  int rix1[MS_NS1], rix2[MS_NS2];
+  {  // stage 1: the shared expert's steps, then slots [0, KH)
+    Cur c;
+    if (j0 < nsh) { c.sh = true; c.k = K; c.t = j0 / nbS; c.b = j0 - c.t * nbS; c.ebase = 0; }
+    else c = cur_routed(j0 < J1 ? j0 - nsh : 0, 0);
+#pragma unroll
+    for (int q = 0; q < MS_NS1; ++q)
+      if (j0 + q < j1) {
+        rec1[q] = cur_rec(c); rix1[q] = cur_rix(c);
+        tstep_load(S1[q], c.sh ? WS : WR, TL, cur_soff(c));
+        cur_next(c);
+      }
+  }
+  // wait until every phase-A unit of every slot has been handed over: wave 0 polls the slot counters through the scalar path
+  // (two batches of four loads), the others meet it at the barrier with their requests in flight
+#ifdef MS_TL2  // diagnostics: wave 0: stage 1 requested -> [2]; poll passed -> [7]
+  if (tl && tid == 0) tl[2] = wall_clock64();
+#endif
+  if (wave == 0) {
+    unsigned spins = 0;
+    if (mp_sload_glc(a.slot_ctr + MOE_GAVE_UP_WORD) != 0u) spins = (unsigned)a.spin_limit > 64u ? (unsigned)a.spin_limit - 64u : 0u;
+    for (;;) {
+      if (mp_sload_glc(a.slot_ctr + K * MOE_CTR_STRIDE) >= (unsigned)K) break;
+      __builtin_amdgcn_s_sleep(MS_POLL_NAP);  // (sparse polls: a tight loop of 256 pollers on one line delays the very atomics it waits for)
+      if (++spins > (unsigned)a.spin_limit) {
+        if (lane == 0) { *a.err = 1u; __hip_atomic_store(a.slot_ctr + MOE_GAVE_UP_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        break;
+      }
+    }
+    if (a.spin_limit < 0 && bid == 0 && lane == 0) *a.err = 1u;  // fault injection (option "moe_spin_limit" < 0)
+#ifdef MS_TL2
+    if (tl && lane == 0) tl[7] = wall_clock64();
+#endif
+  }
+  lds_barrier();
+  if (tl && tid == 0) tl[3] = wall_clock64();
+  {  // the routed slots' hidden vectors: copies of the Q8_K blocks their producers left (sc1 loads: written during THIS launch)
+    const rsrc_t qr = make_rsrc(a.hq_qs), br = make_rsrc(a.hq_bsums), dr = make_rsrc(a.hq_d);
+    const int runs_per_slot = a.mi >> 4, nruns = K * runs_per_slot;
+    for (int i = tid; i < nruns; i += NW * 64) {
+      const int s = i / runs_per_slot, r = i - s * runs_per_slot, b = r >> 4, j = r & 15;
+      const int e16 = s * (a.hb_stride >> 4) + r;
+      const u32x4 codes = __builtin_amdgcn_raw_buffer_load_b128(qr, e16 * 16, 0, 16);
+      const int bs = (int)(short)__builtin_amdgcn_raw_buffer_load_b16(br, e16 * 2, 0, 16);
+      uint8_t* rec = actB + (size_t)s * a.lds_b + (size_t)b * TREC;
+      *reinterpret_cast<u32x4*>(rec + j * 16) = codes;
+      rec[TREC_BS + 8 * (j >> 2) + (j & 3)] = (uint8_t)(bs >> 8);
+      rec[TREC_BS + 4 + 8 * (j >> 2) + (j & 3)] = (uint8_t)(bs & 0xff);
+    }
+    for (int i = tid; i < K * nbR; i += NW * 64) {
+      const int s = i / nbR, b = i - s * nbR;
+      uint8_t* rec = actB + (size_t)s * a.lds_b + (size_t)b * TREC;
+      *reinterpret_cast<u32x4*>(rec + TREC_ZERO) = u32x4{0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32*>(rec + TREC_D) = __builtin_amdgcn_raw_buffer_load_b32(dr, (s * (a.hb_stride >> 8) + b) * 4, 0, 16);
+    }
+  }
+  {  // stage 2: slots [KH, K) - requested behind the copies
+    Cur c = cur_routed(k0 < J2 ? k0 : 0, KH);
+#pragma unroll
+    for (int q = 0; q < MS_NS2; ++q)
+      if (k0 + q < k1) {
+        rec2[q] = cur_rec(c); rix2[q] = cur_rix(c);
+        tstep_load(S2[q], WR, TL, cur_soff(c));
+        cur_next(c);
+      }
+  }
+  lds_barrier();  // the copies are in LDS (every wave's share); stage 2's tiles stay in flight
+  if (tl && tid == 0) tl[4] = wall_clock64();
+#ifndef DSK_NO_TAPS
+  if (a.tap_qs && bid == 0)  // parity tap: what the slots staged
+    for (int s = 0; s < slots; ++s)
+      dump_staged_q8<LAY_TILE>(actB + (size_t)s * a.lds_b, s < K ? a.mi : a.shared_n, a.tap_qs + (size_t)s * a.tap_stride,
+                               a.tap_d + (size_t)s * (a.tap_stride >> 8), tid, 1024);
+#endif
+#pragma unroll
+  for (int q = 0; q < MS_NS1; ++q)
+    if (j0 + q < j1) {
+      float accd = 0.f, accm = 0.f;
+      tstep_mac(S1[q], rec1[q], TL, accd, accm);
+      red[(size_t)rix1[q] * 64 + lane] = titem_value(accd, accm, TL);
+    }
+#pragma unroll
+  for (int q = 0; q < MS_NS2; ++q)
+    if (k0 + q < k1) {
+      float accd = 0.f, accm = 0.f;
+      tstep_mac(S2[q], rec2[q], TL, accd, accm);
+      red[(size_t)rix2[q] * 64 + lane] = titem_value(accd, accm, TL);
+    }
+  __syncthreads();
+  // one wave per (slot, tile): the rows' values (association of tile_device.h: one item per block)
+  for (int q = wave; q < slots * ntile; q += NW) {
+    const int s = q / ntile, tl_ = q - s * ntile;
+    const int nbq = s < K ? nbR : nbS;
+    const float* rs = red + (size_t)(s < K ? (s * ntile + tl_) * nbR : R + tl_ * nbS) * 64;
+    const float v = tile_strip_value(rs, nbq, lane);
+    if (lane < 16) {
+      o_s[s * a.rows_wg + tl_ * 16 + lane] = v;
+      a.eout[(size_t)s * a.dim + r_lo + tl_ * 16 + lane] = v;
+    }
+  }
+  __syncthreads();
+  if (tl && tid == 0) tl[5] = wall_clock64();
+  if (tid < nrows) {  // x += w_k * o_k in k order (src/infer.cpp:874-877), then the shared expert (:900-903)
+    for (int k = 0; k < K; ++k) xv = fmaf(o_s[k * a.rows_wg + tid], a.route_w[k], xv);
+    if (slots > K) xv += o_s[K * a.rows_wg + tid];
+    a.x[r_lo + tid] = xv;
+  }
+  if (tl && tid == 0) tl[6] = wall_clock64();
+}
+
 __global__ __launch_bounds__(1024) void moe_ffn_pipe_kernel(const MoeFfnArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ float scratch[16];
@@ -536,7 +800,7 @@ static size_t moe_pipe_lds(const MoeFfnArgs& a) {
   return (size_t)a.lds_a + (size_t)a.lds_b * (a.K + 1) + a.lds_o + (size_t)(2 * I + J) * 256;
 }
 // the pipelined form applies to a plan of moe_ffn_plan_tile when its exact deals exist (DeepSeek-V3: 8 slots, 2048-wide experts, 7168-wide x)
-bool moe_pipe_applies(const MoeFfnArgs& a) {
+static bool moe_halves_applies(const MoeFfnArgs& a) {
   if (!a.tiled || a.quant != DSK_QUANT_Q2_K || a.hq_qs == nullptr) return false;
   if (a.K * 8 > a.grid || a.K * 8 * 16 > MOE_BLK_CTRS) return false;  // (8 block counters per slot, a 64-byte line each, re-armed by the first workgroups)
   const int nbA = a.dim >> 8, nbR = a.mi >> 8, nbS = a.shared_n >> 8, ips = tile_ips(nbA);
@@ -549,7 +813,27 @@ bool moe_pipe_applies(const MoeFfnArgs& a) {
   if (nbS + (a.K / 2) * nbR > MP_NP * MP_HB || (a.K / 2) * nbR > MP_NP * MP_HB) return false;  // hidden blocks per producer and stage
   return moe_pipe_lds(a) <= 150 * 1024;
 }
+// the staged form (option "moe_pipe" = 2) applies where the lean one-phase instantiation does and a wave's stage shares fit its registers
+static bool moe_stage_applies(const MoeFfnArgs& a) {
+  if (!a.tiled || a.quant != DSK_QUANT_Q2_K || a.hq_qs == nullptr) return false;
+  const int nbA = a.dim >> 8, nbR = a.mi >> 8, nbS = a.shared_n >> 8;
+  if (nbA <= 8 || a.K < 2 || a.K > 8 || nbR > 8 || nbS > 8 || nbS > 15 || a.mi % 64 || a.shared_n == 0) return false;  // (slot K's counter line is re-armed when there are K + 1 slots)
+  if (a.K * a.UA != a.grid || (a.mi + 15) / 16 != a.UA * 4) return false;  // one whole 64-row unit per workgroup
+  const int ntile_max = a.rows_wg / 16, KH = a.K / 2;
+  if (ntile_max * (nbS + KH * nbR) > 16 * MS_NS1 || ntile_max * (a.K - KH) * nbR > 16 * MS_NS2) return false;
+  const int itemsA = 8 * tile_ips(nbA), itemsB = ntile_max * (a.K * nbR + nbS);
+  return (itemsA > itemsB ? itemsA : itemsB) * 256 <= a.lds_red;
+}
+bool moe_pipe_applies(const MoeFfnArgs& a) { return a.pipe == 2 ? moe_stage_applies(a) : moe_halves_applies(a); }
 int launch_moe_ffn_pipe(hipStream_t st, const MoeFfnArgs& a, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  if (a.pipe == 2) {
+    const size_t lds = (size_t)a.lds_a + (size_t)a.lds_b * (a.K + 1) + a.lds_o + (size_t)a.lds_red;
+    auto k = moe_ffn_stage_kernel;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (ev_start && ev_stop) hipExtLaunchKernelGGL(k, dim3(a.grid + (a.pf_wgs > 0 ? a.pf_wgs : 0)), dim3(1024), (uint32_t)lds, st, ev_start, ev_stop, 0u, a);
+    else hipLaunchKernelGGL(k, dim3(a.grid + (a.pf_wgs > 0 ? a.pf_wgs : 0)), dim3(1024), lds, st, a);
+    return DSK_OK;
+  }
   const size_t lds = moe_pipe_lds(a);
   auto k = moe_ffn_pipe_kernel;
   if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -113,6 +113,28 @@ def test_full_width_block_tiled_fused_equals_two_launch(ctx, experts, mla):
         M.close()
 
 
+@pytest.mark.parametrize("pipe", [1, 2], ids=["slot-halves", "staged-second-half"])
+def test_experimental_schedules_of_the_fused_expert_launch_are_bit_identical(ctx, pipe):
+    """option "moe_pipe" (kernels_moe_pipe.hip; off by default: measured slower, EXPERIMENTS.md 6.1): the fused expert launch pipelined
+    by slot halves with service waves publishing through the scalar memory path (1), and the one-phase launch with its second half
+    staged around the hand-off (2).  Other schedules of the same arithmetic (src/infer.cpp:853-904): logits, slot outputs and routing
+    bit for bit, DeepSeek-V3 width with 256 experts, MHA and MLA"""
+    import dsk
+    for mla in (False, True):
+        c = synth.preset("v3", "q2_k", mla, n_layers=3, first_k_dense_replace=1, max_seq_len=64)
+        A = dsk.Model(ctx, c, None, synth_seed=5)
+        P = dsk.Model(ctx, c, None, synth_seed=5, options={"moe_pipe": pipe})
+        assert P.info("fused_moe_layers") == 2
+        for pos, t in enumerate([3, 77, 1500, 9, 100000]):
+            la, lp = A.forward(t, pos), P.forward(t, pos)
+            assert np.array_equal(la, lp), (mla, pos)
+            assert np.array_equal(A.slot_outputs(), P.slot_outputs()), (mla, pos)
+            assert np.array_equal(A.routing()[0], P.routing()[0]), (mla, pos)
+        assert P.info("handoff_fallbacks") == 0
+        A.close()
+        P.close()
+
+
 def test_synthesized_weights_do_not_depend_on_the_layout(ctx):
     """dsk_model_synthesize fills tile records THROUGH the plane layout: one seed = one logical model at every q2k_tiles
     level, so an A/B across levels compares layouts, not models - first-token logits agree to float precision, routing identical"""

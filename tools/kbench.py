@@ -28,6 +28,8 @@ V3 = [
     ("wq_a 1536x7168", 1536, 7168, 1, 0, 2),
     ("wkv_a 576x7168", 576, 7168, 1, 0, 2),
     ("shared_w13 (2048x7168)x2", 2048, 7168, 1, 1, 2),
+    ("mla wq_rope_b||wc 73728x1536", 73728, 1536, 1, 0, 2),
+    ("mla wv_b (block-diagonal stand-in) 16384x512", 16384, 512, 1, 0, 0),
 ]
 
 

@@ -9,10 +9,11 @@ from tools import synth
 
 ctx = dsk.Ctx(0)
 bad = 0
+PIPE = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 for mla in (False, True):
     c = synth.preset("v3", "q2_k", mla, n_layers=3, first_k_dense_replace=1, max_seq_len=64)
     A = dsk.Model(ctx, c, None, synth_seed=5)
-    P = dsk.Model(ctx, c, None, synth_seed=5, options={"moe_pipe": 1})
+    P = dsk.Model(ctx, c, None, synth_seed=5, options={"moe_pipe": PIPE})
     for pos, t in enumerate([3, 77, 1500, 9, 100000, 5]):
         la, lp = A.forward(t, pos), P.forward(t, pos)
         ok = np.array_equal(la, lp) and np.array_equal(A.slot_outputs(), P.slot_outputs()) and np.array_equal(A.routing()[0], P.routing()[0])
