@@ -505,7 +505,8 @@ struct HydLatentArgs {
 };
 int launch_hyd_latent_q8(hipStream_t st, const HydLatentArgs& A, int P);
 int launch_hyd_kv_write(hipStream_t st, const AttnMhaArgs& a, const StepParams* sps, int P, const float* kv_b, int kvb_stride, const float* kv_a, int kva_stride);
-int launch_hyd_attn(hipStream_t st, const AttnMhaArgs& a, const StepParams* sps, int P, int max_kv, const float* q, int q_stride, float* out, int out_stride);
+int launch_hyd_attn(hipStream_t st, const AttnMhaArgs& a, const StepParams* sps, int P, int max_kv, const float* q, int q_stride, float* out, int out_stride,
+                    int n_split, int split_min);
 int launch_hyd_mla_kv_write(hipStream_t st, const MlaKvArgs& kv, const StepParams* sps, int P, int kva_stride);
 int launch_hyd_mla_attn(hipStream_t st, const AttnMlaArgs& a, const StepParams* sps, int P, int max_kv, const float* q_c, int qc_stride, const float* q_rope,
                         int qr_stride, float* latent, int lat_stride);

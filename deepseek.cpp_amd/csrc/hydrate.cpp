@@ -273,7 +273,7 @@ static int hyd_layer(dsk_model* m, int l, int P, int max_kv) {
     DSK_TRY(hyd_gemm(m, L.t[DSK_ROLE_WKV_B], nullptr, h.a_kva, P, P, h.kv_b, H * nv, EPI_STORE));
     const AttnMhaArgs& a = m->head_attn[l].a;
     DSK_TRY(launch_hyd_kv_write(st, a, h.sp, P, h.kv_b, H * nv, h.kv_a, kvl + rope));
-    DSK_TRY(launch_hyd_attn(st, a, h.sp, P, max_kv, h.q, H * hd, h.att, H * vd));
+    DSK_TRY(launch_hyd_attn(st, a, h.sp, P, max_kv, h.q, H * hd, h.att, H * vd, m->mha_split_part && m->mha_split_counter ? m->mha_split : 1, m->mha_split_min));
     DSK_TRY(hyd_tap_q8(m, l, "q_a", h.a_qa, P, qlr));
     DSK_TRY(hyd_tap_q8(m, l, "kv_a", h.a_kva, P, kvl));
     DSK_TRY(hyd_tap(m, l, "q", h.q, P, (size_t)H * hd * 4));
@@ -397,9 +397,8 @@ static int hyd_position_limit(const dsk_model* m) {
   // MLA: from mla_flash_min_kv cached positions on the decode path scores on the matrix cores (mla_flash_kernel: its own
   // association); the batched path reproduces the short-context kernel only
   if (m->c.use_mla && m->fl_part_o) limit = std::min(limit, std::max(1, m->mla_flash_min_kv - 1));
-  // MHA: from mha_split_min cached positions on decode runs mha_split workgroups per head over pieces of the context and merges
-  // un-normalised partials (head_attn_kernel) - another association than the whole-context softmax hyd_attn_kernel reproduces
-  if (!m->c.use_mla && m->mha_split > 1) limit = std::min(limit, std::max(1, m->mha_split_min - 1));
+  // (MHA: from mha_split_min cached positions on decode runs mha_split workgroups per head over pieces of the context and merges
+  // un-normalised partials - hyd_attn_kernel walks the same pieces and merges them the same way: no limit from that regime)
   // the attention launches keep one float per cached position in LDS
   limit = std::min(limit, 24 * 1024);
   return limit;

@@ -833,8 +833,12 @@ __global__ __launch_bounds__(256) void hyd_kv_write_kernel(const AttnMhaArgs a, 
 // (same attn_mha_body<1024>: same score / softmax / value-mix trees)
 // (64 VGPRs - 12 dwords of scratch - so that TWO workgroups share a CU: the launch is a chain of dependent round trips per (head,
 // token), 8192 of them at P = 64: 115 -> 87 us per block.  The MLA kernel below measured slower with the same cap: 30 dwords spilled.)
+// From split_min cached positions on the decode step runs n_split workgroups per head over pieces of the context and merges their
+// un-normalised partials (head_attn_kernel, kernels_gemv.hip): another float association than one softmax over the whole context.
+// Here ONE workgroup walks the same pieces [kv_len s / S, kv_len (s + 1) / S) in turn, keeps the partials in LDS and merges them with
+// the decode launch's statements: the same bits.
 __global__ __launch_bounds__(1024, 8) void hyd_attn_kernel(const AttnMhaArgs a, const StepParams* __restrict__ sps, const float* __restrict__ q, int q_stride,
-                                                        float* __restrict__ out, int out_stride) {
+                                                        float* __restrict__ out, int out_stride, int n_split, int split_min) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ float scratch[16];
   __shared__ __attribute__((aligned(16))) float q_s[256];
@@ -862,20 +866,48 @@ __global__ __launch_bounds__(1024, 8) void hyd_attn_kernel(const AttnMhaArgs a, 
     }
   }
   __syncthreads();
-  const float o = ad::attn_mha_body<1024>(a, q_s, 0, sp->kv_len, h, tid, att, scratch, part);
+  const int kv_len = sp->kv_len;
+  if (n_split <= 1 || kv_len < split_min) {
+    const float o = ad::attn_mha_body<1024>(a, q_s, 0, kv_len, h, tid, att, scratch, part);
+    if (tid < vd) out[(size_t)p * out_stride + (size_t)h * vd + tid] = o;
+    return;
+  }
+  __shared__ float ml_s[2];
+  __shared__ float sp_s[MHA_SPLIT_MAX][260];  // a piece's un-normalised mix [v_dim] | its maximum | its sum
+  const int S = n_split;
+  for (int j = 0; j < S; ++j) {
+    const int t_lo = (int)((long long)kv_len * j / S), t_hi = (int)((long long)kv_len * (j + 1) / S);
+    const float oj = ad::attn_mha_body<1024>(a, q_s, t_lo, t_hi, h, tid, att, scratch, part, ml_s);
+    if (tid < vd) sp_s[j][tid] = oj;
+    __syncthreads();  // ml_s
+    if (tid < 2) sp_s[j][vd + tid] = ml_s[tid];
+    __syncthreads();
+  }
+  // O = sum_s O_s e^{m_s - M} / sum_s l_s e^{m_s - M}, pieces in order (head_attn_kernel's merge)
+  float M = -INFINITY;
+  for (int j = 0; j < S; ++j) M = fmaxf(M, sp_s[j][vd]);
+  float Lsum = 0.f, o = 0.f;
+  for (int j = 0; j < S; ++j) {
+    const float w = expf(sp_s[j][vd] - M);
+    Lsum = fmaf(sp_s[j][vd + 1], w, Lsum);
+    if (tid < vd) o = fmaf(sp_s[j][tid], w, o);
+  }
+  o /= Lsum;
   if (tid < vd) out[(size_t)p * out_stride + (size_t)h * vd + tid] = o;
 }
 int launch_hyd_kv_write(hipStream_t st, const AttnMhaArgs& a, const StepParams* sps, int P, const float* kv_b, int kvb_stride, const float* kv_a, int kva_stride) {
   hipLaunchKernelGGL(hyd_kv_write_kernel, dim3(a.n_heads, P), dim3(256), 0, st, a, sps, kv_b, kvb_stride, kv_a, kva_stride);
   return DSK_OK;
 }
-int launch_hyd_attn(hipStream_t st, const AttnMhaArgs& a, const StepParams* sps, int P, int max_kv, const float* q, int q_stride, float* out, int out_stride) {
+int launch_hyd_attn(hipStream_t st, const AttnMhaArgs& a, const StepParams* sps, int P, int max_kv, const float* q, int q_stride, float* out, int out_stride,
+                    int n_split, int split_min) {
   const size_t lds = (size_t)max_kv * 4;
   if (lds > 96 * 1024) DSK_FAIL(DSK_ERR_UNSUPPORTED, "hyd_attn: kv_len %d does not fit LDS", max_kv);
   if (a.head_dim > 256 || a.v_dim > 256) DSK_FAIL(DSK_ERR_UNSUPPORTED, "hyd_attn: head_dim %d / v_head_dim %d", a.head_dim, a.v_dim);
   auto k = hyd_attn_kernel;
   if (lds > 32 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k, dim3(a.n_heads, P), dim3(1024), lds, st, a, sps, q, q_stride, out, out_stride);
+  if (n_split > MHA_SPLIT_MAX) n_split = MHA_SPLIT_MAX;  // (launch_head_attn's clamp)
+  hipLaunchKernelGGL(k, dim3(a.n_heads, P), dim3(1024), lds, st, a, sps, q, q_stride, out, out_stride, n_split, split_min);
   return DSK_OK;
 }
 

@@ -122,11 +122,14 @@ def test_reference_main_with_device_hip_matches_reference_main(ctx, oracle, pres
     try:
         synth.write_dseek(d, c, T, shards=2, tokenizer=True)
         n_cpu, ppl_cpu = _perplexity(_run(MAIN, d, "-m", "perplexity", "-i", TEXT))
-        n_hip, ppl_hip = _perplexity(_run(MAIN_HIP, d, "-m", "perplexity", "-i", TEXT, "-d", "hip"))
+        n_hip, ppl_hip = _perplexity(_run(MAIN_HIP, d, "-m", "perplexity", "-i", TEXT, "-d", "hip", env_extra={"DSK_HIP_OPTS": "q2k_tiles=2"}))
         assert n_cpu == n_hip and n_cpu > 20
         rel = abs(ppl_hip - ppl_cpu) / ppl_cpu
         out_cpu = _run(MAIN, d, "-m", "completion", "-t", "0", "-n", "32", "-i", TEXT[:40])
-        out_hip = _run(MAIN_HIP, d, "-m", "completion", "-t", "0", "-n", "32", "-i", TEXT[:40], "-d", "hip")
+        # (DSK_HIP_OPTS: the host application's choice of engine options - Q2_K matrices as tile records, so that the prompt takes
+        # dsk_hydrate's batched path; without it the engine's defaults apply: the faster decode layout, prompts token by token)
+        tiles = {"DSK_HIP_OPTS": "q2k_tiles=2"}
+        out_hip = _run(MAIN_HIP, d, "-m", "completion", "-t", "0", "-n", "32", "-i", TEXT[:40], "-d", "hip", env_extra=tiles)
         (t_cpu, k_cpu), (t_hip, k_hip) = _completion(out_cpu), _completion(out_hip)
         assert k_cpu == k_hip
         if quant in ("q2_k", "q3_k"):
