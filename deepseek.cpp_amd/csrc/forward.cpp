@@ -191,6 +191,7 @@ int build_plans(dsk_model* m) {
         add(L.t[DSK_ROLE_WKV_B], m->kv_a, L.t[DSK_ROLE_KV_A_NORM], m->kv_b);
       }
       h.algo_bytes = bytes;
+      if (c.use_mla && m->ride_kvwrite) h.reserve_wgs = 1;  // the latent's cache write rides as one more workgroup of this launch
       DSK_TRY(add_plan(m, h, &m->lp_qkv_b[l]));
       if (!c.use_mla) {  // MHA: the same projections, consumed per head by the fused attention launch
         HeadAttnArgs A;

@@ -1296,7 +1296,7 @@ int gemv_plan(GemvLaunch& h, int target_wgs) {
   }
   // activation groups: consecutive tasks that read the same vector (the fused combine keeps one task per
   // group: its arrival counters are per task)
-  const int W = h.NW == 16 ? 256 : target_wgs;
+  const int W = h.NW == 16 ? 256 - (h.reserve_wgs > 0 && h.reserve_wgs < 128 ? h.reserve_wgs : 0) : target_wgs;
   int wg = 0;
   h.n_groups = 0;
   for (int i = 0; i < h.n_tasks;) {

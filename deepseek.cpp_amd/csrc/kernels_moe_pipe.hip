@@ -30,17 +30,10 @@
 #else
 #define MP_PST(w, i) do { } while (0)
 #endif
-#ifdef MP_TL_MAC
-#undef MP_PST
-#define MP_PST(w, i) do { if ((i) == 1 && tl && wave == (w) && lane == 0) tl[i] = wall_clock64(); } while (0)
-#endif
-#if defined(MP_TL_SVC) || defined(MP_TL_PROD) || defined(MP_TL_MAC)
+#if defined(MP_TL_SVC) || defined(MP_TL_PROD)
 #define MP_TLN(i) do { } while (0)
 #else
 #define MP_TLN(i) tl[i] = wall_clock64()
-#endif
-#ifndef MP_EXACT
-#define MP_EXACT 0  // 1: diagnostics - the unit deal is known to be exact (two whole 4-block items per producer): no guards
 #endif
 // the workgroup barrier as the meeting point of a unit: LDS traffic ordered, requests in flight left alone
 #define MP_UNIT_MEET() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -438,15 +431,9 @@ __global__ __launch_bounds__(1024) void moe_ffn_pipe_kernel(const MoeFfnArgs a) 
   // geometry of both phases
   const int nb = a.dim >> 8, ips = tile_ips(nb);  // rows of x: nb > 8, 4-block items (moe_pipe_applies)
   const int UH = a.mi / MP_ROWS;                  // phase-A units per slot
-#ifdef MP_DEAL8  // diagnostics (wrong results): both units from ALL K slots, like the one-phase launch's deal
-  const int sA = bid / (UH / 2), u0_ = bid - sA * (UH / 2);
-#define MP_SLOT(g) (sA)
-#define MP_UNIT(g) (u0_ + (g) * (UH / 2))
-#else
   const int sA = bid / UH, u0_ = bid - sA * UH;   // this workgroup's unit: rows [32 u, 32 u + 32) of slot sA, then of slot sA + KH
 #define MP_SLOT(g) (sA + (g) * KH)
 #define MP_UNIT(g) (u0_)
-#endif
   const int I = 4 * ips;                          // items of a unit: (w1 | w3) x 2 strips x ips
   const int tiles_x = a.dim >> 4;
   const int t_lo = (int)((long long)tiles_x * bid / G), t_hi = (int)((long long)tiles_x * (bid + 1) / G);
@@ -468,11 +455,7 @@ __global__ __launch_bounds__(1024) void moe_ffn_pipe_kernel(const MoeFfnArgs a) 
   __syncthreads();
   if (tl && tid == 0) MP_TLN(1);
 
-#ifdef MP_OLD_A16
-  if (true) {
-#else
   if (wave >= 2) {
-#endif
     // =========================== PRODUCERS ===========================
     const int p = wave - 2;
     {  // ---- phase A: two units, two 4-block items of each for this wave: a stream of four items, two of them requested at any time ----
@@ -499,36 +482,6 @@ __global__ __launch_bounds__(1024) void moe_ffn_pipe_kernel(const MoeFfnArgs a) 
         for (int q = 0; q < 4; ++q) tstep_mac(S[q], actA + (size_t)(4 * k + q) * TREC, TL, accd, accm);
         red[(size_t)rix * 64 + lane] = titem_value(accd, accm, TL);
       };
-#ifdef MP_OLD_A  // diagnostics (wrong results): the one-phase launch's phase A code over a 64-row unit, 14 waves
-      {
-        const int sO = bid / (UH / 2), uO = bid - sO * (UH / 2);
-        const int e = route_of(sO);
-        const uint8_t* const W1o = a.w1_qs + (size_t)e * a.e13_qs;
-        const uint8_t* const W3o = a.w3_qs + (size_t)e * a.e13_qs;
-        const int tb = uO * 4, nt = 4, Io = 2 * nt * ips;
-#ifdef MP_OLD_A16
-        const int i0 = (int)((long long)Io * wave / 16), i1 = (int)((long long)Io * (wave + 1) / 16);
-#else
-        const int i0 = (int)((long long)Io * p / NP), i1 = (int)((long long)Io * (p + 1) / NP);
-#endif
-        auto strip_of = [&](int sidx, rsrc_t& W, int& soff0, const uint8_t*& act) {
-          const bool m3 = sidx >= nt;
-          W = make_rsrc(m3 ? W3o : W1o);
-          soff0 = (tb + (m3 ? sidx - nt : sidx)) * nb * TILE_B;
-          act = actA;
-        };
-        MP_PST(2, 1);
-        tile_items<4>(i0, i1, ips, nb, red, TL, lane, strip_of, [](int, int) {});
-        MP_PST(2, 2);
-        MP_UNIT_MEET();
-        if (tl && tid == 0) tl[1] = wall_clock64();
-        MP_PST(2, 4);
-#ifndef MP_OLD_A16
-        MP_UNIT_MEET();
-#endif
-      }
-      if (false) {
-#endif
       rsrc_t W0, W1_, W2, W3_;
       int so0, so1, so2, so3, rx0, rx1, rx2, rx3, k0_, k1_, k2_, k3_;
       item_at(0, 0, W0, so0, rx0, k0_);
@@ -549,14 +502,8 @@ __global__ __launch_bounds__(1024) void moe_ffn_pipe_kernel(const MoeFfnArgs a) 
       item_mac(B, k3_, rx3);
       MP_PST(2, 4);
       MP_UNIT_MEET();  // the second unit's
-#ifdef MP_OLD_A
-      }
-#endif
     }
     if (tl && wave == 2 && lane == 0) MP_TLN(2);
-#if defined(MP_A_ONLY) || defined(MP_OLD_A16)
-    if (true) { } else
-#endif
     {
     // ---- phase B: this workgroup's tiles [t_lo, t_hi) of x for all slots, two stages ----
     // stage 1: the shared expert's steps (tile, block), then slots [0, KH) as (slot, tile, block); stage 2: slots [KH, K)
@@ -689,12 +636,6 @@ __global__ __launch_bounds__(1024) void moe_ffn_pipe_kernel(const MoeFfnArgs a) 
     unsigned spins = 0;
     bool gave_up = false;
     MP_PST(0, 7);
-#ifdef MP_SVC_NAP  // diagnostics: the service waves sleep through the first microseconds instead of watching the LDS counter
-    for (int i = 0; i < MP_SVC_NAP; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
-#ifdef MP_A_ONLY
-    if (true) { } else
-#endif
     {
     // (an earlier launch of this token already gave up - a DEVICE word next to the counters says so: do not spin the limit out again)
     if (mp_sload_glc(a.slot_ctr + MOE_GAVE_UP_WORD) != 0u) spins = (unsigned)a.spin_limit > 64u ? (unsigned)a.spin_limit - 64u : 0u;

@@ -47,12 +47,7 @@ __global__ __launch_bounds__(1024) void moe_ffn_tile_kernel(const MoeFfnArgs a) 
   const int K = a.K, slots = K + (a.shared_n > 0 ? 1 : 0);
   unsigned long long* tl = a.timeline && bid < DSK_TL_WGS ? a.timeline + (size_t)bid * 8 : nullptr;
   if (tl && tid == 0) tl[0] = wall_clock64();
-#ifdef TILE_DBG
-  TLane TL = tlane_init(lane);
-  if (tl && (wave == 2 || wave == 15)) { TL.dbg = tl + (wave == 2 ? 7 : 6); if (lane == 0) *TL.dbg = 0; }
-#else
   const TLane TL = tlane_init(lane);
-#endif
 
   // ---- prologue: the router left Q8_K(rmsnorm(x)) behind (previous launch): copy it into block records ----
   {

@@ -73,7 +73,7 @@ int gemv_plan_tile(GemvLaunch& h, int target_wgs) {
     h.n_groups = 1; h.grp_wg_end[0] = h.grid; h.grp_t0[0] = 0; h.grp_t0[1] = 1;
     return DSK_OK;
   }
-  int W = h.NW == 16 ? 256 : (h.NW == 8 ? 512 : target_wgs);
+  int W = h.NW == 16 ? 256 - (h.reserve_wgs > 0 && h.reserve_wgs < 128 ? h.reserve_wgs : 0) : (h.NW == 8 ? 512 : target_wgs);
   if (h.force_U > 8) W = h.force_U;  // micro-benchmarks (tools/kbench.py sweep): the workgroup count
   int wg = 0;
   h.n_groups = 0;

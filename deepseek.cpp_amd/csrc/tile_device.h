@@ -51,9 +51,6 @@ struct TLane {
   int shA;         // results of an even group carry factors (1, 1, 4, 4), of an odd group (16, 16, 16, 16)
   float lanefac;   // ... undone once per item: 1/4 or 1/16
   int vq, vs, vd;  // byte offsets of the lane's qs / scales / d|dmin inside a tile
-#ifdef TILE_DBG
-  unsigned long long* dbg;
-#endif
 };
 DEV TLane tlane_init(int lane) {
   TLane L;
@@ -66,9 +63,6 @@ DEV TLane tlane_init(int lane) {
   L.shA = (L.g & 1) ? 0 : 2;
   L.lanefac = (L.g & 1) ? 0.0625f : 0.25f;
   L.vq = lane * 16; L.vs = 1024 + lane * 4; L.vd = 1280 + L.n * 4;
-#ifdef TILE_DBG
-  L.dbg = nullptr;
-#endif
   return L;
 }
 
@@ -123,9 +117,6 @@ DEV void tile_group(rsrc_t W, int soff0, const uint8_t* act, int b, float* red_s
   TStep S[N];
 #pragma unroll
   for (int u = 0; u < N; ++u) tstep_load(S[u], W, L, soff0 + (b + u) * TILE_B);
-#ifdef TILE_DBG  // diagnostics: when the first group of a wave was requested / multiplied (low 32 bits of the 100 MHz clock each)
-  if (L.dbg && lane == 0 && (*L.dbg >> 32) == 0) *L.dbg = (unsigned long long)(unsigned)wall_clock64() << 32;
-#endif
   float accd = 0.f, accm = 0.f;
 #pragma unroll
   for (int u = 0; u < N; ++u) {
@@ -135,9 +126,6 @@ DEV void tile_group(rsrc_t W, int soff0, const uint8_t* act, int b, float* red_s
       accd = accm = 0.f;
     }
   }
-#ifdef TILE_DBG
-  if (L.dbg && lane == 0 && (unsigned)*L.dbg == 0) *L.dbg |= (unsigned)wall_clock64();
-#endif
 }
 template <int SEG>
 DEV void tile_strip_range(rsrc_t W, int soff0, const uint8_t* act, int b0, int b1, float* red_strip, const TLane& L, int lane) {
