@@ -2,7 +2,7 @@
 # Round evidence, one gpurun call on one box (profiles/README.md): bench line, rocprofv3 kernel traces (MHA, MLA, kv_len 4096),
 # a PMC pass of its own for HBM traffic, SQ counters in situ, the op-level GEMV table, the in-kernel timelines, the probes.
 #   bash tools/collect_profiles.sh r05        (every step bounded by `timeout`, nothing reads stdin)
-R=${1:-r05}
+R=${1:-r06}
 N="round ${R#r0} final build"
 mkdir -p gpurun_out profiles
 export TMPDIR=/tmp
@@ -26,9 +26,11 @@ $T python tools/moe_timeline.py < /dev/null 2>&1 | grep -v amdgpu.ids > gpurun_o
 # round 5: the floor of a five-launch block on this box; the prompt phase (dsk_hydrate) on the full model and its kernel trace
 timeout 120 tools/_build/block_floor 58 < /dev/null > gpurun_out/${R}_block_floor.txt 2>&1
 $T python tools/hydrate_bench.py --P 16,64,128,256,512 < /dev/null 2>&1 | grep '^{' | tail -1 > gpurun_out/${R}_hydrate.json
-$T python tools/hydrate_bench.py --P 16,64,128,256,512 --opt hydrate_route_seed=7 < /dev/null 2>&1 | grep '^{' | tail -1 > gpurun_out/${R}_hydrate_uniform.json
+# uniform routing instead of the synthetic model's skewed one: a measurement knob of -DDSK_AB builds only (tools/ab_build.sh ab "")
+AB=deepseek.cpp_amd/_ab/libdsk_ab.so
+[ -f $AB ] && DSK_LIB=$AB DSK_HYD_ROUTE_SEED=7 $T python tools/hydrate_bench.py --P 16,64,128,256,512 < /dev/null 2>&1 | grep '^{' | tail -1 > gpurun_out/${R}_hydrate_uniform.json
 $T python tools/hydrate_bench.py --attn mla --P 16,64,128,256 < /dev/null 2>&1 | grep '^{' | tail -1 > gpurun_out/${R}_hydrate_mla.json
-$T python tools/hydrate_bench.py --attn mla --P 64,128 --opt hydrate_route_seed=7 < /dev/null 2>&1 | grep '^{' | tail -1 > gpurun_out/${R}_hydrate_mla_uniform.json
+[ -f $AB ] && DSK_LIB=$AB DSK_HYD_ROUTE_SEED=7 $T python tools/hydrate_bench.py --attn mla --P 64,128 < /dev/null 2>&1 | grep '^{' | tail -1 > gpurun_out/${R}_hydrate_mla_uniform.json
 cd /tmp
 timeout 240 rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/trace_hyd -- python $ROOT/tools/hydrate_bench.py --P 64 --layers 8 --reps 1 --no-loop < /dev/null > $ROOT/gpurun_out/trace_hyd.log 2>&1
 cd $ROOT
@@ -38,6 +40,11 @@ rm -rf gpurun_out/trace_hyd
 $T python bench.py --model v2lite --steps 32 --warmup 4 --no-cpu-baseline --no-extras < /dev/null 2>&1 | grep '^{' | tail -1 > gpurun_out/${R}_bench_v2lite.json
 $T python bench.py --model v2lite --steps 32 --warmup 4 --no-cpu-baseline --no-extras --opt q2k_tiles=0 < /dev/null 2>&1 | grep '^{' | tail -1 > gpurun_out/${R}_bench_v2lite_planes.json
 rm -rf gpurun_out/trace_mha gpurun_out/trace_mla gpurun_out/pmc gpurun_out/pmc_sq
+# round 6: the scalar-path publish probe; the experimental schedules of the fused expert launch next to the shipped one (A/B lines + stamps)
+[ -x tools/_build/scalar_store_probe ] && timeout 120 tools/_build/scalar_store_probe < /dev/null 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_scalar_store_probe.txt
+( $T python tools/moe_ab.py; $T python tools/moe_ab.py --opt moe_pipe=1; $T python tools/moe_ab.py --opt moe_pipe=2; $T python tools/moe_ab.py --attn mla; $T python tools/moe_ab.py --attn mla --opt ride_kvwrite=0 ) < /dev/null 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_ab_moe_pipe.txt
+$T python tools/moe_timeline.py --layers 61 --opt moe_pipe=1 < /dev/null 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_timeline_moe_pipe1.txt
+$T python tools/moe_timeline.py --layers 61 --opt moe_pipe=2 < /dev/null 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_timeline_moe_pipe2.txt
 # the whole GPU test-suite and the smoke entry point on the same sources, same box
 ( timeout 900 python -m pytest tests -q -m gpu < /dev/null; timeout 300 python __graft_entry__.py smoke < /dev/null ) > gpurun_out/${R}_gputests.log 2>&1
 tail -3 gpurun_out/${R}_gputests.log
