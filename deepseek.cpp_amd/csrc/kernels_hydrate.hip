@@ -837,6 +837,9 @@ __global__ __launch_bounds__(256) void hyd_kv_write_kernel(const AttnMhaArgs a, 
 // un-normalised partials (head_attn_kernel, kernels_gemv.hip): another float association than one softmax over the whole context.
 // Here ONE workgroup walks the same pieces [kv_len s / S, kv_len (s + 1) / S) in turn, keeps the partials in LDS and merges them with
 // the decode launch's statements: the same bits.
+// (SPLIT is an instantiation of its own, launched only for chunks that reach the regime: the partials' 16 KB of LDS and the merge
+// cost the short-context instantiation a third of its speed - 87 -> 129 us per block at P = 64 - when they were one kernel)
+template <bool SPLIT>
 __global__ __launch_bounds__(1024, 8) void hyd_attn_kernel(const AttnMhaArgs a, const StepParams* __restrict__ sps, const float* __restrict__ q, int q_stride,
                                                         float* __restrict__ out, int out_stride, int n_split, int split_min) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -867,11 +870,12 @@ __global__ __launch_bounds__(1024, 8) void hyd_attn_kernel(const AttnMhaArgs a, 
   }
   __syncthreads();
   const int kv_len = sp->kv_len;
-  if (n_split <= 1 || kv_len < split_min) {
+  if (!SPLIT || n_split <= 1 || kv_len < split_min) {
     const float o = ad::attn_mha_body<1024>(a, q_s, 0, kv_len, h, tid, att, scratch, part);
     if (tid < vd) out[(size_t)p * out_stride + (size_t)h * vd + tid] = o;
     return;
   }
+  if constexpr (SPLIT) {
   __shared__ float ml_s[2];
   __shared__ float sp_s[MHA_SPLIT_MAX][260];  // a piece's un-normalised mix [v_dim] | its maximum | its sum
   const int S = n_split;
@@ -894,6 +898,7 @@ __global__ __launch_bounds__(1024, 8) void hyd_attn_kernel(const AttnMhaArgs a, 
   }
   o /= Lsum;
   if (tid < vd) out[(size_t)p * out_stride + (size_t)h * vd + tid] = o;
+  }
 }
 int launch_hyd_kv_write(hipStream_t st, const AttnMhaArgs& a, const StepParams* sps, int P, const float* kv_b, int kvb_stride, const float* kv_a, int kva_stride) {
   hipLaunchKernelGGL(hyd_kv_write_kernel, dim3(a.n_heads, P), dim3(256), 0, st, a, sps, kv_b, kvb_stride, kv_a, kva_stride);
@@ -904,9 +909,10 @@ int launch_hyd_attn(hipStream_t st, const AttnMhaArgs& a, const StepParams* sps,
   const size_t lds = (size_t)max_kv * 4;
   if (lds > 96 * 1024) DSK_FAIL(DSK_ERR_UNSUPPORTED, "hyd_attn: kv_len %d does not fit LDS", max_kv);
   if (a.head_dim > 256 || a.v_dim > 256) DSK_FAIL(DSK_ERR_UNSUPPORTED, "hyd_attn: head_dim %d / v_head_dim %d", a.head_dim, a.v_dim);
-  auto k = hyd_attn_kernel;
-  if (lds > 32 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (n_split > MHA_SPLIT_MAX) n_split = MHA_SPLIT_MAX;  // (launch_head_attn's clamp)
+  const bool split = n_split > 1 && max_kv >= split_min;
+  auto k = split ? hyd_attn_kernel<true> : hyd_attn_kernel<false>;
+  if (lds > 32 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k, dim3(a.n_heads, P), dim3(1024), lds, st, a, sps, q, q_stride, out, out_stride, n_split, split_min);
   return DSK_OK;
 }
