@@ -35,7 +35,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "deepseek.cpp_amd"))
 
-PMC_FILE = "r05_pmc.json"
 
 
 def csrc_sha() -> str:
@@ -345,13 +344,17 @@ def main():
         # HBM traffic is NOT measured in this run: PMC counters need their own rocprofv3 passes.  The figure of the committed
         # pass is reported only if it was taken on these very kernel sources (sha of deepseek.cpp_amd/csrc), and labelled.
         traffic, traffic_source = None, "not measured in this run (no committed PMC pass for these kernel sources)"
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
-            if pm.get("csrc_sha") == csrc_sha():
-                traffic = pm.get("traffic_bytes_per_launch", {}).get(dom)
-                traffic_source = f"profiles/{PMC_FILE} (separate rocprofv3 --pmc passes on the same kernel sources, csrc sha {pm.get('csrc_sha')})"
-        except Exception:
-            pass
+        import glob
+        for pmc_path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):  # the newest round's first
+            try:
+                pm = json.load(open(pmc_path))
+                if pm.get("csrc_sha") == csrc_sha():
+                    traffic = pm.get("traffic_bytes_per_launch", {}).get(dom)
+                    traffic_source = (f"profiles/{os.path.basename(pmc_path)} (separate rocprofv3 --pmc passes on the same kernel sources, "
+                                      f"csrc sha {pm.get('csrc_sha')})")
+                    break
+            except Exception:
+                pass
         roof = dict(bound="hbm", kernel=dom, achieved=k["gbps"], peak=HBM_PEAK_GBPS, unit="GB/s",
                     frac=round(k["gbps"] / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_source=traffic_source,
                     bytes_per_launch=k["bytes_per_launch"], avg_launch_us=k["us_per_launch"],
