@@ -440,8 +440,9 @@ def main():
         extras["v2lite"] = v2
     if rank == 0 and world == 1 and not a.no_extras and not a.dry_shard and full_v3 and a.attn == "mha":
         # the prompt phase through dsk_hydrate (batched launches, every weight read once per chunk) on the same
-        # shapes with every Q2_K matrix stored as tile records, next to the per-token loop of the same model (what the reference
-        # does with a prompt, src/main.cpp:312-319)
+        # model at the same options as the timed decode (since round 6 the default layout batches: tile copies of its plane
+        # matrices, hydrate.cpp), next to the per-token loop of that model (what the reference does with a prompt,
+        # src/main.cpp:312-319)
         try:
             from tools import hydrate_bench
             c3 = synth.preset(a.model, a.quant, False)

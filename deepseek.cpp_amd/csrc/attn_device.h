@@ -401,4 +401,45 @@ ADEV void attn_out_q8(const AttnMhaArgs& a, int h, int tid, float o, int* last_f
     __syncthreads();
   }
 }
+
+// MLA long contexts: merge of mla_flash_kernel's chunk partials for head h - out = sum_c e^(m_c - M) O_c / sum_c e^(m_c - M) l_c -
+// by a 1024-thread workgroup; `part` = 64 + 1024 floats of LDS, o_s = the head's lora (<= 512) merged columns, valid after the
+// call (it ends with a barrier).  ONE body for the decode launch (kernels_gemv.hip mla_head_kernel) and the batched prompt path
+// (kernels_hydrate.hip hyd_mla_merge_kernel): the same statements in the same order, the same bits.
+ADEV void mla_merge_partials(const float* __restrict__ part_ml, const float* __restrict__ part_o, int H, int h, int lora, int nc, int tid,
+                             float* part, float* o_s) {
+  float* wc = part;  // per-chunk weights e^(m_c - M) / L, computed once
+  if (tid < 64) {
+    const float mc = tid < nc ? part_ml[((size_t)tid * H + h) * 2] : -INFINITY;
+    const float lc = tid < nc ? part_ml[((size_t)tid * H + h) * 2 + 1] : 0.f;
+    const float M = wave_max_dpp(mc);
+    const float e = tid < nc ? expf(mc - M) : 0.f;
+    const float Lsum = wave_sum_dpp(e * lc);
+    wc[tid] = e / Lsum;
+  }
+  __syncthreads();
+  // column tid & 511, even chunks in the lower half of the workgroup, odd ones in the upper; 8 partials requested per
+  // round trip (one dependent load per chunk made this merge ~0.4 us x the number of chunks)
+  {
+    const int col = tid & 511, half = tid >> 9;
+    float o = 0.f;
+    for (int c0 = half; c0 < nc; c0 += 16) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = c0 + 2 * j;
+        v[j] = (c < nc && col < lora) ? part_o[((size_t)c * H + h) * lora + col] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = c0 + 2 * j;
+        if (c < nc) o = fmaf(wc[c], v[j], o);
+      }
+    }
+    part[64 + tid] = o;
+  }
+  __syncthreads();
+  if (tid < lora && tid < 512) o_s[tid] = part[64 + tid] + part[64 + 512 + tid];
+  __syncthreads();
+}
 }  // namespace ad

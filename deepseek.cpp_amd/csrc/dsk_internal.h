@@ -418,12 +418,16 @@ struct MlaFlashArgs {
   int n_heads, head_dim, lora, rope, is_v3;
   unsigned long long* timeline;  // debug (DSK_TIMELINE=1): 8 stamps per workgroup (chunk x head group)
   int chunk_len, n_chunks;   // positions per chunk (multiple of 32; 0: derived from the step's kv_len, MLA_FL_CHUNK), chunks in the grid
+  // the batched prompt path (kernels_hydrate.hip): blockIdx.z = token of the chunk - its own step row (sp + z), q rows (z * the
+  // strides below, in floats) and partials (z * n_chunks * H * lora / * 2); tokens whose context is shorter than min_kv are skipped
+  // (they take the per-head kernel's own attention).  All zero in the decode launches (grid z = 1).
+  int tok_qc_stride, tok_qr_stride, min_kv;
 };
 // positions per chunk for a context of kv_len: the grid (n_chunks x head groups) is fixed in the captured graph, the
 // share of each chunk follows the context, so that a 1024-position context occupies 32 chunks of 32 positions instead
 // of 11 chunks of 96 (mla_flash_kernel at kv_len 1024: 31 -> 13 us)
 #define MLA_FL_CHUNK(kv_len, n_chunks) ((((kv_len) + (n_chunks) - 1) / (n_chunks) + 31) / 32 * 32)
-int launch_mla_flash(hipStream_t st, const MlaFlashArgs& a, const StepParams* sp, int kv_len_override);
+int launch_mla_flash(hipStream_t st, const MlaFlashArgs& a, const StepParams* sp, int kv_len_override, int n_tokens = 1);
 int launch_mla_merge(hipStream_t st, const MlaFlashArgs& a, const StepParams* sp, int kv_len_override, float* out);
 // MLA, model path: (1) one workgroup normalises the latent, writes this position's cache entries and rotates the
 // sink keys; (2) one 16-wave workgroup per head: RoPE of q_rope, attention over the shared latent cache, the head's
@@ -511,6 +515,7 @@ int launch_hyd_kv_write(hipStream_t st, const AttnMhaArgs& a, const StepParams* 
 int launch_hyd_attn(hipStream_t st, const AttnMhaArgs& a, const StepParams* sps, int P, int max_kv, const float* q, int q_stride, float* out, int out_stride,
                     int n_split, int split_min);
 int launch_hyd_mla_kv_write(hipStream_t st, const MlaKvArgs& kv, const StepParams* sps, int P, int kva_stride);
+int launch_hyd_mla_merge(hipStream_t st, const MlaFlashArgs& f, const StepParams* sps, int n_tokens, float* latent, int lat_stride);
 int launch_hyd_mla_attn(hipStream_t st, const AttnMlaArgs& a, const StepParams* sps, int P, int max_kv, const float* q_c, int qc_stride, const float* q_rope,
                         int qr_stride, float* latent, int lat_stride);
 int launch_hyd_head_list(hipStream_t st, int* list, int* count, int H, int P, int stride);

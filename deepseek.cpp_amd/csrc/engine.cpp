@@ -270,6 +270,7 @@ extern "C" int dsk_model_set_option(dsk_model* m, const char* key, int value) {
   else if (k == "exchange_allgather") m->exchange_allgather = value != 0;
   else if (k == "hydrate_chunk") { if (value < 1 || value > 1024) DSK_FAIL(DSK_ERR_INVALID, "set_option: hydrate_chunk %d (1 .. 1024)", value); m->hydrate_chunk = value; }
   else if (k == "hydrate_batched") m->hydrate_batched = value != 0;
+  else if (k == "hydrate_tile_copies") m->hydrate_tile_copies = value != 0;
   else if (k == "hydrate_tap_layer") { if (value < -1 || value >= m->c.n_layers) DSK_FAIL(DSK_ERR_INVALID, "set_option: hydrate_tap_layer %d", value); m->hydrate_tap_layer = value; }
   else if (k == "q2k_tiles") {
     if (m->any_bound) DSK_FAIL(DSK_ERR_STATE, "set_option: q2k_tiles must be set before the first tensor is bound");
@@ -287,6 +288,7 @@ extern "C" int dsk_model_get_info(dsk_model* m, const char* key, int* value) {
   else if (k == "graph_capture_fallbacks") *value = m->graph_capture_fallbacks;
   else if (k == "hydrate_batched_tokens") *value = (int)std::min<long long>(m->hydrate_batched_tokens, 0x7fffffff);
   else if (k == "hydrate_looped_tokens") *value = (int)std::min<long long>(m->hydrate_looped_tokens, 0x7fffffff);
+  else if (k == "hydrate_tile_copy_mb") *value = (int)(m->hydrate_tile_copy_bytes / 1048576.0);
   else if (k == "fused_moe_layers") { int n = 0; for (auto& a : m->moe_ffn) n += a.grid > 0; *value = n; }
   else if (k == "graph_captured") { int n = 0; for (auto g : m->graph) n += g != nullptr; *value = n; }
   else if (k == "exchange_calls") *value = m->exchange_calls;

@@ -151,6 +151,8 @@ struct dsk_model {
   int hydrate_tap_layer = -1;       // option "hydrate_tap_layer" (parity harness): the block whose intermediates a batched chunk copies aside for
                                     // dsk_hydrate_get_buffer; the chunk itself runs unchanged
   bool hydrate_batched = true;      // option "hydrate_batched": 0 = dsk_hydrate always runs the per-token loop
+  bool hydrate_tile_copies = true;  // option "hydrate_tile_copies": the batched path may keep tile-record copies of the plane-layout Q2_K matrices (hydrate.cpp)
+  double hydrate_tile_copy_bytes = 0;  // bytes of those copies (made by the first batched dsk_hydrate call)
   long long hydrate_batched_tokens = 0, hydrate_looped_tokens = 0;  // dsk_model_get_info
   const char* hydrate_why = nullptr;  // why the last dsk_hydrate call looped (nullptr: it did not)
   std::vector<MlaHeadArgs> mla_head;   // per layer (MLA path)

@@ -44,6 +44,8 @@ struct HydState {
   HydQ8 a_x, a_qa, a_kva, a_att, a_hd, a_hb, a_hsh, a_lat;
   float *q_rope = nullptr, *q_c = nullptr, *latent = nullptr;  // MLA: (P, H * rope), (P, H * lora), (P, H * lora)
   int *head_list = nullptr, *head_count = nullptr;              // MLA: wv_b as one GEMM task per head
+  // MLA, tokens whose context has reached the matrix-core regime (mla_flash_min_kv): chunk partials of HYD_FL_TOKENS tokens at a time
+  float *fl_part_o = nullptr, *fl_part_ml = nullptr;
   StepParams *sp = nullptr, *sp_host = nullptr;  // the chunk's step rows; the pinned side is two halves used in turn (sp_done)
   hipEvent_t sp_done[2] = {nullptr, nullptr};     // the upload that last read half k
   int sp_turn = 0;
@@ -52,8 +54,14 @@ struct HydState {
   int last_P = 0;                                 // tokens of the last batched chunk (what the accessors may hand out)
   // parity harness (option "hydrate_tap_layer"): copies of ONE block's intermediates, taken while the chunk runs on
   std::map<std::string, std::pair<void*, size_t>> taps;  // name -> (device copy of `cap` rows, bytes per row)
+  // Q2_K matrices the decode launches keep as PLANES (option "q2k_tiles" = 1: every role but the experts'), re-laid-out as tile
+  // records for the batched GEMMs when the first prompt arrives (hyd_tile_copies below)
+  std::map<const DTensor*, const uint8_t*> tile_copy;
+  double tile_copy_bytes = 0;
   std::vector<void*> allocs;
 };
+
+#define HYD_FL_TOKENS 16  // tokens per mla_flash launch of the batched path: 16 x 64 chunks x 128 heads x 512 floats = 268 MB of partials
 
 static int hyd_alloc(HydState* h, void** p, size_t bytes, double* total) {
   if (bytes == 0) bytes = 16;
@@ -76,6 +84,28 @@ void hydrate_free(dsk_model* m) {
   for (hipEvent_t e : m->hyd->sp_done) if (e) hipEventDestroy(e);
   delete m->hyd;
   m->hyd = nullptr;
+  m->hydrate_tile_copy_bytes = 0;
+}
+
+// The tile records of a matrix: the tensor itself when it is stored that way, else the batched path's copy.
+static const uint8_t* tile_w(const HydState& h, const DTensor& t) {
+  if (t.tiled) return t.qs;
+  const auto it = h.tile_copy.find(&t);
+  return it == h.tile_copy.end() ? nullptr : it->second;
+}
+// a plane-layout Q2_K matrix the batched path may copy into tile records (option "hydrate_tile_copies")
+static bool tile_copyable(const dsk_model* m, const DTensor& t) {
+  return m->hydrate_tile_copies && t.bound() && !t.tiled && t.quant == DSK_QUANT_Q2_K && t.n_experts == 0 && t.n % 256 == 0 && t.n / 256 <= 255 && t.qs && t.sc && t.dm;
+}
+// the matrices of block l the batched path multiplies as plain (one-matrix) GEMMs
+static void hyd_plain_roles(const dsk_model* m, int l, std::vector<int>& roles) {
+  const dsk_config& c = m->c;
+  const Layer& L = m->L[l];
+  roles = {DSK_ROLE_WQ_A, DSK_ROLE_WKV_A, DSK_ROLE_WO};
+  if (c.use_mla) roles.insert(roles.end(), {DSK_ROLE_WQ_ROPE_B, DSK_ROLE_WC, DSK_ROLE_WV_B});
+  else roles.insert(roles.end(), {DSK_ROLE_WQ_B, DSK_ROLE_WKV_B});
+  if (!L.is_moe) roles.insert(roles.end(), {DSK_ROLE_W1, DSK_ROLE_W2, DSK_ROLE_W3});
+  else if (c.n_shared_experts > 0) roles.insert(roles.end(), {DSK_ROLE_SHARED_W1, DSK_ROLE_SHARED_W2, DSK_ROLE_SHARED_W3});
 }
 
 // why this model takes the per-token loop (nullptr: the batched path applies)
@@ -90,21 +120,18 @@ static const char* hyd_why_not(const dsk_model* m) {
   if (m->head_dim > 256 || c.v_head_dim > 256 || (c.v_head_dim & 3) || (m->head_dim & 3)) return "head dims";
   if (c.q_lora_rank % 256 || c.kv_lora_rank % 256 || c.q_lora_rank / 256 + c.kv_lora_rank / 256 > 16) return "latent ranks";
   if (c.n_routed_experts > 256 || c.n_active_routed > 64) return "expert counts";
-  auto tiled = [&](const Layer& L, int role) { return L.t[role].bound() && L.t[role].tiled; };
+  // tile records: stored that way (option "q2k_tiles"), or - the plain matrices only, never the expert stacks - copied into that
+  // layout when the first prompt arrives (option "hydrate_tile_copies": ~4.4 GB next to DeepSeek-V3's 242)
+  std::vector<int> roles;
   for (int l = 0; l < c.n_layers; ++l) {
     const Layer& L = m->L[l];
-    for (int role : {DSK_ROLE_WQ_A, DSK_ROLE_WKV_A, DSK_ROLE_WO, DSK_ROLE_W1, DSK_ROLE_W2, DSK_ROLE_W3})
-      if (!tiled(L, role)) return "a Q2_K matrix is not stored as tile records (set option q2k_tiles = 2 before binding)";
-    if (c.use_mla) {
-      for (int role : {DSK_ROLE_WQ_ROPE_B, DSK_ROLE_WC, DSK_ROLE_WV_B})
-        if (!tiled(L, role)) return "an MLA projection is not stored as tile records (set option q2k_tiles = 2 before binding)";
-    } else {
-      for (int role : {DSK_ROLE_WQ_B, DSK_ROLE_WKV_B})
-        if (!tiled(L, role)) return "a Q2_K matrix is not stored as tile records (set option q2k_tiles = 2 before binding)";
-    }
-    if (L.is_moe && c.n_shared_experts > 0)
-      for (int role : {DSK_ROLE_SHARED_W1, DSK_ROLE_SHARED_W2, DSK_ROLE_SHARED_W3})
-        if (!tiled(L, role)) return "the shared expert is not stored as tile records";
+    hyd_plain_roles(m, l, roles);
+    for (int role : roles)
+      if (!(L.t[role].bound() && (L.t[role].tiled || tile_copyable(m, L.t[role]))))
+        return "a Q2_K matrix is neither stored as tile records nor copyable into them (options q2k_tiles, hydrate_tile_copies)";
+    if (L.is_moe)
+      for (int role : {DSK_ROLE_W1, DSK_ROLE_W2, DSK_ROLE_W3})
+        if (!(L.t[role].bound() && L.t[role].tiled)) return "the routed experts are not stored as tile records (option q2k_tiles >= 1 and shapes the tiled expert kernels take)";
     if (L.is_moe && c.moe_intermediate_size % 256) return "moe_intermediate_size";
     // the norm + Q8_K launches reproduce the sum-of-squares tree of the decode launch that consumes the vector: built for 4 / 8 / 16 waves
     for (int lp : {m->lp_qkv_a[l], c.use_mla ? m->lp_qkv_b[l] : -1, L.is_moe ? -1 : m->lp_w13[l]})
@@ -146,6 +173,10 @@ static int hyd_ensure_alloc(dsk_model* m) {
     DSK_TRY(hyd_alloc_q8(h, h->a_lat, P * H, lora, &tot));
     DSK_TRY(hyd_alloc(h, (void**)&h->head_list, H * P * 4, &tot));
     DSK_TRY(hyd_alloc(h, (void**)&h->head_count, H * 4, &tot));
+    if (m->fl_part_o) {
+      DSK_TRY(hyd_alloc(h, (void**)&h->fl_part_o, (size_t)HYD_FL_TOKENS * 64 * H * lora * 4, &tot));
+      DSK_TRY(hyd_alloc(h, (void**)&h->fl_part_ml, (size_t)HYD_FL_TOKENS * 64 * H * 8, &tot));
+    }
   } else {
     DSK_TRY(hyd_alloc(h, (void**)&h->q, P * H * hd * 4, &tot));
     DSK_TRY(hyd_alloc(h, (void**)&h->kv_b, P * H * nv * 4, &tot));
@@ -177,6 +208,26 @@ static int hyd_ensure_alloc(dsk_model* m) {
   for (hipEvent_t& e : h->sp_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   if (m->trace) DSK_TRY(hyd_alloc(h, (void**)&h->trace, (size_t)c.n_layers * P * dim * 4, &tot));
   m->scratch_bytes += tot;
+  // tile-record copies of the plane matrices (nothing to do at "q2k_tiles" = 2); the decode launches keep reading the planes
+  std::vector<int> roles;
+  for (int l = 0; l < c.n_layers; ++l) {
+    hyd_plain_roles(m, l, roles);
+    for (int role : roles) {
+      const DTensor& t = m->L[l].t[role];
+      if (t.tiled) continue;
+      const size_t bytes = tile_mat_bytes(t.rows, t.n);
+      void* p = nullptr;
+      double cb = 0;
+      DSK_TRY(hyd_alloc(h, &p, bytes, &cb));
+      if (t.rows & 15) HIP_TRY(hipMemsetAsync(p, 0, bytes, m->ctx->stream));  // (padding rows of the last strip stay zero)
+      DSK_TRY(launch_planes_to_tiles_q2k(m->ctx->stream, t.qs, t.sc, t.dm, 0, (size_t)t.rows * (t.n / 256), t.rows, t.n / 256, bytes, static_cast<uint8_t*>(p)));
+      h->tile_copy[&t] = static_cast<const uint8_t*>(p);
+      h->tile_copy_bytes += cb;
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+  HIP_TRY(hipGetLastError());
+  m->hydrate_tile_copy_bytes = h->tile_copy_bytes;
   return DSK_OK;
 }
 
@@ -208,7 +259,8 @@ static int hyd_tap_q8(dsk_model* m, int l, const std::string& point, const HydQ8
 static int hyd_gemm(dsk_model* m, const DTensor& w, const DTensor* w3, const HydQ8& a, int a_rows, int P, float* out, int out_stride, int epilogue) {
   HydGemmArgs A;
   memset(&A, 0, sizeof A);
-  A.W = w.qs; A.W3 = w3 ? w3->qs : nullptr;
+  A.W = tile_w(*m->hyd, w); A.W3 = w3 ? tile_w(*m->hyd, *w3) : nullptr;
+  if (!A.W || (w3 && !A.W3)) DSK_FAIL(DSK_ERR_STATE, "hydrate: a matrix has no tile records");
   A.rows = w.rows; A.n = w.n;
   A.a_qs = a.qs; A.a_d = a.d; A.a_bsums = a.bsums; A.a_rows = a_rows; A.a_div = 1;
   A.m = P; A.out = out; A.out_stride = out_stride; A.epilogue = epilogue; A.act = m->c.act;
@@ -217,7 +269,8 @@ static int hyd_gemm(dsk_model* m, const DTensor& w, const DTensor* w3, const Hyd
   return launch_hyd_gemm(m->ctx->stream, A, P <= 4 ? 1 : 2);
 }
 
-static int hyd_layer(dsk_model* m, int l, int P, int max_kv) {
+// n_short: the chunk's first tokens whose context is below the MLA matrix-core regime (all of them for MHA)
+static int hyd_layer(dsk_model* m, int l, int P, int max_kv, int n_short) {
   const dsk_config& c = m->c;
   HydState& h = *m->hyd;
   Layer& L = m->L[l];
@@ -242,14 +295,22 @@ static int hyd_layer(dsk_model* m, int l, int P, int max_kv) {
     kv.nope_cache = L.nope_cache; kv.rope_cache = L.rope_cache; kv.lora = kvl; kv.rope = rope; kv.is_v3 = c.has_moegate_bias;
     DSK_TRY(launch_hyd_mla_kv_write(st, kv, h.sp, P, kvl + rope));
     const AttnMlaArgs& am = m->mla_head[l].a;
-    DSK_TRY(launch_hyd_mla_attn(st, am, h.sp, P, max_kv, h.q_c, H * kvl, h.q_rope, H * rope, h.latent, H * kvl));
+    if (n_short > 0) DSK_TRY(launch_hyd_mla_attn(st, am, h.sp, n_short, max_kv - (P - n_short), h.q_c, H * kvl, h.q_rope, H * rope, h.latent, H * kvl));
+    for (int t0 = n_short; t0 < P; t0 += HYD_FL_TOKENS) {  // decode's long-context regime, token by token in one grid (src/infer.cpp:766-804)
+      const int nb = std::min(HYD_FL_TOKENS, P - t0);
+      MlaFlashArgs F = m->mla_flash[l];
+      F.q_c = h.q_c + (size_t)t0 * H * kvl; F.q_rope = h.q_rope + (size_t)t0 * H * rope; F.tok_qc_stride = H * kvl; F.tok_qr_stride = H * rope;
+      F.part_o = h.fl_part_o; F.part_ml = h.fl_part_ml; F.timeline = nullptr; F.min_kv = 0;
+      DSK_TRY(launch_mla_flash(st, F, h.sp + t0, 0, nb));
+      DSK_TRY(launch_hyd_mla_merge(st, F, h.sp + t0, nb, h.latent + (size_t)t0 * H * kvl, H * kvl));
+    }
     DSK_TRY(launch_quantize_q8k(st, h.latent, P * H * kvl, h.a_lat.qs, h.a_lat.d, h.a_lat.bsums));
     {  // per-head wv_b (src/infer.cpp:1134-1137): one task per head over all tokens
       const DTensor& wv = L.t[DSK_ROLE_WV_B];
       DSK_TRY(launch_hyd_head_list(st, h.head_list, h.head_count, H, P, h.cap));
       HydGemmArgs A;
       memset(&A, 0, sizeof A);
-      A.W = wv.qs; A.e_bytes = tile_mat_bytes(vd, kvl); A.n_experts = H; A.rows = vd; A.n = kvl;
+      A.W = tile_w(h, wv); A.e_bytes = tile_mat_bytes(vd, kvl); A.n_experts = H; A.rows = vd; A.n = kvl;
       A.a_qs = h.a_lat.qs; A.a_d = h.a_lat.d; A.a_bsums = h.a_lat.bsums; A.a_rows = P * H; A.a_div = 1;
       A.list = h.head_list; A.count = h.head_count; A.list_stride = h.cap;
       A.out = h.att; A.out_stride = vd; A.epilogue = EPI_STORE; A.act = c.act;
@@ -383,8 +444,15 @@ static int hyd_chunk(dsk_model* m, const int32_t* tokens, int P, int pos0) {
   // Model::_copy_embedding, src/infer.cpp:1217-1263: the P rows in one launch (the tokens come from the step rows)
   DSK_TRY(launch_embed_rows(st, m->g[DSK_ROLE_EMBED], h.sp, P, std::max(1, c.block_size[0]), std::max(1, c.block_size[1]), h.X));
   const int max_kv = pos0 + P;
+  int n_short = P;
+  if (c.use_mla && m->fl_part_o) {
+    n_short = 0;
+    while (n_short < P && rows[n_short].kv_len < m->mla_flash_min_kv) ++n_short;
+    for (int p = n_short; p < P; ++p)
+      if (rows[p].kv_len < m->mla_flash_min_kv) DSK_FAIL(DSK_ERR_STATE, "hydrate: context lengths of a chunk are not ascending");
+  }
   for (int l = 0; l < c.n_layers; ++l) {
-    DSK_TRY(hyd_layer(m, l, P, max_kv));
+    DSK_TRY(hyd_layer(m, l, P, max_kv, n_short));
     if (h.trace) HIP_TRY(hipMemcpyAsync(h.trace + (size_t)l * h.cap * c.dim, h.X, (size_t)P * c.dim * 4, hipMemcpyDeviceToDevice, st));
   }
   return DSK_OK;
@@ -394,9 +462,8 @@ static int hyd_chunk(dsk_model* m, const int32_t* tokens, int P, int pos0) {
 static int hyd_position_limit(const dsk_model* m) {
   // positions before the ring wraps (src/infer.cpp:1271-1277: from pos >= W on the sink keys are rotated in place, token by token)
   int limit = std::min(m->c.max_seq_len, std::max(1, m->c.rs_original_max_position_embeddings));
-  // MLA: from mla_flash_min_kv cached positions on the decode path scores on the matrix cores (mla_flash_kernel: its own
-  // association); the batched path reproduces the short-context kernel only
-  if (m->c.use_mla && m->fl_part_o) limit = std::min(limit, std::max(1, m->mla_flash_min_kv - 1));
+  // (MLA: from mla_flash_min_kv cached positions on the decode path scores on the matrix cores - its own association; the batched
+  // path runs that very kernel over the chunk's long-context tokens and merges like mla_head_kernel: no limit from that regime)
   // (MHA: from mha_split_min cached positions on decode runs mha_split workgroups per head over pieces of the context and merges
   // un-normalised partials - hyd_attn_kernel walks the same pieces and merges them the same way: no limit from that regime)
   // the attention launches keep one float per cached position in LDS
@@ -420,7 +487,7 @@ extern "C" int dsk_hydrate(dsk_model* m, const int32_t* tokens, int n_tokens, in
   if (!why && hyd_ensure(m) != DSK_OK) {  // no room for the chunk buffers: the call is still valid - it IS the loop
     (void)hipGetLastError();
     dsk_clear_error();
-    why = "the chunk buffers do not fit the device's free memory";
+    why = "the chunk buffers (and tile copies) do not fit the device's free memory";
   }
   m->hydrate_why = why;
   if (!why) {

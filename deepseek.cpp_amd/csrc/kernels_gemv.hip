@@ -773,39 +773,7 @@ __global__ __launch_bounds__(1024) void mla_head_kernel(const MlaHeadArgs A, con
     const int fcl = A.fl_chunk_len > 0 ? A.fl_chunk_len : MLA_FL_CHUNK(kv_len, A.fl_n_chunks);
     const int nc = min(A.fl_n_chunks, (kv_len + fcl - 1) / fcl);
     const int H = a.n_heads;
-    float* wc = part;  // per-chunk weights e^(m_c - M) / L, computed once
-    if (tid < 64) {
-      const float mc = tid < nc ? A.fl_part_ml[((size_t)tid * H + h) * 2] : -INFINITY;
-      const float lc = tid < nc ? A.fl_part_ml[((size_t)tid * H + h) * 2 + 1] : 0.f;
-      const float M = ad::wave_max_dpp(mc);
-      const float e = tid < nc ? expf(mc - M) : 0.f;
-      const float Lsum = ad::wave_sum_dpp(e * lc);
-      wc[tid] = e / Lsum;
-    }
-    __syncthreads();
-    // column tid & 511, even chunks in the lower half of the workgroup, odd ones in the upper; 8 partials requested per
-    // round trip (one dependent load per chunk made this merge ~0.4 us x the number of chunks)
-    {
-      const int col = tid & 511, half = tid >> 9;
-      float o = 0.f;
-      for (int c0 = half; c0 < nc; c0 += 16) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int c = c0 + 2 * j;
-          v[j] = (c < nc && col < lora) ? A.fl_part_o[((size_t)c * H + h) * lora + col] : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int c = c0 + 2 * j;
-          if (c < nc) o = fmaf(wc[c], v[j], o);
-        }
-      }
-      part[64 + tid] = o;
-    }
-    __syncthreads();
-    if (tid < lora && tid < 512) o_s[tid] = part[64 + tid] + part[64 + 512 + tid];
-    __syncthreads();
+    ad::mla_merge_partials(A.fl_part_ml, A.fl_part_o, H, h, lora, nc, tid, part, o_s);
   } else {
   // ---- scores: 16 lanes per position, 2 positions per group and step ----
   float qv[8][4], qr4[4];

@@ -923,8 +923,9 @@ int launch_hyd_attn(hipStream_t st, const AttnMhaArgs& a, const StepParams* sps,
 // scores over the shared latent cache, softmax, the latent value mix - leaving the head's latent output; the per-head wv_b rows
 // are a block-diagonal GEMM over all tokens afterwards (launch_hyd_gemm with one task per head).  The code below is the decode
 // kernel's (kernels_gemv.hip mla_head_kernel, `!merged` branch), statement for statement: the same trees, the same bits.
-// Contexts from MLA_FLASH_MIN_KV positions on take the matrix-core path in decode (its own association): the host keeps such
-// positions out of the batched path.
+// Contexts from MLA_FLASH_MIN_KV positions on take the matrix-core path in decode (its own association): for those tokens the host
+// launches decode's own mla_flash_kernel with the token as a third grid dimension (kernels_misc.hip) and hyd_mla_merge_kernel
+// below - the merge of mla_head_kernel's `merged` branch, one body for both (attn_device.h mla_merge_partials).
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void hyd_mla_kv_write_kernel(MlaKvArgs kv, const StepParams* __restrict__ sps, int kva_stride) {
   const int p = blockIdx.x;
@@ -1071,6 +1072,23 @@ __global__ __launch_bounds__(1024) void hyd_mla_attn_kernel(const AttnMlaArgs a,
       latent[(size_t)p * lat_stride + (size_t)h * lora + tid] = o;
     }
   }
+}
+// the long-context tokens of a chunk: per (head, token) the merge of mla_flash_kernel's chunk partials (mla_head_kernel, `merged`)
+__global__ __launch_bounds__(1024) void hyd_mla_merge_kernel(const float* __restrict__ part_ml, const float* __restrict__ part_o, int H, int lora, int n_chunks,
+                                                             const StepParams* __restrict__ sps, float* __restrict__ latent, int lat_stride) {
+  __shared__ __attribute__((aligned(16))) float part[64 + 1024];
+  __shared__ __attribute__((aligned(16))) float o_s[512];
+  const int tid = threadIdx.x, h = blockIdx.x, p = blockIdx.y;
+  const int kv_len = sps[p].kv_len;
+  const int fcl = MLA_FL_CHUNK(kv_len, n_chunks);
+  const int nc = min(n_chunks, (kv_len + fcl - 1) / fcl);
+  ad::mla_merge_partials(part_ml + (size_t)p * n_chunks * H * 2, part_o + (size_t)p * n_chunks * H * lora, H, h, lora, nc, tid, part, o_s);
+  if (tid < lora && tid < 512) latent[(size_t)p * lat_stride + (size_t)h * lora + tid] = o_s[tid];
+}
+int launch_hyd_mla_merge(hipStream_t st, const MlaFlashArgs& f, const StepParams* sps, int n_tokens, float* latent, int lat_stride) {
+  if (f.lora > 512 || f.n_chunks > 64 || f.chunk_len != 0) DSK_FAIL(DSK_ERR_UNSUPPORTED, "hyd_mla_merge: kv_lora_rank %d / %d chunks", f.lora, f.n_chunks);
+  hipLaunchKernelGGL(hyd_mla_merge_kernel, dim3(f.n_heads, n_tokens), dim3(1024), 0, st, f.part_ml, f.part_o, f.n_heads, f.lora, f.n_chunks, sps, latent, lat_stride);
+  return DSK_OK;
 }
 // list[h][p] = p * H + h (the rows of head h in the (token, head)-major latent array), count[h] = P: wv_b as one task per head
 __global__ void hyd_head_list_kernel(int* __restrict__ list, int* __restrict__ count, int H, int P, int stride) {

@@ -1012,6 +1012,14 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 #define FL_NWV 8
 __global__ __launch_bounds__(FL_NWV * 64) void mla_flash_kernel(MlaFlashArgs a, const StepParams* __restrict__ sp, int kv_len_override) {
   extern __shared__ __attribute__((aligned(16))) uint8_t fl_smem[];
+  {  // the batched prompt path: token blockIdx.z of the chunk (decode: z = 0, nothing moves)
+    const size_t z = blockIdx.z;
+    sp += z;
+    a.q_c += z * a.tok_qc_stride;
+    a.q_rope += z * a.tok_qr_stride;
+    a.part_o += z * a.n_chunks * a.n_heads * a.lora;
+    a.part_ml += z * a.n_chunks * a.n_heads * 2;
+  }
   unsigned short* Ks = reinterpret_cast<unsigned short*>(fl_smem);                                   // [32][FL_KSTRIDE]
   float (*Sp)[32][FL_PSTRIDE] = reinterpret_cast<float (*)[32][FL_PSTRIDE]>(fl_smem + 32 * FL_KSTRIDE * 2);  // [FL_NWV][32][33]
   float (*Pm)[FL_PSTRIDE] = reinterpret_cast<float (*)[FL_PSTRIDE]>(fl_smem + 32 * FL_KSTRIDE * 2 + FL_NWV * 32 * FL_PSTRIDE * 4);
@@ -1048,7 +1056,7 @@ __global__ __launch_bounds__(FL_NWV * 64) void mla_flash_kernel(MlaFlashArgs a, 
   const int kv_len = kv_len_override > 0 ? kv_len_override : sp->kv_len;
   const int chunk_len = a.chunk_len > 0 ? a.chunk_len : MLA_FL_CHUNK(kv_len, a.n_chunks);
   const int p0 = blockIdx.x * chunk_len;
-  if (p0 >= kv_len) return;  // (uniform; a workgroup past the context drops its Q requests)
+  if (p0 >= kv_len || kv_len < a.min_kv) return;  // (uniform; a workgroup past the context drops its Q requests)
   const int p1 = min(kv_len, p0 + chunk_len);
   // 32 rows x 72 sixteen-byte pieces over 512 threads: 4.5 per thread, all in flight at once; rows past the chunk are zero
   constexpr int per_row = KT / 8, NK = (32 * per_row + FL_NWV * 64 - 1) / (FL_NWV * 64);
@@ -1249,13 +1257,13 @@ __global__ __launch_bounds__(FL_NWV * 64) void mla_flash_kernel(MlaFlashArgs a, 
   }
   if (tl && tid == 0) tl[7] = wall_clock64();
 }
-int launch_mla_flash(hipStream_t st, const MlaFlashArgs& a, const StepParams* sp, int kv_len_override) {
+int launch_mla_flash(hipStream_t st, const MlaFlashArgs& a, const StepParams* sp, int kv_len_override, int n_tokens) {
   if (a.lora != 512 || a.rope != 64) DSK_FAIL(DSK_ERR_UNSUPPORTED, "mla flash attention: kv_lora_rank %d / rope %d (512 / 64 only)", a.lora, a.rope);
   if (a.chunk_len < 0 || a.chunk_len % 32 || a.n_chunks < 1) DSK_FAIL(DSK_ERR_INVALID, "mla flash attention: chunk_len %d", a.chunk_len);
   const size_t lds = 32 * FL_KSTRIDE * 2 + FL_NWV * 32 * FL_PSTRIDE * 4 + 32 * FL_PSTRIDE * 4;
   static bool attr_set = false;
   if (!attr_set) { hipFuncSetAttribute((const void*)mla_flash_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-  hipLaunchKernelGGL(mla_flash_kernel, dim3(a.n_chunks, (a.n_heads + 31) / 32), dim3(FL_NWV * 64), lds, st, a, sp, kv_len_override);
+  hipLaunchKernelGGL(mla_flash_kernel, dim3(a.n_chunks, (a.n_heads + 31) / 32, n_tokens), dim3(FL_NWV * 64), lds, st, a, sp, kv_len_override);
   return DSK_OK;
 }
 

@@ -157,14 +157,16 @@ def test_mha_batches_through_the_split_context_regime(ctx):
     B.close()
 
 
+@pytest.mark.parametrize("level", [2, 1], ids=["tiles-everywhere", "default-layout"])
 @pytest.mark.parametrize("mla", [False, True], ids=["mha", "mla"])
-def test_hydrate_blocks_audited_on_the_oracle(ctx, oracle, mla):
+def test_hydrate_blocks_audited_on_the_oracle(ctx, oracle, mla, level):
     """Not 'batched == own loop' but 'batched == the reference': the golden tiny DeepSeek-V3 Q2_K models (tests/golden, seed 7), a
     37-token prompt through dsk_hydrate, and EVERY block audited on the oracle for ten of the tokens (tests/teacher.py
     HydrateDevice + BlockAuditor: Q8_K codes equal to the oracle's except proven ties, every GEMV / float stage on the device's codes
     within 2e-5 / 1e-4, this position's K / V (latent) cache row against the oracle's arithmetic to the last f16 place, attention over
     the rows the same chunk wrote, route_e identical on the device's router logits).  The classifier row of the call (the last token's
-    logits) goes through the head audit's arithmetic as well."""
+    logits) goes through the head audit's arithmetic as well.  `default-layout`: the engine's default options (planes for decode, tile
+    copies for the batched path - hydrate.cpp hyd_tile_copies) under the same audit."""
     import dsk
     from tests import teacher
     c = synth.preset("tiny_v3", "q2_k", mla)
@@ -174,10 +176,10 @@ def test_hydrate_blocks_audited_on_the_oracle(ctx, oracle, mla):
     aud = teacher.BlockAuditor(oracle, c, T)
     worst, flips, logits = 0.0, 0, None
     for l in range(c.n_layers):
-        M = dsk.Model(ctx, c, T, options={"q2k_tiles": 2, "hydrate_tap_layer": l})
+        M = dsk.Model(ctx, c, T, options={"q2k_tiles": level, "hydrate_tap_layer": l})
         M.set_trace(True)
         lg = M.hydrate(tokens, 0, dsk.MODE_OUTPUT_LOGITS)
-        assert M.info("hydrate_batched_tokens") == len(tokens) and M.info("hydrate_looped_tokens") == 0
+        assert M.info("hydrate_batched_tokens") == len(tokens) and M.info("hydrate_looped_tokens") == 0, M.hydrate_why_not()
         assert logits is None or np.array_equal(lg, logits)  # a tap changes nothing
         logits = lg
         for i in list(range(0, 37, 4)) + [36]:
@@ -191,7 +193,7 @@ def test_hydrate_blocks_audited_on_the_oracle(ctx, oracle, mla):
             flips += Ah.total_flips()
             worst = max(worst, max(Ah.errs.values()))
         M.close()
-    print(f"\n[batched prompt, tiny_v3 q2_k {'mla' if mla else 'mha'}] {c.n_layers} blocks x 11 tokens: worst stage error {worst:.2e}, {flips} proven int8 ties")
+    print(f"\n[batched prompt, tiny_v3 q2_k {'mla' if mla else 'mha'}, q2k_tiles={level}] {c.n_layers} blocks x 11 tokens: worst stage error {worst:.2e}, {flips} proven int8 ties")
     assert worst < teacher.FLOAT_TOL
 
 
@@ -214,13 +216,20 @@ def test_hydrate_across_the_ring_wrap_takes_the_loop_there(ctx):
     B.close()
 
 
-def test_mla_batches_up_to_the_matrix_core_regime(ctx):
-    """MLA at DeepSeek-V3 width: from mla_flash_min_kv (320) cached positions on decode scores on the matrix cores - another
-    association - so dsk_hydrate batches positions below and loops from there; the result is the loop's either way"""
+@pytest.mark.timeout(900)
+def test_mla_batches_through_the_matrix_core_regime(ctx):
+    """MLA at DeepSeek-V3 width: from mla_flash_min_kv (320) cached positions on decode scores on the matrix cores (mla_flash_kernel:
+    chunk partials with an online softmax, merged per head by mla_head_kernel) - another association than the short-context
+    kernel's.  Round 5 sent such positions to the loop; since round 6 the batched path launches decode's own flash kernel over the
+    chunk's long-context tokens (token = third grid dimension, 16 tokens' partials at a time) and merges with the one body both
+    paths share (attn_device.h mla_merge_partials).  Pinned here: a 300-token prompt (short regime only), then 90 tokens whose chunk
+    STRADDLES position 319 (19 short-context tokens + 71 long ones: both kernels in one chunk, more than four flash launches), then
+    a chunk deep inside the regime (positions 700-739 after a jump of the cache contents) - logits and every latent / rope cache row
+    equal to the loop's bit for bit, nothing looped."""
     import dsk
-    c = synth.preset("v3", "q2_k", True, n_layers=2, first_k_dense_replace=1, max_seq_len=352)
-    tokens = [(17 * i + 3) % c.vocab_size for i in range(40)]
+    c = synth.preset("v3", "q2_k", True, n_layers=2, first_k_dense_replace=1, max_seq_len=768)
     pre = [(5 * i + 1) % c.vocab_size for i in range(300)]
+    tokens = [(17 * i + 3) % c.vocab_size for i in range(90)]
     A = dsk.Model(ctx, c, None, synth_seed=13, options={"q2k_tiles": 2})
     B = dsk.Model(ctx, c, None, synth_seed=13, options={"q2k_tiles": 2})
     assert B.hydrate_why_not() == ""
@@ -229,23 +238,39 @@ def test_mla_batches_up_to_the_matrix_core_regime(ctx):
     assert B.info("hydrate_batched_tokens") == 300
     la, _ = _loop(A, tokens, 300)
     lb = B.hydrate(tokens, 300, dsk.MODE_OUTPUT_LOGITS)
-    assert B.info("hydrate_batched_tokens") == 319 and B.info("hydrate_looped_tokens") == 21
+    assert B.info("hydrate_batched_tokens") == 390 and B.info("hydrate_looped_tokens") == 0
     assert np.array_equal(la, lb)
-    for (ka, va), (kb, vb) in zip(_caches(A, c, 340), _caches(B, c, 340)):
+    for (ka, va), (kb, vb) in zip(_caches(A, c, 390), _caches(B, c, 390)):
+        assert np.array_equal(ka, kb) and np.array_equal(va, vb)
+    # deep inside the regime: rows 390-699 of both models filled with the same random f16 rows, then 40 more tokens
+    rng = np.random.default_rng(3)
+    for l in range(c.n_layers):
+        for name, width in (("nope_cache", c.kv_lora_rank), ("rope_cache", c.qk_rope_head_dim)):
+            rows = (0.5 * rng.standard_normal((310, width))).astype(np.float16).view(np.uint16)
+            A.set_cache_rows(l, name, 390, rows)
+            B.set_cache_rows(l, name, 390, rows)
+    more = [(29 * i + 11) % c.vocab_size for i in range(40)]
+    la, _ = _loop(A, more, 700)
+    lb = B.hydrate(more, 700, dsk.MODE_OUTPUT_LOGITS)
+    assert B.info("hydrate_batched_tokens") == 430 and B.info("hydrate_looped_tokens") == 0
+    assert np.array_equal(la, lb)
+    for (ka, va), (kb, vb) in zip(_caches(A, c, 740), _caches(B, c, 740)):
         assert np.array_equal(ka, kb) and np.array_equal(va, vb)
     A.close()
     B.close()
 
 
-@pytest.mark.parametrize("quant,mla,level", [("f8e5m2", False, 2), ("q2_k", True, 1), ("q2_k", False, 1), ("q3_k", False, 2)])
-def test_models_that_do_not_qualify_run_the_loop(ctx, quant, mla, level):
-    """float weights, the default plane layout (MHA and MLA), Q3_K: dsk_hydrate IS the loop there (and says why)"""
+@pytest.mark.parametrize("quant,mla,level,copies", [("f8e5m2", False, 2, 1), ("q2_k", True, 0, 1), ("q2_k", False, 0, 1), ("q2_k", True, 1, 0),
+                                                    ("q2_k", False, 1, 0), ("q3_k", False, 2, 1)])
+def test_models_that_do_not_qualify_run_the_loop(ctx, quant, mla, level, copies):
+    """float weights, planes everywhere (the expert stacks are never copied), the default layout with the tile copies switched off,
+    Q3_K: dsk_hydrate IS the loop there (and says why)"""
     import dsk
     c = synth.preset("tiny_v3", quant, mla)
     T = synth.synth_model(c, seed=47)
     tokens = [3, 99, 512, 7, 1000, 64]
     A = dsk.Model(ctx, c, T, options={"q2k_tiles": level})
-    B = dsk.Model(ctx, c, T, options={"q2k_tiles": level})
+    B = dsk.Model(ctx, c, T, options={"q2k_tiles": level, "hydrate_tile_copies": copies})
     assert B.hydrate_why_not() != ""
     la, _ = _loop(A, tokens, 0)
     lb = B.hydrate(tokens, 0, dsk.MODE_OUTPUT_LOGITS)
@@ -253,6 +278,39 @@ def test_models_that_do_not_qualify_run_the_loop(ctx, quant, mla, level):
     assert np.array_equal(la, lb)
     A.close()
     B.close()
+
+
+@pytest.mark.parametrize("mla", [False, True], ids=["mha", "mla"])
+def test_default_layout_batches_its_prompts(ctx, mla):
+    """The engine's default options (q2k_tiles = 1): decode multiplies planes, the batched path tile-record copies of the same
+    weights (made when the first prompt arrives) - two float associations of the same integers, so the prompt's cache rows are the
+    loop's within rounding, not bit for bit (that statement holds at q2k_tiles = 2; the oracle audit above holds at both levels).
+    What this test pins: the call batches and the copies exist; the batched path on copies IS the batched path on stored tile
+    records (cache rows of a level-2 model's dsk_hydrate: equal to an f16 place); block 0's K / V rows - upstream of every router -
+    agree with the loop's to 2e-3 of their range; the last token's logits stay inside the K-quant free-running guard (5e-2 of their
+    range: a random 3-block model amplifies a last-bit difference by ~100 per block, tests/test_teacher_forced_gpu.py says why)."""
+    import dsk
+    c = synth.preset("tiny_v3", "q2_k", mla)
+    T = synth.synth_model(c, seed=61)
+    tokens = [int(t) for t in np.random.default_rng(5).integers(0, c.vocab_size, 29)]
+    A, B, C2 = dsk.Model(ctx, c, T), dsk.Model(ctx, c, T), dsk.Model(ctx, c, T, options={"q2k_tiles": 2})
+    assert B.hydrate_why_not() == ""
+    la, _ = _loop(A, tokens, 0)
+    lb = B.hydrate(tokens, 0, dsk.MODE_OUTPUT_LOGITS)
+    C2.hydrate(tokens, 0, dsk.MODE_OUTPUT_LOGITS)
+    assert B.info("hydrate_batched_tokens") == len(tokens) and B.info("hydrate_looped_tokens") == 0
+    assert B.info("hydrate_tile_copy_mb") >= 0 and A.info("hydrate_tile_copy_mb") == 0 and C2.info("hydrate_tile_copy_mb") == 0
+    assert float(np.max(np.abs(la - lb))) < 5e-2 * float(np.max(np.abs(la)))
+
+    def rel(a, b):
+        a32, b32 = a.view(np.float16).astype(np.float32), b.view(np.float16).astype(np.float32)
+        return float(np.max(np.abs(a32 - b32))) / max(1e-6, float(np.max(np.abs(a32))))
+    ca, cb, cc = _caches(A, c, len(tokens)), _caches(B, c, len(tokens)), _caches(C2, c, len(tokens))
+    assert rel(ca[0][0], cb[0][0]) < 2e-3 and rel(ca[0][1], cb[0][1]) < 2e-3
+    for (kb, vb), (kc, vc) in zip(cb, cc):
+        assert rel(kb, kc) < 2e-3 and rel(vb, vc) < 2e-3
+    for M in (A, B, C2):
+        M.close()
 
 
 def test_hydrate_then_decode_continues_the_same_stream(ctx):

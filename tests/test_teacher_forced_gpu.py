@@ -130,14 +130,18 @@ def test_v3_full_width_256_experts_teacher_forced(ctx, oracle, mla, quant, tiles
 
 
 @pytest.mark.timeout(1500)
+@pytest.mark.parametrize("level", [2, 1], ids=["tiles-everywhere", "default-layout"])
 @pytest.mark.parametrize("mla", [False, True], ids=["mha", "mla"])
-def test_v3_full_width_batched_prompt_audited_on_the_oracle(ctx, oracle, mla):
+def test_v3_full_width_batched_prompt_audited_on_the_oracle(ctx, oracle, mla, level):
     """The batched prompt path (dsk_hydrate, src/main.cpp:312-319 as GEMMs) against the ORACLE at full DeepSeek-V3 width
     (256 experts, 128 heads, 1 dense + 1 MoE block), not against the engine's own loop: a 37-token prompt in one chunk, then for
     the first, a middle and the last token every stage of every block goes through the same audit as the per-token block
     (teacher.HydrateDevice: codes = the oracle's except proven ties, integer GEMVs and float stages on the device's codes within
     2e-5 / 1e-4, the position's K/V (latent) cache row to the last f16 place, attention over the rows the SAME chunk wrote,
-    expert indices identical on the device's router logits, the k-ordered combine within 2e-6)."""
+    expert indices identical on the device's router logits, the k-ordered combine within 2e-6).
+    `default-layout` (round 6): the engine's DEFAULT options - decode keeps every matrix but the experts' as planes, the batched
+    path multiplies tile-record copies made when the first prompt arrives (option "hydrate_tile_copies") - held to the same audit:
+    the model bench.py times is a model that batches its prompts."""
     import dsk
     c, T = _v3_full_width(mla, seed=33)
     emb = T["model.embed.weight"]
@@ -145,17 +149,54 @@ def test_v3_full_width_batched_prompt_audited_on_the_oracle(ctx, oracle, mla):
     aud = teacher.BlockAuditor(oracle, c, T)
     worst, flips = 0.0, 0
     for l in range(c.n_layers):
-        M = dsk.Model(ctx, c, T, options={"q2k_tiles": 2, "hydrate_tap_layer": l})
+        M = dsk.Model(ctx, c, T, options={"q2k_tiles": level, "hydrate_tap_layer": l})
         assert M.hydrate_why_not() == ""
         M.set_trace(True)
         M.hydrate(tokens, 0, dsk.MODE_HYDRATE_KV_CACHE)
         assert M.info("hydrate_batched_tokens") == len(tokens) and M.info("hydrate_looped_tokens") == 0
+        assert (M.info("hydrate_tile_copy_mb") > 0) == (level == 1)
         for i in (0, 18, 36):
             x_in = oracle.embed_row(emb.quant, emb.data, c.dim, tokens[i]) if l == 0 else M.hydrate_trace_x(l - 1, i)
             A, _ = aud.run(teacher.HydrateDevice(M, c, l, i), l, x_in, i)
             flips += A.total_flips()
             worst = max(worst, max(A.errs.values()))
-            print(f"\n[v3 {'mla' if mla else 'mha'} batched prompt, block {l}, token {i}] {A.summary()}")
+            print(f"\n[v3 {'mla' if mla else 'mha'} batched prompt, q2k_tiles={level}, block {l}, token {i}] {A.summary()}")
+        M.close()
+    assert worst < teacher.FLOAT_TOL
+
+
+@pytest.mark.timeout(1500)
+def test_v3_full_width_batched_prompt_in_the_mla_matrix_core_regime_audited_on_the_oracle(ctx, oracle):
+    """Round 6: dsk_hydrate batches MLA tokens whose context has reached mla_flash_min_kv (320) - decode's mla_flash_kernel over the
+    chunk's tokens + the per-head merge (hydrate.cpp hyd_layer).  Oracle-side, at full DeepSeek-V3 width: caches pre-filled with 400
+    random f16 rows per block, a 24-token chunk at positions 400-423 (every token in the matrix-core regime; two flash launches), and
+    for the first, a middle and the last token of the chunk every stage of every block through the block audit - this position's
+    latent / rope row to the last f16 place, latent_out against the oracle's attn_mla (src/infer.cpp:766-804) over the 401-424 rows
+    the device holds, the Q8_K of it, wv_b, wo, router, experts."""
+    import dsk
+    c, T = _v3_full_width(True, seed=41)
+    c.max_seq_len = 512
+    emb = T["model.embed.weight"]
+    tokens = [int(t) for t in np.random.default_rng(4).integers(0, c.vocab_size, 24)]
+    aud = teacher.BlockAuditor(oracle, c, T)
+    lora, rope = c.kv_lora_rank, c.qk_rope_head_dim
+    worst, flips = 0.0, 0
+    for l in range(c.n_layers):
+        M = dsk.Model(ctx, c, T, options={"hydrate_tap_layer": l})
+        rng = np.random.default_rng(78)
+        for ll in range(c.n_layers):
+            M.set_cache_rows(ll, "nope_cache", 0, _f16_bits(rng.standard_normal((400, lora))))
+            M.set_cache_rows(ll, "rope_cache", 0, _f16_bits(rng.standard_normal((400, rope))))
+        assert M.hydrate_why_not() == ""
+        M.set_trace(True)
+        M.hydrate(tokens, 400, dsk.MODE_HYDRATE_KV_CACHE)
+        assert M.info("hydrate_batched_tokens") == len(tokens) and M.info("hydrate_looped_tokens") == 0
+        for i in (0, 11, 23):
+            x_in = oracle.embed_row(emb.quant, emb.data, c.dim, tokens[i]) if l == 0 else M.hydrate_trace_x(l - 1, i)
+            A, _ = aud.run(teacher.HydrateDevice(M, c, l, i), l, x_in, 400 + i)
+            flips += A.total_flips()
+            worst = max(worst, max(A.errs.values()))
+            print(f"\n[v3 mla batched prompt at pos {400 + i}, block {l}] latent_out {A.errs['latent_out']:.2e}; {A.summary()}")
         M.close()
     assert worst < teacher.FLOAT_TOL
 

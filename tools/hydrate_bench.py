@@ -1,8 +1,9 @@
-"""Prompt ingestion rate of dsk_hydrate on the full DeepSeek-V3 Q2_K model (61 blocks, 256 experts, tile records everywhere),
-next to the single-token rate of the same model: what the batched path buys over the reference's one forward per prompt token
+"""Prompt ingestion rate of dsk_hydrate on the full DeepSeek-V3 Q2_K model (61 blocks, 256 experts; the engine's DEFAULT options
+since round 6: the layout bench.py times for decode, the batched path on tile copies of the plane matrices), next to the
+single-token rate of the same model: what the batched path buys over the reference's one forward per prompt token
 (src/main.cpp:312-319).
 
-  python tools/hydrate_bench.py [--P 16,64,128] [--layers 0] [--reps 2]
+  python tools/hydrate_bench.py [--P 16,64,128] [--layers 0] [--reps 2] [--attn mla] [--pos0 N] [--opt q2k_tiles=2]
 """
 import argparse
 import json
@@ -18,9 +19,9 @@ for p in (ROOT, os.path.join(ROOT, "deepseek.cpp_amd")):
         sys.path.insert(0, p)
 
 
-def measure(ctx, c, Ps, reps=2, seed=0, chunk=0, opts=None, loop=True):
+def measure(ctx, c, Ps, reps=2, seed=0, chunk=0, opts=None, loop=True, pos0=0):
     import dsk
-    o = {"q2k_tiles": 2}
+    o = {}
     if chunk:
         o["hydrate_chunk"] = chunk  # (0: the engine's default)
     o.update(opts or {})
@@ -42,11 +43,11 @@ def measure(ctx, c, Ps, reps=2, seed=0, chunk=0, opts=None, loop=True):
     res = {}
     for P in Ps:
         toks = rng.integers(0, c.vocab_size, P)
-        M.hydrate(toks, 0, dsk.MODE_HYDRATE_KV_CACHE)  # warm-up (allocations, code objects)
+        M.hydrate(toks, pos0, dsk.MODE_HYDRATE_KV_CACHE)  # warm-up (allocations, tile copies, code objects)
         best = 1e9
         for _ in range(reps):
             t0 = time.perf_counter()
-            M.hydrate(toks, 0, dsk.MODE_HYDRATE_KV_CACHE)
+            M.hydrate(toks, pos0, dsk.MODE_HYDRATE_KV_CACHE)
             best = min(best, time.perf_counter() - t0)
         res[str(P)] = {"ms": round(best * 1e3, 3), "tok_s": round(P / best, 1), "x_loop": round(P / best * dt, 2) if dt else None}
     out["hydrate"] = res
@@ -60,6 +61,10 @@ def measure(ctx, c, Ps, reps=2, seed=0, chunk=0, opts=None, loop=True):
     except Exception as e:  # noqa: BLE001
         out["last_chunk_experts"] = {"error": repr(e)[:80]}
     out["batched_tokens"] = M.info("hydrate_batched_tokens")
+    out["looped_tokens"] = M.info("hydrate_looped_tokens")
+    out["q2k_tiles"] = o.get("q2k_tiles", 1)
+    out["tile_copy_mb"] = M.info("hydrate_tile_copy_mb")
+    out["pos0"] = pos0
     M.close()
     return out
 
@@ -75,6 +80,7 @@ def main():
     ap.add_argument("--opt", action="append", default=[])
     ap.add_argument("--no-loop", action="store_true", help="skip the per-token loop (a kernel trace of the batched path only)")
     ap.add_argument("--attn", default="mha", choices=["mha", "mla"])
+    ap.add_argument("--pos0", type=int, default=0, help="first position of the timed prompt (rows below it: whatever the cache holds)")
     a = ap.parse_args()
     c = synth.preset("v3", "q2_k", a.attn == "mla")
     if a.layers:
@@ -83,7 +89,7 @@ def main():
     c.max_seq_len = 1100
     ctx = dsk.Ctx(0)
     opts = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.opt}
-    print(json.dumps(measure(ctx, c, [int(p) for p in a.P.split(",")], a.reps, chunk=a.chunk, opts=opts, loop=not a.no_loop)))
+    print(json.dumps(measure(ctx, c, [int(p) for p in a.P.split(",")], a.reps, chunk=a.chunk, opts=opts, loop=not a.no_loop, pos0=a.pos0)))
 
 
 if __name__ == "__main__":
