@@ -209,11 +209,19 @@ int dsk_model_destroy(dsk_model* m);
  *                        0 planes for the dot4 kernels; 1 the routed and shared experts' matrices as 16-row x 256-column tile
  *                        records (1344 B) whose sub-block dots run on v_mfma_i32_16x16x64_i8; 2 every role that has a tiled
  *                        kernel.  Same integer arithmetic at every level (src/quant.cpp:666-783), a different f32 association of
- *                        the block sums; the caller's bytes are reference-format blocks at every level */
+ *                        the block sums; the caller's bytes are reference-format blocks at every level
+ *   "hydrate_chunk"   512  tokens per batched chunk of dsk_hydrate (1 .. 1024)
+ *   "hydrate_batched" 1  0: dsk_hydrate always runs the per-token loop
+ *   "hydrate_tile_copies" 1  at "q2k_tiles" = 1 the first batched dsk_hydrate call may copy the plane-layout matrices it multiplies
+ *                        into tile records (0: no copies - such a model then runs the loop)
+ *   "hydrate_tap_layer" -1  parity harness: copy block l's stages of every batched chunk aside for dsk_hydrate_get_buffer
+ *   "moe_pipe"        0  experimental schedules of the fused expert launch (1: slot halves with service waves, 2: staged second
+ *                        half; bit-identical to 0 and slower on MI355X: EXPERIMENTS.md 6.1-6.2) */
 int dsk_model_set_option(dsk_model* m, const char* key, int value);
 /* Read-only counters: "handoff_fallbacks" (times a hand-off give-up moved the model to the two-launch form; the token
  * that hit it was re-run transparently), "fused_moe_layers", "graph_captured", "exchange_calls" (RCCL collectives this
- * model has enqueued eagerly), "tiled_tensors" (weight tensors held as tile records, option "q2k_tiles"). */
+ * model has enqueued eagerly), "tiled_tensors" (weight tensors held as tile records, option "q2k_tiles"),
+ * "hydrate_batched_tokens" / "hydrate_looped_tokens", "hydrate_tile_copy_mb" (MiB of tile copies the batched prompt path holds). */
 int dsk_model_get_info(dsk_model* m, const char* key, int* value);
 /* models created on the context and not yet destroyed (a context destroyed while models are alive is freed by the last
  * dsk_model_destroy) */
@@ -239,7 +247,7 @@ int dsk_dseek_read_config(const char* dir, int context, dsk_config* out, int32_t
 /* create + bind every tensor + finalize.  `stats` may be NULL. */
 int dsk_model_load_dseek(dsk_ctx* ctx, const char* dir, int context, dsk_model** out, dsk_load_stats* stats);
 /* ... with model options applied between create and the first bind: "key=value,key=value" (dsk_model_set_option keys),
- * e.g. "q2k_tiles=2" so that prompts take dsk_hydrate's batched path.  options may be NULL. */
+ * e.g. "q2k_tiles=2" (every Q2_K matrix as tile records: dsk_hydrate bit-identical to the per-token loop).  options may be NULL. */
 int dsk_model_load_dseek_opts(dsk_ctx* ctx, const char* dir, int context, const char* options, dsk_model** out, dsk_load_stats* stats);
 
 /* ---- the hot path (replaces Model::forward, src/model.cpp:874-883) -------- */
@@ -252,11 +260,18 @@ int dsk_forward(dsk_model* m, int token, int pos, int mode, float* host_logits);
  *     for i < n_tokens - 1:  dsk_forward(m, tokens[i], pos0 + i, DSK_MODE_HYDRATE_KV_CACHE, NULL)
  *     dsk_forward(m, tokens[n_tokens - 1], pos0 + n_tokens - 1, mode, host_logits)
  * and runs it as batched launches - every weight matrix read once per chunk of up to "hydrate_chunk" tokens (option,
- * default 512), the Q2_K row products as i8 GEMMs on the matrix pipe - when the model qualifies: Q2_K weights stored as tile
- * records (option "q2k_tiles" = 2 before binding), MHA or MLA attention with a q latent (MLA: positions below 319), one GPU, and positions below the ring
- * wrap (rs_original_max_position_embeddings).  KV-cache rows, routing and logits are then BIT-identical to the loop
- * (tests/test_hydrate_gpu.py).  Anything else - other models, the tokens at and past the wrap - runs the loop itself, so
- * the call is always valid.  dsk_hydrate_why_not: "" when the batched path applies to this model, else the reason.
+ * default 512), the Q2_K row products as i8 GEMMs on the matrix pipe - when the model qualifies: Q2_K weights with the experts'
+ * matrices stored as tile records (option "q2k_tiles" >= 1: the default), MHA or MLA attention with a q latent, one GPU, and
+ * positions below the ring wrap (rs_original_max_position_embeddings).
+ *   "q2k_tiles" = 2 (every matrix as tile records): KV-cache rows, routing and logits are BIT-identical to the loop
+ *       (tests/test_hydrate_gpu.py), at every context length below the wrap.
+ *   "q2k_tiles" = 1 (default): the first batched call makes tile-record copies of the plane-layout matrices it multiplies (~4-5 GB
+ *       for DeepSeek-V3; option "hydrate_tile_copies" = 0 refuses them and the call runs the loop; get_info "hydrate_tile_copy_mb")
+ *       and runs the same kernels on them: the rows are the "q2k_tiles" = 2 engine's, and the default engine's loop within the float
+ *       association of its plane kernels - audited against the reference's arithmetic block by block like decode
+ *       (tests/test_teacher_forced_gpu.py), not bit-identical to a loop that associates differently.
+ * Anything else - other models, the tokens at and past the wrap, no room for buffers or copies - runs the loop itself, so the call
+ * is always valid.  dsk_hydrate_why_not: "" when the batched path applies to this model, else the reason.
  * dsk_model_get_info "hydrate_batched_tokens" / "hydrate_looped_tokens" count what ran where. */
 int dsk_hydrate(dsk_model* m, const int32_t* tokens, int n_tokens, int pos0, int mode, float* host_logits);
 const char* dsk_hydrate_why_not(dsk_model* m);

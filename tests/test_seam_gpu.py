@@ -75,14 +75,14 @@ def _kquant_text_against_the_oracle(ctx, oracle, c, T, out_cpu, out_hip, t_cpu, 
     ids = _prompt_ids(out_cpu)
     assert ids == _prompt_ids(out_hip) and ids[0] == 0 and len(ids) > 8
     vocab = synth.synthetic_vocab(c.vocab_size)
-    M, O = dsk.Model(ctx, c, T, options={"q2k_tiles": 2}), oracle.model(c, T)  # (the options the patched main loads with)
+    M, O = dsk.Model(ctx, c, T), oracle.model(c, T)  # (the engine's defaults: what the patched main's completion run loads with)
     lg_hip = M.hydrate(ids, 0, dsk.MODE_OUTPUT_LOGITS)
-    assert M.info("hydrate_batched_tokens") == len(ids)
+    assert M.info("hydrate_batched_tokens") == len(ids), M.hydrate_why_not()
     lo = None
     aud = teacher.BlockAuditor(oracle, c, T)
     emb = T["model.embed.weight"]
     flips = 0
-    M2 = dsk.Model(ctx, c, T, options={"q2k_tiles": 2})
+    M2 = dsk.Model(ctx, c, T)
     for pos, tok in enumerate(ids):  # the oracle's stream, and the audit of every block of the prompt on it
         lo = O.forward(tok, pos)
         x = oracle.embed_row(emb.quant, emb.data, c.dim, tok)
@@ -108,7 +108,8 @@ def _kquant_text_against_the_oracle(ctx, oracle, c, T, out_cpu, out_hip, t_cpu, 
         m.close()
 
 
-# (the Q2_K MHA case: the patched main loads with "q2k_tiles=2" and hands the whole prompt to dsk_hydrate - the batched path)
+# (the Q2_K cases: the patched main hands the whole prompt to dsk_hydrate - the batched path, at the engine's default layout in the
+# completion run and with DSK_HIP_OPTS=q2k_tiles=2 in the perplexity run)
 CASES = [("tiny_v3", "fp16", False), ("tiny_v3", "f8e5m2", True), ("tiny_v2lite", "fp32", False), ("tiny_v3", "q2_k", True), ("tiny_v3", "q2_k", False)]
 
 
@@ -126,10 +127,9 @@ def test_reference_main_with_device_hip_matches_reference_main(ctx, oracle, pres
         assert n_cpu == n_hip and n_cpu > 20
         rel = abs(ppl_hip - ppl_cpu) / ppl_cpu
         out_cpu = _run(MAIN, d, "-m", "completion", "-t", "0", "-n", "32", "-i", TEXT[:40])
-        # (DSK_HIP_OPTS: the host application's choice of engine options - Q2_K matrices as tile records, so that the prompt takes
-        # dsk_hydrate's batched path; without it the engine's defaults apply: the faster decode layout, prompts token by token)
-        tiles = {"DSK_HIP_OPTS": "q2k_tiles=2"}
-        out_hip = _run(MAIN_HIP, d, "-m", "completion", "-t", "0", "-n", "32", "-i", TEXT[:40], "-d", "hip", env_extra=tiles)
+        # (DSK_HIP_OPTS is the host application's way to pass engine options - above: every Q2_K matrix as tile records; here none:
+        # the engine's defaults, i.e. the faster decode layout, whose prompts dsk_hydrate batches on tile copies since round 6)
+        out_hip = _run(MAIN_HIP, d, "-m", "completion", "-t", "0", "-n", "32", "-i", TEXT[:40], "-d", "hip")
         (t_cpu, k_cpu), (t_hip, k_hip) = _completion(out_cpu), _completion(out_hip)
         assert k_cpu == k_hip
         if quant in ("q2_k", "q3_k"):
