@@ -140,6 +140,7 @@ struct GemvLaunch {
   int NW;                     // waves per workgroup (4 or 16)
   int part_unit;              // rows are dealt to workgroups in multiples of this
   int force_lpr, force_R, force_U, force_NW;  // > 0: override the planner (micro-benchmarks)
+  int ahead;             // the caller allows gemv_ahead_kernel (kernels_gemv.hip: weights requested ahead of the staging) where the plan fits it
   int reserve_wgs;       // 16-wave workgroups of the same launch that are NOT this plan's (the MLA latent's cache-write rider): the plan
                          // takes that many fewer, so that every workgroup of the launch is resident at once - a workgroup behind the
                          // 256th starts when the first one leaves (kvwrite: 13.2 us = the GEMV's 10.7 + the rider's 3.6 behind it)

@@ -263,6 +263,7 @@ extern "C" int dsk_model_set_option(dsk_model* m, const char* key, int value) {
   else if (k == "moe_spin_limit") m->moe_spin_limit = value;
   else if (k == "moe_q8_handoff") m->moe_q8_handoff = value != 0;
   else if (k == "moe_pipe") m->moe_pipe = value;
+  else if (k == "gemv_ahead") m->gemv_ahead = value & 3;
   else if (k == "tail_prefetch") m->tail_prefetch = value;
   else if (k == "fuse_moe_float") m->fuse_moe_float = value != 0;
   else if (k == "force_exchange") m->force_exchange = value != 0;

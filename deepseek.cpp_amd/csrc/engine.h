@@ -150,6 +150,7 @@ struct dsk_model {
                                     // uniformly drawn experts - a measurement of balanced routing; the shipped library has no way to set it
   int hydrate_tap_layer = -1;       // option "hydrate_tap_layer" (parity harness): the block whose intermediates a batched chunk copies aside for
                                     // dsk_hydrate_get_buffer; the chunk itself runs unchanged
+  int gemv_ahead = 3;               // option "gemv_ahead" (bits): 1 the first-stage projection launch, 2 wo request weights ahead of the staging of their vector (round 6, kernels_gemv.hip)
   bool hydrate_batched = true;      // option "hydrate_batched": 0 = dsk_hydrate always runs the per-token loop
   bool hydrate_tile_copies = true;  // option "hydrate_tile_copies": the batched path may keep tile-record copies of the plane-layout Q2_K matrices (hydrate.cpp)
   double hydrate_tile_copy_bytes = 0;  // bytes of those copies (made by the first batched dsk_hydrate call)

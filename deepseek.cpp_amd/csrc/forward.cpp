@@ -169,6 +169,7 @@ int build_plans(dsk_model* m) {
       b.out = m->kv_a;
       h.algo_bytes = weight_bytes_2d(m, wq, a.rows, a.n) + weight_bytes_2d(m, wq, b.rows, b.n) + c.dim * 8.0 + 4.0 * (a.rows + b.rows);
       h.timeline = m->timeline_of(0);
+      h.ahead = m->gemv_ahead & 1;  // option "gemv_ahead": the workgroup's weights requested ahead of the staging of x (kernels_gemv.hip gemv_ahead_kernel)
       DSK_TRY(add_plan(m, h, &m->lp_qkv_a[l]));
     }
     {  // 2. second-stage projections on the normed latents
@@ -265,6 +266,7 @@ int build_plans(dsk_model* m) {
       T.out = m->x; T.epilogue = EPI_ADD;
       h.algo_bytes = weight_bytes_2d(m, wq, T.rows, T.n) + io_bytes(wq, T.n, T.rows) + 4.0 * T.rows;
       h.timeline = m->timeline_of(2);
+      h.ahead = m->gemv_ahead & 2;  // (gemv_ahead_q8_kernel: the first row group's first half requested ahead of the vector's copy into LDS)
       DSK_TRY(add_plan(m, h, &m->lp_wo[l]));
     }
     if (!L.is_moe) {

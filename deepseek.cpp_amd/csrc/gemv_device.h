@@ -545,6 +545,13 @@ DEV rsrc_t make_rsrc(const void* p) {
   const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
   return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, -1, 0x00020000);
 }
+// ... or, for a wave that has nothing to read there, a descriptor of zero records: every load returns zeros without touching memory
+DEV rsrc_t make_rsrc_n(const void* p, bool live) {
+  const unsigned long long v = (unsigned long long)p;
+  const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
+  const u32 nrec = __builtin_amdgcn_readfirstlane(live ? 0xffffffffu : 0u);  // (wave-uniform by construction, like the base)
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, (int)nrec, 0x00020000);
+}
 #define BUF_NT 2  // streaming data: non-temporal
 struct KQRsrc {
   rsrc_t qs, sc, hm, dm, qs2, sc2, hm2, dm2;

@@ -280,6 +280,249 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(const GemvLaunch* __restr
   gemv_body<QT, R, U, GLU, NW>(Lp, h_a0, h_a1, h_a2, h_n, h_mode, h_eps, h_gwgs, h_gstride, (int)blockIdx.x, 0.f);
 }
 
+
+// ------------------------------------------------------------------------------------
+// Round 6: a small plain Q2_K launch whose every workgroup stages the SAME rmsnorm'ed vector (the first-stage projections: wq_a and
+// wkv_a, 2112 rows of 7168 over 256 workgroups = 19 KB of weights each) with ALL of a workgroup's weights requested AHEAD of the
+// staging.  Round 1 measured that as slower twice - the requests left BEFORE the loads of x (a CU returns its vector memory
+// operations in order: x queued behind 19 KB from HBM), and the staging's barriers were fences (`__syncthreads()` waits for every
+// outstanding load, i.e. for the weights).  Here the order is: x and the norm weights first, then the descriptor (warm in L2: the
+// previous launch's spare workgroups read it), then the weights - at most two (task, row group) pairs per wave - then the staging
+// with LDS-only barriers (gemv_device.h lds_barrier), then the multiplies on registers that have been travelling since entry.
+// Same device functions, same column-step order, same lane trees as gemv_body: same bits.  The planner selects it (GemvLaunch::
+// ahead) for one activation group of <= 2 plain tasks, rows of <= 2 column steps, a share of <= one row group per workgroup.
+// ------------------------------------------------------------------------------------
+// (Straight-line on purpose: row length and lanes per row are template constants and a (task, row group) pair that does not exist
+// for a wave reads through a NULL buffer descriptor - zeros, no memory traffic - instead of being branched around.  With a load
+// inside a branch hipcc's waitcnt pass must assume either path at the join and waits for EVERYTHING before x is touched.)
+template <int ITEMS, int LL>
+__global__ __launch_bounds__(1024) void gemv_ahead_kernel(const GemvLaunch* __restrict__ Lp, const float* __restrict__ x, const float* __restrict__ norm_w,
+                                                         float eps) {
+  constexpr int QT = DSK_QUANT_Q2_K, NW = 16, KB1 = 32 / NW, nb = ITEMS / 4, n = nb * 256, ITS = (ITEMS + (1 << LL) - 1) >> LL;
+  constexpr int RPW = 64 >> LL;
+  static_assert(ITS <= 2 && nb <= 32, "gemv_ahead_kernel: rows of at most two column steps");
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ float scratch[16];
+  const GemvLaunch& L = *Lp;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, bid = blockIdx.x;
+  const unsigned long long t_entry = wall_clock64();
+  // ---- 1. this wave's blocks of x and of the norm weights (stage_q8's single-pass path, first half) ----
+  f32x4 t[KB1], wv[KB1];
+#pragma unroll
+  for (int k = 0; k < KB1; ++k) {
+    const int b = wave + NW * k < nb ? wave + NW * k : nb - 1;  // (a wave without a k-th block re-reads the last one and drops it)
+    t[k] = *reinterpret_cast<const f32x4*>(x + b * 256 + lane * 4);
+    wv[k] = *reinterpret_cast<const f32x4*>(norm_w + b * 256 + lane * 4);
+  }
+  // ---- 2. the descriptor, this workgroup's share, and the weights of (at most) two (task, row group) pairs ----
+  const int rloc = lane >> LL, sub = lane & ((1 << LL) - 1), q = sub & 3;
+  unsigned long long* tl = L.timeline && bid < DSK_TL_WGS ? L.timeline + (size_t)bid * 8 : nullptr;
+  // (the stamps are kept in registers and stored at the end: a store in flight makes hipcc wait for every outstanding operation at
+  // the next use of a loaded register - it would wait for the weights before it touched x)
+  unsigned long long t_staged = 0, t_bar = 0, t_rows = 0;
+  const int n_tasks = L.grp_t0[1], nwg = L.grp_wg_end[0];
+  const int vtotal = L.t[n_tasks - 1].vrow_end, unit = L.part_unit;
+  // (gemv_body's partition in 32-bit arithmetic: units * workgroups < 2^31 for a launch this small, so the quotients are the same)
+  const unsigned units = (unsigned)((vtotal + unit - 1) / unit);
+  const int r_lo = __builtin_amdgcn_readfirstlane((int)(units * (unsigned)bid / (unsigned)nwg) * unit);
+  int r_hi = __builtin_amdgcn_readfirstlane((int)(units * (unsigned)(bid + 1) / (unsigned)nwg) * unit);
+  if (r_hi > vtotal) r_hi = vtotal;
+  ChunkKQ<QT, 1, 2, false> ch[2];
+  int p_row[2];
+  bool p_valid[2];
+  float* p_out[2];
+  int p_epi[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const GemvTask& T = L.t[j < n_tasks ? j : 0];
+    const int vb = T.vrow_begin, ve = T.vrow_end;
+    const int lo = (r_lo > vb ? r_lo : vb) - vb, hi = (r_hi < ve ? r_hi : ve) - vb;
+    // (the planner guarantees hi - lo <= RG: one row group per task and workgroup)
+    const int row0 = lo + wave * RPW, rr = row0 + rloc;
+    const bool has = j < n_tasks && row0 < hi;  // wave-uniform
+    p_valid[j] = has && rr < hi;
+    p_row[j] = p_valid[j] ? rr : (hi > 0 ? hi - 1 : 0);
+    p_out[j] = T.out;
+    p_epi[j] = T.epilogue;
+    KQRsrc B;
+    B.qs = make_rsrc_n(T.qs, has);
+    B.sc = make_rsrc_n(T.sc, has);
+    B.dm = make_rsrc_n(T.dm, has);
+    B.hm = B.qs2 = B.sc2 = B.dm2 = B.hm2 = B.qs;
+    const int rowblk[1] = {has ? p_row[j] * nb + (sub >> 2) : 0};
+    load_chunk_kq<QT, 1, 2, false>(ch[j], B, ITS, ITEMS, sub, LL, q, rowblk, 0);
+  }
+  // ---- 3. rmsnorm (src/infer.cpp:601-611) + Q8_K of x into LDS: stage_q8's single-pass path, second half, LDS-only barriers ----
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < KB1; ++k) {
+    if (wave + NW * k < nb) {
+      ss = fmaf(t[k].x, t[k].x, ss);
+      ss = fmaf(t[k].y, t[k].y, ss);
+      ss = fmaf(t[k].z, t[k].z, ss);
+      ss = fmaf(t[k].w, t[k].w, ss);
+    }
+  }
+  ss = wave_sum(ss);
+  if (lane == 0) scratch[wave] = ss;
+  lds_barrier();
+  const float total = scratch_total<NW>(scratch);
+  const float scale = 1.0f / sqrtf(total / (float)n + eps);
+#pragma unroll
+  for (int k = 0; k < KB1; ++k) {
+    const int b = wave + NW * k;
+    if (b < nb) {
+      float v[4] = {t[k].x * scale * wv[k].x, t[k].y * scale * wv[k].y, t[k].z * scale * wv[k].z, t[k].w * scale * wv[k].w};
+      q8k_block_lds<LAY_Q2>(v, lane, smem + (size_t)b * 4 * ITEM_LDS);
+    }
+  }
+  if (tl) t_staged = wall_clock64();
+  lds_barrier();
+  if (tl) t_bar = wall_clock64();
+#ifndef DSK_NO_TAPS
+  if (L.tap_qs && bid == 0) {  // parity tap: what this launch staged (taps are armed for eager block runs only)
+    dump_staged_q8<LAY_Q2>(smem, n, L.tap_qs, L.tap_d, tid, NW * 64);
+  }
+#endif
+  // ---- 4. the multiplies (registers requested in 2.), the lane tree, the store ----
+  const uint8_t* lds_lane = smem + sub * ITEM_LDS;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float acc[1] = {0.f}, acc2[1] = {0.f};
+    compute_chunk_kq<QT, 1, 2, false>(ch[j], ITS, ITEMS, sub, LL, q, 0, lds_lane, acc, acc2);
+    const float r = lanes_sum(acc[0], LL);
+    if (tl && j == 0) t_rows = wall_clock64();
+    if (p_valid[j] && sub == 0) {
+      float* o = p_out[j] + p_row[j];
+      if (p_epi[j] == EPI_ADD) *o += r;  // residual add, src/infer.cpp:832-834
+      else *o = r;
+    }
+  }
+  if (tl && tid == 0) {
+    tl[0] = t_entry; tl[6] = t_staged; tl[7] = tl[1] = t_bar; tl[2] = t_rows; tl[3] = wall_clock64();
+  }
+}
+// The same for a plain one-task launch on a READY Q8_K vector with rows of four column steps (wo: 7168 rows of 16384 over 256
+// workgroups = two row groups of 16 each): the first row group's first two steps (43 KB per workgroup: what a CU keeps in flight)
+// leave behind the loads of the vector and ahead of its copy into LDS records; the second half of the group is requested when the
+// records are in place, the remaining groups go through rows_dot_kq_exact like before.  Column steps in order: same bits.
+template <int ITEMS, int LL>
+__global__ __launch_bounds__(1024) void gemv_ahead_q8_kernel(const GemvLaunch* __restrict__ Lp, const int8_t* __restrict__ a_qs, const float* __restrict__ a_d,
+                                                            const int16_t* __restrict__ a_bsums) {
+  constexpr int QT = DSK_QUANT_Q2_K, NW = 16, nb = ITEMS / 4, n = nb * 256, ITS = ITEMS >> LL, RPW = 64 >> LL, RG = NW * RPW;
+  static_assert(ITS == 4 && (ITEMS & ((1 << LL) - 1)) == 0 && (n >> 4) <= NW * 64, "gemv_ahead_q8_kernel: four exact column steps, one 16-byte run per thread");
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const GemvLaunch& L = *Lp;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, bid = blockIdx.x;
+  const unsigned long long t_entry = wall_clock64();
+  // ---- 1. the vector: one 16-byte run (a sub-block), its sum, and for the first nb * 4 threads a block scale ----
+  // (every thread loads its block's scale and every thread stores it: the four sub-block threads of a record write the same two
+  // floats.  A load whose only use sits in a branch is sunk INTO the branch by hipcc, behind the weights' requests)
+  const int ri = tid < (n >> 4) ? tid : 0;
+  const u32x4 run = reinterpret_cast<const u32x4*>(a_qs)[ri];
+  const int bs = a_bsums[ri];
+  const float dv = a_d[ri >> 4];
+  // ---- 2. the descriptor, this workgroup's share, the first row group's steps 0 and 1 ----
+  const int rloc = lane >> LL, sub = lane & ((1 << LL) - 1), q = sub & 3;
+  unsigned long long* tl = L.timeline && bid < DSK_TL_WGS ? L.timeline + (size_t)bid * 8 : nullptr;
+  unsigned long long t_staged = 0, t_bar = 0, t_rows = 0;
+  const GemvTask& T = L.t[0];
+  const int nwg = L.grp_wg_end[0], vtotal = T.vrow_end, unit = L.part_unit;
+  const unsigned units = (unsigned)((vtotal + unit - 1) / unit);
+  const int lo = __builtin_amdgcn_readfirstlane((int)(units * (unsigned)bid / (unsigned)nwg) * unit);
+  int hi = __builtin_amdgcn_readfirstlane((int)(units * (unsigned)(bid + 1) / (unsigned)nwg) * unit);
+  if (hi > vtotal) hi = vtotal;
+  WPtr P;
+  P.qs = T.qs; P.sc = T.sc; P.dm = T.dm; P.hm = nullptr; P.qs2 = P.sc2 = P.hm2 = P.dm2 = nullptr; P.scale = P.scale2 = nullptr; P.present = true;
+  const KQRsrc B = kq_rsrc<QT, false>(P);
+  ChunkKQ<QT, 1, 2, false> ca, cb;
+  int row, rowblk[1];
+  bool valid;
+  {
+    const int rr = lo + wave * RPW + rloc;
+    const bool has = lo + wave * RPW < hi;
+    valid = rr < hi;
+    row = valid ? rr : (hi > 0 ? hi - 1 : 0);
+    rowblk[0] = row * nb + (sub >> 2);
+    KQRsrc B0 = B;
+    B0.qs = make_rsrc_n(T.qs, has); B0.sc = make_rsrc_n(T.sc, has); B0.dm = make_rsrc_n(T.dm, has);
+    load_chunk_kq<QT, 1, 2, false>(ca, B0, ITS, ITEMS, sub, LL, q, rowblk, 0);
+  }
+  // ---- 3. the vector into item records (stage_q8, the ready-Q8_K path for LAY_Q2) ----
+  if (tid < (n >> 4)) {
+    const int b = tid >> 4, j = tid & 15, h = j >> 3, sidx = (j >> 1) & 3, lh = j & 1;
+    uint8_t* rec = smem + (size_t)(b * 4 + 2 * h + lh) * ITEM_LDS;
+    *reinterpret_cast<u32x4*>(rec + sidx * 16) = run;
+    rec[64 + sidx] = (uint8_t)(bs >> 8);
+    rec[68 + sidx] = (uint8_t)(bs & 0xff);
+    float* mrec = reinterpret_cast<float*>(rec + 72);
+    mrec[0] = dv * 0.0625f;
+    mrec[1] = dv;
+  }
+  if (tl) t_staged = wall_clock64();
+  lds_barrier();
+  if (tl) t_bar = wall_clock64();
+  // ---- 4. the first row group: steps 2 and 3 requested now, then the four steps multiplied in order ----
+  const uint8_t* lds_lane = smem + sub * ITEM_LDS;
+  float* const out = T.out;
+  const int epi = T.epilogue;
+  {
+    const bool has = lo + wave * RPW < hi;
+    KQRsrc B0 = B;
+    B0.qs = make_rsrc_n(T.qs, has); B0.sc = make_rsrc_n(T.sc, has); B0.dm = make_rsrc_n(T.dm, has);
+    load_chunk_kq<QT, 1, 2, false>(cb, B0, ITS, ITEMS, sub, LL, q, rowblk, 2);
+    float acc[1] = {0.f}, acc2[1] = {0.f};
+    compute_chunk_kq<QT, 1, 2, false>(ca, ITS, ITEMS, sub, LL, q, 0, lds_lane, acc, acc2);
+    compute_chunk_kq<QT, 1, 2, false>(cb, ITS, ITEMS, sub, LL, q, 2, lds_lane, acc, acc2);
+    const float r = lanes_sum(acc[0], LL);
+    if (tl) t_rows = wall_clock64();
+    if (valid && sub == 0) {
+      float* o = out + row;
+      if (epi == EPI_ADD) *o += r;  // residual add, src/infer.cpp:832-834
+      else *o = r;
+    }
+  }
+  // ---- 5. the remaining row groups ----
+  for (int base = lo + RG; base < hi; base += RG) {
+    const int row0 = base + wave * RPW, rr = row0 + rloc;
+    if (row0 >= hi) continue;
+    const bool v2 = rr < hi;
+    const int rw = v2 ? rr : hi - 1;
+    const int rb[1] = {rw * nb + (sub >> 2)};
+    float acc[1], acc2[1];
+    rows_dot_kq_exact<QT, 1, false, ITS, LL>(B, sub, q, rb, lds_lane, acc, acc2);
+    if (v2 && sub == 0) {
+      float* o = out + rw;
+      if (epi == EPI_ADD) *o += acc[0];
+      else *o = acc[0];
+    }
+  }
+  if (tl && tid == 0) {
+    tl[0] = t_entry; tl[6] = t_staged; tl[7] = tl[1] = t_bar; tl[2] = t_rows; tl[3] = wall_clock64();
+  }
+}
+static bool gemv_ahead_q8_ok(const GemvLaunch& h) {
+  if (h.tiled || h.quant != DSK_QUANT_Q2_K || h.glu || h.R != 1 || h.U != 4 || h.NW != 16 || h.n_groups != 1 || h.bd_heads != 0 || h.n_tasks != 1) return false;
+  if (h.comb_x || h.comb_geometry || h.compact_absent || h.zero_absent || h.tap_qs) return false;
+  const GemvTask& T = h.t[0];
+  return T.act_mode == ACT_Q8 && T.n == 16384 && h.lpr_log2 == 6 && T.e_qs == 0 && !T.accum_w && h.grid == h.grp_wg_end[0] && T.vrow_begin == 0;
+}
+// the plans gemv_ahead_kernel runs (set by gemv_plan: GemvLaunch::ahead)
+static bool gemv_ahead_ok(const GemvLaunch& h) {
+  if (h.tiled || h.quant != DSK_QUANT_Q2_K || h.glu || h.R != 1 || h.U != 2 || h.NW != 16 || h.n_groups != 1 || h.bd_heads != 0) return false;
+  if (h.comb_x || h.comb_geometry || h.compact_absent || h.zero_absent || h.n_tasks > 2) return false;
+  const GemvTask& T0 = h.t[0];
+  if (T0.act_mode != ACT_F32_NORM || T0.n != 7168 || h.lpr_log2 != 6) return false;  // (the one instantiation: 112 items at 64 lanes per row)
+  for (int i = 0; i < h.n_tasks; ++i) {
+    const GemvTask& T = h.t[i];
+    if (T.n != T0.n || T.a_f32 != T0.a_f32 || T.norm_w != T0.norm_w || T.act_mode != ACT_F32_NORM || T.e_qs != 0 || T.accum_w) return false;
+  }
+  const int RG = 16 * (64 >> h.lpr_log2);
+  const long vtotal = h.t[h.n_tasks - 1].vrow_end, units = (vtotal + h.part_unit - 1) / h.part_unit;
+  const long per = (units + h.grid - 1) / h.grid * h.part_unit;  // the largest share of a workgroup
+  return h.grid == h.grp_wg_end[0] && per <= RG;
+}
+
 // ------------------------------------------------------------------------------------
 // The router launch with the shared expert riding along (K-quant models, 1 GPU).  The router keeps E / 2 = 128 CUs busy
 // for ~10 us (a latency chain: norm, 7 MB of F32 rows, arrival, gate); the shared expert's w1/w3 GLU depends only on
@@ -1019,6 +1262,16 @@ static void launch_one(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& 
     if (h.lds_bytes > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds_bytes);
     if (g_prof_start && g_prof_stop) hipExtLaunchKernelGGL(k, grid, block, (uint32_t)h.lds_bytes, st, g_prof_start, g_prof_stop, 0u, dev, a0, a1, a2, hn, hm, he, gw, gs);
     else hipLaunchKernelGGL(k, grid, block, h.lds_bytes, st, dev, a0, a1, a2, hn, hm, he, gw, gs);
+  } else if (QT == DSK_QUANT_Q2_K && R == 1 && U == 2 && NW == 16 && (h.ahead & 1) && hn > 0 && hm == ACT_F32_NORM && gemv_ahead_ok(h)) {
+    auto k = gemv_ahead_kernel<112, 6>;
+    if (h.lds_bytes > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds_bytes);
+    if (g_prof_start && g_prof_stop) hipExtLaunchKernelGGL(k, grid, block, (uint32_t)h.lds_bytes, st, g_prof_start, g_prof_stop, 0u, dev, (const float*)a0, (const float*)a1, he);
+    else hipLaunchKernelGGL(k, grid, block, h.lds_bytes, st, dev, (const float*)a0, (const float*)a1, he);
+  } else if (QT == DSK_QUANT_Q2_K && R == 1 && U == 4 && NW == 16 && (h.ahead & 2) && hn > 0 && hm == ACT_Q8 && gemv_ahead_q8_ok(h)) {
+    auto k = gemv_ahead_q8_kernel<256, 6>;
+    if (h.lds_bytes > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds_bytes);
+    if (g_prof_start && g_prof_stop) hipExtLaunchKernelGGL(k, grid, block, (uint32_t)h.lds_bytes, st, g_prof_start, g_prof_stop, 0u, dev, (const int8_t*)a0, (const float*)a1, (const int16_t*)a2);
+    else hipLaunchKernelGGL(k, grid, block, h.lds_bytes, st, dev, (const int8_t*)a0, (const float*)a1, (const int16_t*)a2);
   } else {
     auto k = gemv_kernel<QT, R, U, false, NW>;
     if (h.lds_bytes > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds_bytes);

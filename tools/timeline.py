@@ -8,10 +8,10 @@ import dsk
 from tools import synth
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--layers", type=int, default=8); ap.add_argument("--attn", default="mha"); ap.add_argument("--pos", type=int, default=6); ap.add_argument("--kv", type=int, default=0)
+ap.add_argument("--layers", type=int, default=8); ap.add_argument("--attn", default="mha"); ap.add_argument("--pos", type=int, default=6); ap.add_argument("--kv", type=int, default=0); ap.add_argument("--opt", action="append", default=[])
 a = ap.parse_args()
 c = synth.preset("v3", "q2_k", a.attn == "mla", n_layers=a.layers, max_seq_len=max(64, a.pos + 8, a.kv + 16))
-ctx = dsk.Ctx(0); M = dsk.Model(ctx, c, None, synth_seed=0, options={"timeline": 1})
+ctx = dsk.Ctx(0); M = dsk.Model(ctx, c, None, synth_seed=0, options=dict({"timeline": 1}, **{kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.opt}))
 for pos in range(a.pos):
     M.forward(17 + pos, pos)
 for i in range(4 if a.kv else 0):  # a long context: the cache rows below hold zeros, the kernels stream them all the same
