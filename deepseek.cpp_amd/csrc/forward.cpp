@@ -193,6 +193,7 @@ int build_plans(dsk_model* m) {
       }
       h.algo_bytes = bytes;
       if (c.use_mla && m->ride_kvwrite) h.reserve_wgs = 1;  // the latent's cache write rides as one more workgroup of this launch
+      if (c.use_mla) h.ahead = m->gemv_ahead & 1;            // (gemv_kvwrite_ahead_kernel: the first row group ahead of the staging of q_a)
       DSK_TRY(add_plan(m, h, &m->lp_qkv_b[l]));
       if (!c.use_mla) {  // MHA: the same projections, consumed per head by the fused attention launch
         HeadAttnArgs A;

@@ -507,6 +507,136 @@ static bool gemv_ahead_q8_ok(const GemvLaunch& h) {
   const GemvTask& T = h.t[0];
   return T.act_mode == ACT_Q8 && T.n == 16384 && h.lpr_log2 == 6 && T.e_qs == 0 && !T.accum_w && h.grid == h.grp_wg_end[0] && T.vrow_begin == 0;
 }
+// The MLA path's second-stage launch (wq_rope_b || wc on rmsnorm(q_a): 73 728 rows of 1536 over 255 workgroups = 2-3 row groups of
+// 128 rows each, + the latent's cache write as the last workgroup) in the same order: q_a and its norm weights, the descriptor, the
+// FIRST (task, row group) pair's rows - whole rows: three column steps in one chunk -, the staging with LDS-only barriers, that
+// pair's multiplies; the remaining pairs go through rows_dot_kq like in gemv_body.  Same functions, same step order: same bits.
+template <int ITEMS, int LL>
+__global__ __launch_bounds__(1024) void gemv_kvwrite_ahead_kernel(const GemvLaunch* __restrict__ Lp, const float* __restrict__ x, const float* __restrict__ norm_w,
+                                                                 float eps, const MlaKvArgs kv, const StepParams* __restrict__ sp) {
+  if (blockIdx.x == gridDim.x - 1) {
+    rd::mla_kv_write_body(kv, sp, threadIdx.x, 1024);
+    return;
+  }
+  constexpr int QT = DSK_QUANT_Q2_K, NW = 16, KB1 = 32 / NW, nb = ITEMS / 4, n = nb * 256, ITS = (ITEMS + (1 << LL) - 1) >> LL;
+  constexpr int RPW = 64 >> LL, RG = NW * RPW;
+  static_assert(ITS <= 4 && nb <= 32, "gemv_kvwrite_ahead_kernel: whole rows in one chunk of four column steps");
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ float scratch[16];
+  const GemvLaunch& L = *Lp;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, bid = blockIdx.x;
+  // ---- 1. this wave's blocks of the vector and of the norm weights ----
+  f32x4 t[KB1], wv[KB1];
+#pragma unroll
+  for (int k = 0; k < KB1; ++k) {
+    const int b = wave + NW * k < nb ? wave + NW * k : nb - 1;
+    t[k] = *reinterpret_cast<const f32x4*>(x + b * 256 + lane * 4);
+    wv[k] = *reinterpret_cast<const f32x4*>(norm_w + b * 256 + lane * 4);
+  }
+  // ---- 2. the descriptor, this workgroup's share, the first pair's rows ----
+  const int rloc = lane >> LL, sub = lane & ((1 << LL) - 1), q = sub & 3;
+  const int n_tasks = L.grp_t0[1], nwg = L.grp_wg_end[0];
+  const int vtotal = L.t[n_tasks - 1].vrow_end, unit = L.part_unit;
+  const unsigned units = (unsigned)((vtotal + unit - 1) / unit);
+  const int r_lo = __builtin_amdgcn_readfirstlane((int)(units * (unsigned)bid / (unsigned)nwg) * unit);
+  int r_hi = __builtin_amdgcn_readfirstlane((int)(units * (unsigned)(bid + 1) / (unsigned)nwg) * unit);
+  if (r_hi > vtotal) r_hi = vtotal;
+  const int ti0 = n_tasks > 1 && r_lo >= L.t[1].vrow_begin ? 1 : 0;  // the first task this workgroup's share touches (<= 2 tasks: the planner's check)
+  ChunkKQ<QT, 1, 4, false> c0;
+  int row_a;
+  bool valid_a;
+  {
+    const GemvTask& T = L.t[ti0];
+    const int vb = T.vrow_begin, ve = T.vrow_end;
+    const int lo = (r_lo > vb ? r_lo : vb) - vb, hi = (r_hi < ve ? r_hi : ve) - vb;
+    const int row0 = lo + wave * RPW, rr = row0 + rloc;
+    const bool has = row0 < hi;
+    valid_a = has && rr < hi;
+    row_a = valid_a ? rr : (hi > 0 ? hi - 1 : 0);
+    KQRsrc B;
+    B.qs = make_rsrc_n(T.qs, has); B.sc = make_rsrc_n(T.sc, has); B.dm = make_rsrc_n(T.dm, has);
+    B.hm = B.qs2 = B.sc2 = B.dm2 = B.hm2 = B.qs;
+    const int rowblk[1] = {has ? row_a * nb + (sub >> 2) : 0};
+    load_chunk_kq<QT, 1, 4, false>(c0, B, ITS, ITEMS, sub, LL, q, rowblk, 0);
+  }
+  // ---- 3. rmsnorm + Q8_K into LDS (stage_q8's single-pass path), LDS-only barriers ----
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < KB1; ++k) {
+    if (wave + NW * k < nb) {
+      ss = fmaf(t[k].x, t[k].x, ss);
+      ss = fmaf(t[k].y, t[k].y, ss);
+      ss = fmaf(t[k].z, t[k].z, ss);
+      ss = fmaf(t[k].w, t[k].w, ss);
+    }
+  }
+  ss = wave_sum(ss);
+  if (lane == 0) scratch[wave] = ss;
+  lds_barrier();
+  const float total = scratch_total<NW>(scratch);
+  const float scale = 1.0f / sqrtf(total / (float)n + eps);
+#pragma unroll
+  for (int k = 0; k < KB1; ++k) {
+    const int b = wave + NW * k;
+    if (b < nb) {
+      float v[4] = {t[k].x * scale * wv[k].x, t[k].y * scale * wv[k].y, t[k].z * scale * wv[k].z, t[k].w * scale * wv[k].w};
+      q8k_block_lds<LAY_Q2>(v, lane, smem + (size_t)b * 4 * ITEM_LDS);
+    }
+  }
+  lds_barrier();
+#ifndef DSK_NO_TAPS
+  if (L.tap_qs && bid == 0) {
+    dump_staged_q8<LAY_Q2>(smem, n, L.tap_qs, L.tap_d, tid, NW * 64);
+  }
+#endif
+  // ---- 4. the first pair's multiplies ----
+  const uint8_t* lds_lane = smem + sub * ITEM_LDS;
+  {
+    float acc[1] = {0.f}, acc2[1] = {0.f};
+    compute_chunk_kq<QT, 1, 4, false>(c0, ITS, ITEMS, sub, LL, q, 0, lds_lane, acc, acc2);
+    const float r = lanes_sum(acc[0], LL);
+    if (valid_a && sub == 0) {
+      float* o = L.t[ti0].out + row_a;
+      if (L.t[ti0].epilogue == EPI_ADD) *o += r;
+      else *o = r;
+    }
+  }
+  // ---- 5. the remaining pairs, like gemv_body ----
+  for (int ti = ti0; ti < n_tasks; ++ti) {
+    const GemvTask& T = L.t[ti];
+    const int vb = T.vrow_begin, ve = T.vrow_end;
+    const int lo = (r_lo > vb ? r_lo : vb) - vb, hi = (r_hi < ve ? r_hi : ve) - vb;
+    if (lo >= hi) continue;
+    WPtr P;
+    P.qs = T.qs; P.sc = T.sc; P.dm = T.dm; P.hm = nullptr; P.qs2 = P.sc2 = P.hm2 = P.dm2 = nullptr; P.scale = P.scale2 = nullptr; P.present = true;
+    const KQRsrc B = kq_rsrc<QT, false>(P);
+    for (int base = ti == ti0 ? lo + RG : lo; base < hi; base += RG) {
+      const int row0 = base + wave * RPW, rr = row0 + rloc;
+      if (row0 >= hi) continue;
+      const bool v2 = rr < hi;
+      const int rw = v2 ? rr : hi - 1;
+      const int rb[1] = {rw * nb + (sub >> 2)};
+      float acc[1], acc2[1];
+      rows_dot_kq<QT, 1, 4, false>(B, ITEMS, sub, LL, q, rb, lds_lane, acc, acc2);
+      if (v2 && sub == 0) {
+        float* o = T.out + rw;
+        if (T.epilogue == EPI_ADD) *o += acc[0];
+        else *o = acc[0];
+      }
+    }
+  }
+}
+static bool gemv_kvwrite_ahead_ok(const GemvLaunch& h) {
+  if (h.tiled || h.quant != DSK_QUANT_Q2_K || h.glu || h.R != 1 || h.U != 4 || h.NW != 16 || h.n_groups != 1 || h.bd_heads != 0 || h.timeline) return false;
+  if (h.comb_x || h.comb_geometry || h.compact_absent || h.zero_absent || !(h.ahead & 1) || h.n_tasks > 2) return false;
+  const GemvTask& T0 = h.t[0];
+  if (T0.act_mode != ACT_F32_NORM || T0.n != 1536 || h.lpr_log2 != 3) return false;  // (the one instantiation: 24 items at 8 lanes per row)
+  for (int i = 0; i < h.n_tasks; ++i) {
+    const GemvTask& T = h.t[i];
+    if (T.n != T0.n || T.a_f32 != T0.a_f32 || T.norm_w != T0.norm_w || T.act_mode != ACT_F32_NORM || T.e_qs != 0 || T.accum_w) return false;
+  }
+  return h.grid == h.grp_wg_end[0];
+}
 // the plans gemv_ahead_kernel runs (set by gemv_plan: GemvLaunch::ahead)
 static bool gemv_ahead_ok(const GemvLaunch& h) {
   if (h.tiled || h.quant != DSK_QUANT_Q2_K || h.glu || h.R != 1 || h.U != 2 || h.NW != 16 || h.n_groups != 1 || h.bd_heads != 0) return false;
@@ -1352,6 +1482,12 @@ int launch_gemv_kvwrite(hipStream_t st, const GemvLaunch* dev, const GemvLaunch&
     auto k = gemv_kvwrite_tile_kernel;
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, grid, block, lds, st, dev, a0, a1, a2, T.n, T.act_mode, T.eps, kv, sp);
+    return DSK_OK;
+  }
+  if (gemv_kvwrite_ahead_ok(h)) {
+    auto k = gemv_kvwrite_ahead_kernel<24, 3>;
+    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, grid, block, lds, st, dev, (const float*)a0, (const float*)a1, T.eps, kv, sp);
     return DSK_OK;
   }
 #define KV_LAUNCH(QT, U)                                                                                             \

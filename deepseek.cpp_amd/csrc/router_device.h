@@ -244,14 +244,21 @@ RDEV void router_body(const RouterArgs& a, int bid, int nblocks) {
   const int row = bid * RW + r;
   const int dim = a.dim, E = a.n_routed;
   unsigned long long* tl = a.timeline && bid < DSK_TL_WGS ? a.timeline + (size_t)bid * 8 : nullptr;
-  if (tl && tid == 0) tl[0] = wall_clock64();
+  // (stamps 0 and 1 are kept in registers until the rows are done: a store in flight makes hipcc wait for EVERY outstanding
+  // operation at the next use of a loaded register - here: for the weight rows before the norm could touch x)
+  const unsigned long long t_entry = tl ? wall_clock64() : 0ull;
+  unsigned long long t_scale = 0ull;
   // the gate's bias, requested now by every workgroup: the last arriver would otherwise wait for it (a cold line) behind the scores
   const float bias_v = a.bias && tid < E ? a.bias[tid] : 0.f;
-  // (Measured and rejected: this wave's weight rows - and its slices of x and of the norm weights - requested before the norm
-  // instead of behind it.  128 KB of requests per CU stall the waves in issue until the first of them are back: the norm scale is
-  // known at 3.5 us instead of 1.25, rows done 4.1 -> 4.5, the launch 10.2 -> 10.5 us.)
+  // (Round 5, measured and rejected: this wave's weight rows - and its slices of x and of the norm weights - requested before the
+  // norm instead of behind it.  128 KB of requests per CU stall the waves in issue until the first of them are back: the norm scale
+  // is known at 3.5 us instead of 1.25, rows done 4.1 -> 4.5, the launch 10.2 -> 10.5 us.)
+  // (Round 6, measured and rejected as well: the order that works for the projections (kernels_gemv.hip gemv_ahead_kernel) - x for
+  // the norm FIRST, a request barrier, then 2 or 4 of the wave's weight loads, the norm with LDS-only barriers: the norm scale is
+  // known at 2.9 us instead of 1.4, rows done 4.6 instead of 4.3, the launch 12.8 -> 13.2 us in situ.  Whatever is queued behind
+  // x delays x: 28 KB of x and 57 KB of rows per CU are more than the CU's window, unlike the projections' 19 - 43 KB.)
   const float scale = a.norm_w && !(a.dbg & 4) ? router_norm_scale(a, tid, scratch) : 1.0f;
-  if (tl && tid == 0) tl[1] = wall_clock64();
+  if (tl) t_scale = wall_clock64();
   float acc = 0.f;
   if (row < E && !(a.dbg & 2)) {
     const int chunk = ((dim / 4 + SL - 1) / SL + 63) / 64 * 64 * 4;  // floats per column slice, multiple of 256
@@ -283,6 +290,7 @@ RDEV void router_body(const RouterArgs& a, int bid, int nblocks) {
     }
     acc = wave_sum_dpp(acc);
   }
+  if (tl && tid == 0) { tl[0] = t_entry; tl[1] = t_scale; }
   if (a.q_qs && a.norm_w && wave == 0) {  // Q8_K of rmsnorm(x): block b by workgroup b (src/quant.cpp:616-653)
     for (int b = bid; b < dim / 256; b += nblocks) {
       const f32x4 xv = *reinterpret_cast<const f32x4*>(a.x + b * 256 + lane * 4);
