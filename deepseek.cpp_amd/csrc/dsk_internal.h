@@ -443,6 +443,7 @@ struct MlaKvArgs {
 int launch_mla_kv_write(hipStream_t st, const MlaKvArgs& a, const StepParams* sp);
 // the second-stage projection launch of the MLA path with the cache write as its last workgroup (kernels_gemv.hip)
 bool gemv_kvwrite_supported(const GemvLaunch& h);
+int gemv_ahead_kind(const GemvLaunch& h, bool kvwrite);  // 0 none, 1 first-stage, 2 wo, 3 the MLA second stage (kernels_gemv.hip, round 6)
 int launch_gemv_kvwrite(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& h, const MlaKvArgs& kv, const StepParams* sp);
 struct MlaHeadArgs {
   AttnMlaArgs a;          // q_rope (un-rotated), q_c, caches; out unused

@@ -289,6 +289,15 @@ extern "C" int dsk_model_get_info(dsk_model* m, const char* key, int* value) {
   else if (k == "graph_capture_fallbacks") *value = m->graph_capture_fallbacks;
   else if (k == "hydrate_batched_tokens") *value = (int)std::min<long long>(m->hydrate_batched_tokens, 0x7fffffff);
   else if (k == "hydrate_looped_tokens") *value = (int)std::min<long long>(m->hydrate_looped_tokens, 0x7fffffff);
+  else if (k == "gemv_ahead_plans") {  // launch plans that run a "weights ahead of the staging" kernel (option "gemv_ahead")
+    int n = 0;
+    for (size_t l = 0; l < m->lp_qkv_a.size(); ++l) {
+      if (m->lp_qkv_a[l] >= 0) n += gemv_ahead_kind(m->plans[m->lp_qkv_a[l]], false) != 0;
+      if (m->lp_wo[l] >= 0) n += gemv_ahead_kind(m->plans[m->lp_wo[l]], false) != 0;
+      if (m->c.use_mla && m->ride_kvwrite && m->lp_qkv_b[l] >= 0) n += gemv_ahead_kind(m->plans[m->lp_qkv_b[l]], true) != 0;
+    }
+    *value = n;
+  }
   else if (k == "hydrate_tile_copy_mb") *value = (int)(m->hydrate_tile_copy_bytes / 1048576.0);
   else if (k == "fused_moe_layers") { int n = 0; for (auto& a : m->moe_ffn) n += a.grid > 0; *value = n; }
   else if (k == "graph_captured") { int n = 0; for (auto g : m->graph) n += g != nullptr; *value = n; }

@@ -1470,6 +1470,16 @@ bool gemv_kvwrite_supported(const GemvLaunch& h) {
   const bool kq = h.quant == DSK_QUANT_Q2_K || h.quant == DSK_QUANT_Q3_K;
   return kq && !h.glu && h.n_groups == 1 && h.bd_heads == 0 && h.NW == 16 && h.R == 1 && (h.U == 4 || h.U == 2) && !h.comb_x && !h.timeline;
 }
+// which of the round-6 "weights ahead of the staging" kernels a planned launch runs: 0 none, 1 gemv_ahead_kernel (first-stage
+// projections), 2 gemv_ahead_q8_kernel (wo), 3 gemv_kvwrite_ahead_kernel (the MLA second stage; `kvwrite`: launched with the rider)
+int gemv_ahead_kind(const GemvLaunch& h, bool kvwrite) {
+  if (kvwrite) return gemv_kvwrite_supported(h) && gemv_kvwrite_ahead_ok(h) ? 3 : 0;
+  if (h.NW != 16 || h.R != 1 || h.bd_heads != 0 || h.n_groups != 1) return 0;
+  const GemvTask& T = h.t[h.grp_t0[0]];
+  if (h.U == 2 && (h.ahead & 1) && T.act_mode == ACT_F32_NORM && gemv_ahead_ok(h)) return 1;
+  if (h.U == 4 && (h.ahead & 2) && T.act_mode == ACT_Q8 && gemv_ahead_q8_ok(h)) return 2;
+  return 0;
+}
 int launch_gemv_kvwrite(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& h, const MlaKvArgs& kv, const StepParams* sp) {
   if (!gemv_kvwrite_supported(h)) DSK_FAIL(DSK_ERR_INVALID, "gemv_kvwrite: unsupported plan");
   if (kv.rope > 128 || (kv.rope & 1)) DSK_FAIL(DSK_ERR_UNSUPPORTED, "rope dim %d (max 128, even)", kv.rope);

@@ -150,3 +150,30 @@ def test_synthesized_weights_do_not_depend_on_the_layout(ctx):
     for lo, r in outs[1:]:
         assert np.array_equal(r, outs[0][1])
         assert np.abs(lo - outs[0][0]).max() <= 3e-4 * scale, np.abs(lo - outs[0][0]).max() / scale
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("mla", [False, True], ids=["mha", "mla"])
+def test_weights_requested_ahead_of_the_staging_are_bit_identical(ctx, mla):
+    """Round 6 (kernels_gemv.hip gemv_ahead_kernel / gemv_ahead_q8_kernel / gemv_kvwrite_ahead_kernel, option "gemv_ahead"): the
+    first-stage projections, wo and the MLA second stage request their first weights behind the loads of their vector and ahead
+    of its staging - another ORDER of the same loads and the same multiplies, so every logit and every cache row must keep its
+    bits.  DeepSeek-V3 width (the kernels are instantiated for its row lengths), 1 dense + 2 MoE blocks, eight positions, graph
+    replay; the counter says the kernels actually ran (and that the option turns them off)."""
+    import dsk
+    c = synth.preset("v3", "q2_k", mla, n_layers=3, first_k_dense_replace=1, max_seq_len=64)
+    A = dsk.Model(ctx, c, None, synth_seed=23, options={"gemv_ahead": 0})
+    B = dsk.Model(ctx, c, None, synth_seed=23)
+    assert A.info("gemv_ahead_plans") == 0
+    assert B.info("gemv_ahead_plans") == c.n_layers * (3 if mla else 2)
+    toks = [int(t) for t in np.random.default_rng(2).integers(0, c.vocab_size, 8)]
+    for pos, t in enumerate(toks):
+        la, lb = A.forward(t, pos), B.forward(t, pos)
+        assert np.array_equal(la, lb), pos
+    H, hd, vd = c.n_heads, c.qk_nope_head_dim + c.qk_rope_head_dim, c.v_head_dim
+    for l in range(c.n_layers):
+        names = (("nope_cache", c.kv_lora_rank), ("rope_cache", c.qk_rope_head_dim)) if mla else (("k_cache", H * hd), ("v_cache", H * vd))
+        for name, width in names:
+            assert np.array_equal(A.get_cache_rows(l, name, 0, len(toks), width), B.get_cache_rows(l, name, 0, len(toks), width))
+    A.close()
+    B.close()
