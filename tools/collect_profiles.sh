@@ -25,11 +25,16 @@ $T python tools/timeline.py < /dev/null 2>&1 | grep -v amdgpu.ids > gpurun_out/$
 $T python tools/moe_timeline.py < /dev/null 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_timeline_moe.txt
 # round 5: the floor of a five-launch block on this box; the prompt phase (dsk_hydrate) on the full model and its kernel trace
 timeout 120 tools/_build/block_floor 58 < /dev/null > gpurun_out/${R}_block_floor.txt 2>&1
+# (round 6: the engine's DEFAULT options - the model bench.py times for decode; the batched path on tile copies of the plane matrices;
+# _alltiles: q2k_tiles = 2, the layout whose batched path is bit-identical to the per-token loop)
 $T python tools/hydrate_bench.py --P 16,64,128,256,512 < /dev/null 2>&1 | grep '^{' | tail -1 > gpurun_out/${R}_hydrate.json
+$T python tools/hydrate_bench.py --P 64,512 --opt q2k_tiles=2 < /dev/null 2>&1 | grep '^{' | tail -1 > gpurun_out/${R}_hydrate_alltiles.json
 # uniform routing instead of the synthetic model's skewed one: a measurement knob of -DDSK_AB builds only (tools/ab_build.sh ab "")
 AB=deepseek.cpp_amd/_ab/libdsk_ab.so
 [ -f $AB ] && DSK_LIB=$AB DSK_HYD_ROUTE_SEED=7 $T python tools/hydrate_bench.py --P 16,64,128,256,512 < /dev/null 2>&1 | grep '^{' | tail -1 > gpurun_out/${R}_hydrate_uniform.json
-$T python tools/hydrate_bench.py --attn mla --P 16,64,128,256 < /dev/null 2>&1 | grep '^{' | tail -1 > gpurun_out/${R}_hydrate_mla.json
+# (MLA through the matrix-core regime, round 6: prompts past position 319 batch; 256 tokens at positions 512-767)
+$T python tools/hydrate_bench.py --attn mla --P 16,64,128,256,512,1024 < /dev/null 2>&1 | grep '^{' | tail -1 > gpurun_out/${R}_hydrate_mla.json
+$T python tools/hydrate_bench.py --attn mla --P 256 --pos0 512 --no-loop < /dev/null 2>&1 | grep '^{' | tail -1 > gpurun_out/${R}_hydrate_mla_pos512.json
 [ -f $AB ] && DSK_LIB=$AB DSK_HYD_ROUTE_SEED=7 $T python tools/hydrate_bench.py --attn mla --P 64,128 < /dev/null 2>&1 | grep '^{' | tail -1 > gpurun_out/${R}_hydrate_mla_uniform.json
 cd /tmp
 timeout 240 rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/trace_hyd -- python $ROOT/tools/hydrate_bench.py --P 64 --layers 8 --reps 1 --no-loop < /dev/null > $ROOT/gpurun_out/trace_hyd.log 2>&1
@@ -43,6 +48,9 @@ rm -rf gpurun_out/trace_mha gpurun_out/trace_mla gpurun_out/pmc gpurun_out/pmc_s
 # round 6: the scalar-path publish probe; the experimental schedules of the fused expert launch next to the shipped one (A/B lines + stamps)
 [ -x tools/_build/scalar_store_probe ] && timeout 120 tools/_build/scalar_store_probe < /dev/null 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_scalar_store_probe.txt
 ( $T python tools/moe_ab.py; $T python tools/moe_ab.py --opt moe_pipe=1; $T python tools/moe_ab.py --opt moe_pipe=2; $T python tools/moe_ab.py --attn mla; $T python tools/moe_ab.py --attn mla --opt ride_kvwrite=0 ) < /dev/null 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_ab_moe_pipe.txt
+# round 6, late: the launches that request their first weights ahead of the staging (option gemv_ahead: bits 1 first-stage / MLA second stage, 2 wo)
+( for v in 0 1 3; do $T python tools/moe_ab.py --opt gemv_ahead=$v; done; $T python tools/moe_ab.py --attn mla --opt gemv_ahead=0; $T python tools/moe_ab.py --attn mla --opt gemv_ahead=2; $T python tools/moe_ab.py --attn mla --opt gemv_ahead=3 ) < /dev/null 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_ab_gemv_ahead.txt
+$T python tools/timeline.py --opt gemv_ahead=0 < /dev/null 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_timeline_mha_noahead.txt
 $T python tools/moe_timeline.py --layers 61 --opt moe_pipe=1 < /dev/null 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_timeline_moe_pipe1.txt
 $T python tools/moe_timeline.py --layers 61 --opt moe_pipe=2 < /dev/null 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_timeline_moe_pipe2.txt
 # the whole GPU test-suite and the smoke entry point on the same sources, same box
