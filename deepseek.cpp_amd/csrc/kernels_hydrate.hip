@@ -841,12 +841,25 @@ __global__ __launch_bounds__(256) void hyd_kv_write_kernel(const AttnMhaArgs a, 
 // cost the short-context instantiation a third of its speed - 87 -> 129 us per block at P = 64 - when they were one kernel)
 template <bool SPLIT>
 __global__ __launch_bounds__(1024, 8) void hyd_attn_kernel(const AttnMhaArgs a, const StepParams* __restrict__ sps, const float* __restrict__ q, int q_stride,
-                                                        float* __restrict__ out, int out_stride, int n_split, int split_min) {
+                                                        float* __restrict__ out, int out_stride, int n_split, int split_min, int n_tok) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ float scratch[16];
   __shared__ __attribute__((aligned(16))) float q_s[256];
   __shared__ __attribute__((aligned(16))) float part[4096];
-  const int h = blockIdx.x, p = blockIdx.y, tid = threadIdx.x;
+  // Workgroup -> (head, token).  The hardware deals workgroups to the 8 XCDs round-robin by linear index, and each XCD has its own
+  // L2: with a (head, token) grid a head's K / V rows (up to 640 B x 512 positions) were read by all 8 XCDs for every token - 10.7 GB
+  // per block at P = 512, the launch bound by that (EXPERIMENTS.md 6.4: 1.36 ms of a block's 5).  1-D grid (gridDim.y == 1, n_heads a
+  // multiple of 8): index i lives on XCD i % 8, which walks heads i % 8 + 8 k, for each head its tokens in order - a head's rows
+  // are read from HBM once per chunk and served from ONE L2 for all its tokens.
+  int h, p;
+  if (gridDim.y == 1) {
+    const int i = (int)blockIdx.x, xcd = i & 7, j = i >> 3;
+    const int hh = j / n_tok;
+    h = hh * 8 + xcd; p = j - hh * n_tok;
+  } else {
+    h = blockIdx.x; p = blockIdx.y;
+  }
+  const int tid = threadIdx.x;
   const StepParams* sp = sps + p;
   float* att = reinterpret_cast<float*>(smem);
   const int hd = a.head_dim, nope = a.nope, rope = a.rope, vd = a.v_dim;
@@ -913,7 +926,8 @@ int launch_hyd_attn(hipStream_t st, const AttnMhaArgs& a, const StepParams* sps,
   const bool split = n_split > 1 && max_kv >= split_min;
   auto k = split ? hyd_attn_kernel<true> : hyd_attn_kernel<false>;
   if (lds > 32 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k, dim3(a.n_heads, P), dim3(1024), lds, st, a, sps, q, q_stride, out, out_stride, n_split, split_min);
+  const bool by_xcd = a.n_heads % 8 == 0;  // (see the kernel: one head's tokens on one XCD)
+  hipLaunchKernelGGL(k, by_xcd ? dim3(a.n_heads * P) : dim3(a.n_heads, P), dim3(1024), lds, st, a, sps, q, q_stride, out, out_stride, n_split, split_min, P);
   return DSK_OK;
 }
 
