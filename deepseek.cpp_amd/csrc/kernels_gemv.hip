@@ -410,7 +410,7 @@ template <int ITEMS, int LL>
 __global__ __launch_bounds__(1024) void gemv_ahead_q8_kernel(const GemvLaunch* __restrict__ Lp, const int8_t* __restrict__ a_qs, const float* __restrict__ a_d,
                                                             const int16_t* __restrict__ a_bsums) {
   constexpr int QT = DSK_QUANT_Q2_K, NW = 16, nb = ITEMS / 4, n = nb * 256, ITS = ITEMS >> LL, RPW = 64 >> LL, RG = NW * RPW;
-  static_assert(ITS == 4 && (ITEMS & ((1 << LL) - 1)) == 0 && (n >> 4) <= NW * 64, "gemv_ahead_q8_kernel: four exact column steps, one 16-byte run per thread");
+  static_assert((ITS == 4 || ITS == 1) && (ITEMS & ((1 << LL) - 1)) == 0 && (n >> 4) <= NW * 64, "gemv_ahead_q8_kernel: four (or one) exact column steps, one 16-byte run per thread");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const GemvLaunch& L = *Lp;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, bid = blockIdx.x;
@@ -502,10 +502,12 @@ __global__ __launch_bounds__(1024) void gemv_ahead_q8_kernel(const GemvLaunch* _
   }
 }
 static bool gemv_ahead_q8_ok(const GemvLaunch& h) {
-  if (h.tiled || h.quant != DSK_QUANT_Q2_K || h.glu || h.R != 1 || h.U != 4 || h.NW != 16 || h.n_groups != 1 || h.bd_heads != 0 || h.n_tasks != 1) return false;
+  if (h.tiled || h.quant != DSK_QUANT_Q2_K || h.glu || h.R != 1 || h.NW != 16 || h.n_groups != 1 || h.bd_heads != 0 || h.n_tasks != 1) return false;
   if (h.comb_x || h.comb_geometry || h.compact_absent || h.zero_absent || h.tap_qs) return false;
   const GemvTask& T = h.t[0];
-  return T.act_mode == ACT_Q8 && T.n == 16384 && h.lpr_log2 == 6 && T.e_qs == 0 && !T.accum_w && h.grid == h.grp_wg_end[0] && T.vrow_begin == 0;
+  // the instantiations: DeepSeek-V3's wo (rows of 16384: four steps at 64 lanes per row) and V2-Lite's (rows of 2048: one step at 32)
+  const bool v3 = T.n == 16384 && h.lpr_log2 == 6 && h.U == 4, v2l = T.n == 2048 && h.lpr_log2 == 5 && h.U == 1;
+  return T.act_mode == ACT_Q8 && (v3 || v2l) && T.e_qs == 0 && !T.accum_w && h.grid == h.grp_wg_end[0] && T.vrow_begin == 0;
 }
 // The MLA path's second-stage launch (wq_rope_b || wc on rmsnorm(q_a): 73 728 rows of 1536 over 255 workgroups = 2-3 row groups of
 // 128 rows each, + the latent's cache write as the last workgroup) in the same order: q_a and its norm weights, the descriptor, the
@@ -639,10 +641,13 @@ static bool gemv_kvwrite_ahead_ok(const GemvLaunch& h) {
 }
 // the plans gemv_ahead_kernel runs (set by gemv_plan: GemvLaunch::ahead)
 static bool gemv_ahead_ok(const GemvLaunch& h) {
-  if (h.tiled || h.quant != DSK_QUANT_Q2_K || h.glu || h.R != 1 || h.U != 2 || h.NW != 16 || h.n_groups != 1 || h.bd_heads != 0) return false;
+  if (h.tiled || h.quant != DSK_QUANT_Q2_K || h.glu || h.R != 1 || h.NW != 16 || h.n_groups != 1 || h.bd_heads != 0) return false;
   if (h.comb_x || h.comb_geometry || h.compact_absent || h.zero_absent || h.n_tasks > 2) return false;
   const GemvTask& T0 = h.t[0];
-  if (T0.act_mode != ACT_F32_NORM || T0.n != 7168 || h.lpr_log2 != 6) return false;  // (the one instantiation: 112 items at 64 lanes per row)
+  // the instantiations: DeepSeek-V3 (rows of 7168: 112 items at 64 lanes per row, two column steps) and V2-Lite (rows of 2048: 32 items
+  // at 32 lanes per row, one step)
+  const bool v3 = T0.n == 7168 && h.lpr_log2 == 6 && h.U == 2, v2l = T0.n == 2048 && h.lpr_log2 == 5 && h.U == 1;
+  if (T0.act_mode != ACT_F32_NORM || !(v3 || v2l)) return false;
   for (int i = 0; i < h.n_tasks; ++i) {
     const GemvTask& T = h.t[i];
     if (T.n != T0.n || T.a_f32 != T0.a_f32 || T.norm_w != T0.norm_w || T.act_mode != ACT_F32_NORM || T.e_qs != 0 || T.accum_w) return false;
@@ -1392,13 +1397,13 @@ static void launch_one(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& 
     if (h.lds_bytes > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds_bytes);
     if (g_prof_start && g_prof_stop) hipExtLaunchKernelGGL(k, grid, block, (uint32_t)h.lds_bytes, st, g_prof_start, g_prof_stop, 0u, dev, a0, a1, a2, hn, hm, he, gw, gs);
     else hipLaunchKernelGGL(k, grid, block, h.lds_bytes, st, dev, a0, a1, a2, hn, hm, he, gw, gs);
-  } else if (QT == DSK_QUANT_Q2_K && R == 1 && U == 2 && NW == 16 && (h.ahead & 1) && hn > 0 && hm == ACT_F32_NORM && gemv_ahead_ok(h)) {
-    auto k = gemv_ahead_kernel<112, 6>;
+  } else if (QT == DSK_QUANT_Q2_K && R == 1 && (U == 2 || U == 1) && NW == 16 && (h.ahead & 1) && hn > 0 && hm == ACT_F32_NORM && gemv_ahead_ok(h)) {
+    auto k = U == 2 ? gemv_ahead_kernel<112, 6> : gemv_ahead_kernel<32, 5>;
     if (h.lds_bytes > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds_bytes);
     if (g_prof_start && g_prof_stop) hipExtLaunchKernelGGL(k, grid, block, (uint32_t)h.lds_bytes, st, g_prof_start, g_prof_stop, 0u, dev, (const float*)a0, (const float*)a1, he);
     else hipLaunchKernelGGL(k, grid, block, h.lds_bytes, st, dev, (const float*)a0, (const float*)a1, he);
-  } else if (QT == DSK_QUANT_Q2_K && R == 1 && U == 4 && NW == 16 && (h.ahead & 2) && hn > 0 && hm == ACT_Q8 && gemv_ahead_q8_ok(h)) {
-    auto k = gemv_ahead_q8_kernel<256, 6>;
+  } else if (QT == DSK_QUANT_Q2_K && R == 1 && (U == 4 || U == 1) && NW == 16 && (h.ahead & 2) && hn > 0 && hm == ACT_Q8 && gemv_ahead_q8_ok(h)) {
+    auto k = U == 4 ? gemv_ahead_q8_kernel<256, 6> : gemv_ahead_q8_kernel<32, 5>;
     if (h.lds_bytes > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds_bytes);
     if (g_prof_start && g_prof_stop) hipExtLaunchKernelGGL(k, grid, block, (uint32_t)h.lds_bytes, st, g_prof_start, g_prof_stop, 0u, dev, (const int8_t*)a0, (const float*)a1, (const int16_t*)a2);
     else hipLaunchKernelGGL(k, grid, block, h.lds_bytes, st, dev, (const int8_t*)a0, (const float*)a1, (const int16_t*)a2);
@@ -1476,8 +1481,8 @@ int gemv_ahead_kind(const GemvLaunch& h, bool kvwrite) {
   if (kvwrite) return gemv_kvwrite_supported(h) && gemv_kvwrite_ahead_ok(h) ? 3 : 0;
   if (h.NW != 16 || h.R != 1 || h.bd_heads != 0 || h.n_groups != 1) return 0;
   const GemvTask& T = h.t[h.grp_t0[0]];
-  if (h.U == 2 && (h.ahead & 1) && T.act_mode == ACT_F32_NORM && gemv_ahead_ok(h)) return 1;
-  if (h.U == 4 && (h.ahead & 2) && T.act_mode == ACT_Q8 && gemv_ahead_q8_ok(h)) return 2;
+  if ((h.ahead & 1) && T.act_mode == ACT_F32_NORM && gemv_ahead_ok(h)) return 1;
+  if ((h.ahead & 2) && T.act_mode == ACT_Q8 && gemv_ahead_q8_ok(h)) return 2;
   return 0;
 }
 int launch_gemv_kvwrite(hipStream_t st, const GemvLaunch* dev, const GemvLaunch& h, const MlaKvArgs& kv, const StepParams* sp) {

@@ -153,15 +153,15 @@ def test_synthesized_weights_do_not_depend_on_the_layout(ctx):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("mla", [False, True], ids=["mha", "mla"])
-def test_weights_requested_ahead_of_the_staging_are_bit_identical(ctx, mla):
+@pytest.mark.parametrize("model,mla", [("v3", False), ("v3", True), ("v2lite", False)], ids=["v3-mha", "v3-mla", "v2lite-mha"])
+def test_weights_requested_ahead_of_the_staging_are_bit_identical(ctx, model, mla):
     """Round 6 (kernels_gemv.hip gemv_ahead_kernel / gemv_ahead_q8_kernel / gemv_kvwrite_ahead_kernel, option "gemv_ahead"): the
     first-stage projections, wo and the MLA second stage request their first weights behind the loads of their vector and ahead
     of its staging - another ORDER of the same loads and the same multiplies, so every logit and every cache row must keep its
-    bits.  DeepSeek-V3 width (the kernels are instantiated for its row lengths), 1 dense + 2 MoE blocks, eight positions, graph
-    replay; the counter says the kernels actually ran (and that the option turns them off)."""
+    bits.  DeepSeek-V3 and DeepSeek-V2-Lite width (the kernels are instantiated for their row lengths), 1 dense + 2 MoE blocks,
+    eight positions, graph replay; the counter says the kernels actually ran (and that the option turns them off)."""
     import dsk
-    c = synth.preset("v3", "q2_k", mla, n_layers=3, first_k_dense_replace=1, max_seq_len=64)
+    c = synth.preset(model, "q2_k", mla, n_layers=3, first_k_dense_replace=1, max_seq_len=64)
     A = dsk.Model(ctx, c, None, synth_seed=23, options={"gemv_ahead": 0})
     B = dsk.Model(ctx, c, None, synth_seed=23)
     assert A.info("gemv_ahead_plans") == 0
