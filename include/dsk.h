@@ -215,13 +215,18 @@ int dsk_model_destroy(dsk_model* m);
  *   "hydrate_tile_copies" 1  at "q2k_tiles" = 1 the first batched dsk_hydrate call may copy the plane-layout matrices it multiplies
  *                        into tile records (0: no copies - such a model then runs the loop)
  *   "hydrate_tap_layer" -1  parity harness: copy block l's stages of every batched chunk aside for dsk_hydrate_get_buffer
+ *   "gemv_ahead"      3  bits: 1 the first-stage projection launch (and the MLA second stage), 2 wo request their first weights
+ *                        behind the loads of their vector and AHEAD of its staging (kernels_gemv.hip gemv_ahead_kernel & co;
+ *                        bit-identical to 0; instantiated for the DeepSeek-V3 and V2-Lite row lengths, other shapes run the plain
+ *                        kernel); get_info "gemv_ahead_plans" counts the launch plans that run such a kernel
  *   "moe_pipe"        0  experimental schedules of the fused expert launch (1: slot halves with service waves, 2: staged second
  *                        half; bit-identical to 0 and slower on MI355X: EXPERIMENTS.md 6.1-6.2) */
 int dsk_model_set_option(dsk_model* m, const char* key, int value);
 /* Read-only counters: "handoff_fallbacks" (times a hand-off give-up moved the model to the two-launch form; the token
  * that hit it was re-run transparently), "fused_moe_layers", "graph_captured", "exchange_calls" (RCCL collectives this
  * model has enqueued eagerly), "tiled_tensors" (weight tensors held as tile records, option "q2k_tiles"),
- * "hydrate_batched_tokens" / "hydrate_looped_tokens", "hydrate_tile_copy_mb" (MiB of tile copies the batched prompt path holds). */
+ * "hydrate_batched_tokens" / "hydrate_looped_tokens", "hydrate_tile_copy_mb" (MiB of tile copies the batched prompt path holds),
+ * "gemv_ahead_plans". */
 int dsk_model_get_info(dsk_model* m, const char* key, int* value);
 /* models created on the context and not yet destroyed (a context destroyed while models are alive is freed by the last
  * dsk_model_destroy) */
