@@ -360,6 +360,32 @@ extern "C" int dsk_plan_gemv(int quant, int rows, int n, int n_tasks, int kind, 
   return DSK_OK;
 }
 
+// Which "weights ahead of the staging" kernel (kernels_gemv.hip, round 6) the engine runs for such a launch at its default options:
+// 0 none (gemv_kernel), 1 gemv_ahead_kernel, 2 gemv_ahead_q8_kernel, 3 gemv_kvwrite_ahead_kernel (kvwrite != 0: the MLA second-stage
+// launch with its cache-write rider).  Host only, like dsk_plan_gemv, whose arguments it shares.
+extern "C" int dsk_plan_gemv_ahead(int quant, int rows, int n, int n_tasks, int kind, int act_mode, int kvwrite, int* ahead_kind) {
+  if (!ahead_kind || rows < 1 || n < 1 || n_tasks < 1 || n_tasks > GEMV_MAX_TASKS) DSK_FAIL(DSK_ERR_INVALID, "plan_gemv_ahead: bad argument");
+  GemvLaunch h;
+  memset(&h, 0, sizeof h);
+  h.quant = quant; h.glu = kind == 1; h.act = DSK_ACT_SILU; h.b0 = h.b1 = 128;
+  h.ahead = 3;
+  if (kvwrite) h.reserve_wgs = 1;
+  static float dummy_x[4], dummy_res[4];
+  static unsigned dummy_cnt[4];
+  static int8_t dummy_q[4];
+  for (int i = 0; i < n_tasks; ++i) {
+    GemvTask& T = h.t[h.n_tasks++];
+    T.qs = T.sc = T.hm = T.dm = reinterpret_cast<const uint8_t*>(dummy_q);
+    if (kind == 1) T.qs2 = T.sc2 = T.hm2 = T.dm2 = T.qs;
+    T.rows = rows; T.n = n; T.local_experts = 1; T.act_mode = act_mode;
+    T.a_qs = dummy_q; T.a_f32 = dummy_x + (kind >= 2 ? i : 0); T.norm_w = dummy_x; T.eps = 1e-6f;
+  }
+  if (kind >= 2) { h.comb_x = dummy_res; h.comb_counter = dummy_cnt; }
+  DSK_TRY(gemv_plan(h, 1024));
+  *ahead_kind = gemv_ahead_kind(h, kvwrite != 0);
+  return DSK_OK;
+}
+
 extern "C" int dsk_bench_gemv(dsk_ctx* ctx, int quant, int rows, int n, int n_tasks, int kind, int act_mode, int force_lpr,
                               int force_R, int force_U, int target_wgs, int iters, double* us_per_launch, double* bytes_per_launch) {
   DSK_TRY(begin(ctx));
@@ -402,6 +428,7 @@ extern "C" int dsk_bench_gemv(dsk_ctx* ctx, int quant, int rows, int n, int n_ta
     h.quant = quant; h.glu = kind == 1; h.act = DSK_ACT_SILU;
     h.tiled = W[0].t.tiled;
     h.b0 = h.b1 = 128; h.force_lpr = force_lpr; h.force_R = force_R; h.force_U = force_U;
+    h.ahead = dsk_ab_env("DSK_NO_AHEAD") ? 0 : 3;  // the engine's default: where a plan fits an ahead kernel (kernels_gemv.hip) the op-level timing runs it too
     if (h.tiled) { h.force_NW = force_R; h.force_U = target_wgs > 8 ? target_wgs : 0; }  // tiled launches: R -> waves per workgroup, target_wgs -> workgroups
     if (dsk_ab_env("DSK_FORCE_NW")) h.force_NW = atoi(dsk_ab_env("DSK_FORCE_NW"));  // tuning knob of tools/kbench.py
     for (int i = 0; i < n_tasks; ++i) {

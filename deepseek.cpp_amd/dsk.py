@@ -162,6 +162,16 @@ def plan_gemv(quant: int, rows: int, n: int, n_tasks: int = 1, kind: int = 0, ac
     return dict(zip(keys, list(out)))
 
 
+def plan_gemv_ahead(quant: int, rows: int, n: int, n_tasks: int = 1, kind: int = 0, act_mode: int = 2, kvwrite: bool = False) -> int:
+    """Which 'weights ahead of the staging' kernel the engine runs for that launch (include/dsk.h dsk_plan_gemv_ahead; host only):
+    0 none, 1 gemv_ahead_kernel, 2 gemv_ahead_q8_kernel, 3 gemv_kvwrite_ahead_kernel."""
+    out = C.c_int(0)
+    f = lib().dsk_plan_gemv_ahead
+    f.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_int)]
+    check(f(quant, rows, n, n_tasks, kind, act_mode, int(kvwrite), C.byref(out)))
+    return out.value
+
+
 
 def _f(a):
     return a.ctypes.data_as(c_f)

@@ -423,6 +423,11 @@ int dsk_time_kernel_class(dsk_model* m, const char* name, int pos, int reps, dou
  * tiled layout (option "q2k_tiles"): out[0..2] are placeholders, out[7] = item partials a round of strips holds in LDS.
  * tests/test_host_logic.py pins the choices for the DeepSeek-V3 shapes. */
 int dsk_plan_gemv(int quant, int rows, int n, int n_tasks, int kind, int act_mode, int target_wgs, int* out);
+/* ... and which of the round-6 "weights requested ahead of the staging" kernels the engine runs for that launch at its default
+ * options (kernels_gemv.hip): 0 none, 1 gemv_ahead_kernel (f32 + rmsnorm vector, rows of <= 2 column steps), 2 gemv_ahead_q8_kernel
+ * (ready Q8_K vector), 3 gemv_kvwrite_ahead_kernel (kvwrite != 0: the MLA second-stage launch with its cache-write rider).
+ * tests/test_host_logic.py pins the DeepSeek-V3 / V2-Lite launches that qualify. */
+int dsk_plan_gemv_ahead(int quant, int rows, int n, int n_tasks, int kind, int act_mode, int kvwrite, int* ahead_kind);
 
 /* Diagnostics: time the GEMV kernel on device-resident synthetic weights (rotated through > 512 MB
  * so that the Infinity Cache cannot serve them).  kind: 0 plain, 1 GLU pair, 2 MoE accumulate over

@@ -134,3 +134,30 @@ def test_launch_planner_choices_for_the_deepseek_v3_shapes():
         dsk.plan_gemv(Q2, 64, 300)
     with pytest.raises(dsk.DskError):
         dsk.plan_gemv(Q2, 64, 7168, 13)  # more tasks than a launch descriptor holds
+
+
+def test_which_launches_request_their_weights_ahead_of_the_staging():
+    """Round 6 (kernels_gemv.hip, option "gemv_ahead"): which planned launches run one of the "weights ahead of the staging"
+    kernels at the engine's default options - host logic like the planner itself (gemv_ahead_kind behind dsk_plan_gemv_ahead), so a
+    change of the planner's rules that silently sends the first-stage projections or wo back to the plain kernel shows up here."""
+    import dsk
+    Q2, Q3, F8 = 3, 4, 2
+    ahead = dsk.plan_gemv_ahead
+    # DeepSeek-V3: first-stage projections (wq_a || wkv_a: 2112 rows of 7168 on rmsnorm(x)), wo (7168 x 16384 on the ready Q8_K
+    # vector), the MLA second stage (wq_rope_b || wc: 73 728 rows of 1536 on rmsnorm(q_a), launched with the cache-write rider)
+    assert ahead(Q2, 2112, 7168, 1, 0, 2) == 1
+    assert ahead(Q2, 1536, 7168, 1, 0, 2) == 1 and ahead(Q2, 576, 7168, 1, 0, 2) == 1
+    assert ahead(Q2, 7168, 16384, 1, 0, 0) == 2
+    assert ahead(Q2, 73728, 1536, 1, 0, 2, True) == 3
+    # DeepSeek-V2-Lite: wq || wkv_a (3648 rows of 2048) and wo (2048 x 2048)
+    assert ahead(Q2, 3648, 2048, 1, 0, 2) == 1
+    assert ahead(Q2, 2048, 2048, 1, 0, 0) == 2
+    # what does NOT qualify runs gemv_kernel: other quants, GLU pairs, the fused combine, rows of more column steps, a workgroup share
+    # of more than one (f32 vector) or two (Q8_K vector) row groups, the MLA launch without its rider's plan
+    assert ahead(Q3, 2112, 7168, 1, 0, 2) == 0 and ahead(F8, 2112, 7168, 1, 0, 2) == 0
+    assert ahead(Q2, 18432, 7168, 1, 1, 2) == 0            # dense w1 / w3: a GLU pair
+    assert ahead(Q2, 7168, 2048, 9, 3, 1) == 0             # the two-launch experts' W2 with the fused combine
+    assert ahead(Q2, 129280, 7168, 1, 0, 2) == 0           # the classifier: 16 lanes per row, seven column steps
+    assert ahead(Q2, 7168, 18432, 1, 0, 0) == 0            # dense w2: rows of 18432
+    assert ahead(Q2, 24576, 1536, 1, 0, 2) == 0            # the MHA second stage is consumed per head, not launched like this
+    assert ahead(Q2, 65536, 7168, 1, 0, 2) == 0            # a share of many row groups per workgroup
